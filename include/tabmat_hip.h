@@ -1,0 +1,250 @@
+/*
+ * tabmat_hip.h -- C ABI of libtabmat_hip.so: the MI355X (gfx950) implementation of
+ * tabmat's sandwich / matvec / transpose-matvec hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one native loop that
+ * Quantco/tabmat's Cython layer (src/tabmat/ext/*.pyx) binds; the reference
+ * interface it stands in for is cited per function (paths relative to the
+ * reference repository).  Signatures are plain C: raw pointers and sizes, no
+ * torch / numpy types.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE (HBM) pointer unless its name starts with h_.
+ *     Block storage (X, CSR/CSC arrays, category codes) is uploaded once by the
+ *     host side and stays resident; per-call vectors (d, v, rows, cols) and the
+ *     outputs are device buffers too.
+ *   - F is float (_f32) or double (_f64).  Sparse blocks use int32 column/row
+ *     indices and int64 indptr on the device (the host side narrows/widens the
+ *     int32-or-int64 arrays the reference accepts, ext/sparse.pyx:13-15).
+ *   - rows == NULL means "all n rows" (n_rows is then ignored);
+ *     cols == NULL means "all columns".  Index lists hold unique entries, as in
+ *     the reference (dense_matrix.py:208).  d / v are always indexed by ORIGINAL
+ *     row / column id (dense_helpers-tmpl.cpp:224).
+ *   - order_f: 0 = C-contiguous (row-major), 1 = F-contiguous (column-major).
+ *   - *_sandwich functions OVERWRITE out (the reference's wrappers hand the
+ *     kernels a zeroed out and accumulate; here the zeroing is part of the call).
+ *     *_matvec / *_rmatvec / *_transpose_matvec functions ACCUMULATE (out += ...),
+ *     as the reference's in-place kernels do (ext/categorical.pyx:23-180,
+ *     ext/sparse.pyx:79-103).
+ *   - stream is a hipStream_t passed as void* (NULL = the null stream).  Calls are
+ *     asynchronous with respect to the host; results are ordered on the stream.
+ *   - Return value: 0 on success, a negative TM_E* code or a positive hipError_t
+ *     otherwise; tm_last_error() returns a message for the calling thread.
+ *     (The reference's kernels return void and cannot fail; all argument
+ *     validation stays in the host language, util.py:27-67.)
+ *   - Scratch: kernels use a per-device workspace owned by the library
+ *     (grown on demand with hipMalloc), or caller memory given with
+ *     tm_set_workspace().  Calls that share a workspace must be stream-ordered.
+ */
+#ifndef TABMAT_HIP_H
+#define TABMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_OK 0
+#define TM_EINVAL (-1)   /* bad argument */
+#define TM_ENOMEM (-2)   /* workspace / allocation failure */
+#define TM_EUNSUPPORTED (-3)
+
+/* ---- runtime / memory helpers (for hosts that do not bring their own allocator) ---- */
+int tm_version(void);
+const char *tm_last_error(void);
+int tm_device_count(int *count);
+int tm_set_device(int device);
+int tm_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+int tm_malloc(void **ptr, size_t bytes);
+int tm_free(void *ptr);
+int tm_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream);
+int tm_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream);
+int tm_memset(void *dst, int value, size_t bytes, void *stream);
+int tm_stream_synchronize(void *stream);
+/* Give the library caller-owned scratch for the current device (ptr == NULL: go back
+ * to the internal allocation). */
+int tm_set_workspace(void *ptr, size_t bytes);
+/* ---- event helpers so a ctypes host can time kernels on the launch stream ---- */
+int tm_event_create(void **event);
+int tm_event_destroy(void *event);
+int tm_event_record(void *event, void *stream);
+int tm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+
+/* =====================================================================================
+ * Dense block  (reference: ext/dense.pyx + ext/dense_helpers-tmpl.cpp)
+ * ===================================================================================== */
+
+/* out[Ci,Cj] = sum_{k in rows} X[k,cols[Ci]] * d[k] * X[k,cols[Cj]];  out is
+ * [n_cols x n_cols] row-major, full symmetric matrix.
+ * Replaces _dense{C,F}_sandwich<int,F> (ext/dense_helpers-tmpl.cpp:266-311) as bound by
+ * dense_sandwich (ext/dense.pyx:19-44).  MFMA row-weighted syrk. */
+int tm_dense_sandwich_f32(const float *X, int64_t n, int64_t m, int order_f, const float *d,
+                          const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                          int64_t n_cols, float *out, void *stream);
+int tm_dense_sandwich_f64(const double *X, int64_t n, int64_t m, int order_f, const double *d,
+                          const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                          int64_t n_cols, double *out, void *stream);
+
+/* out[Ci] += sum_{Cj} X[rows[Ci], cols[Cj]] * v[cols[Cj]]   (v has length m).
+ * Replaces _dense{C,F}_matvec (ext/dense_helpers-tmpl.cpp:385-417; ext/dense.pyx:76-101) and,
+ * with rows == cols == NULL, the BLAS gemv of dense_matrix.py:212-217. */
+int tm_dense_matvec_f32(const float *X, int64_t n, int64_t m, int order_f, const float *v,
+                        const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                        int64_t n_cols, float *out, void *stream);
+int tm_dense_matvec_f64(const double *X, int64_t n, int64_t m, int order_f, const double *v,
+                        const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                        int64_t n_cols, double *out, void *stream);
+
+/* out[Cj] += sum_{Ci} X[rows[Ci], cols[Cj]] * v[rows[Ci]]   (v has length n; out length n_cols).
+ * Replaces _dense{C,F}_rmatvec (ext/dense_helpers-tmpl.cpp:314-383; ext/dense.pyx:48-73) and the
+ * unrestricted X.T.dot(v). */
+int tm_dense_rmatvec_f32(const float *X, int64_t n, int64_t m, int order_f, const float *v,
+                         const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                         int64_t n_cols, float *out, void *stream);
+int tm_dense_rmatvec_f64(const double *X, int64_t n, int64_t m, int order_f, const double *v,
+                         const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                         int64_t n_cols, double *out, void *stream);
+
+/* =====================================================================================
+ * Sparse block  (reference: ext/sparse.pyx + ext/sparse_helpers-tmpl.cpp)
+ * Only the CSR twin (sparse_matrix.py:133-143) lives on the device:
+ * (csr_data[nnz], csr_indices[nnz] int32, csr_indptr[n+1] int64), indices sorted per row.
+ * ===================================================================================== */
+
+/* out = A[rows,cols]^T diag(d) A[rows,cols], [n_cols x n_cols] row-major, full symmetric.
+ * Replaces sparse_sandwich (ext/sparse.pyx:17-77).  Row-streaming over the CSR twin. */
+int tm_sparse_sandwich_f32(const float *csr_data, const int32_t *csr_indices,
+                           const int64_t *csr_indptr, int64_t n, int64_t m, const float *d,
+                           const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                           int64_t n_cols, float *out, void *stream);
+int tm_sparse_sandwich_f64(const double *csr_data, const int32_t *csr_indices,
+                           const int64_t *csr_indptr, int64_t n, int64_t m, const double *d,
+                           const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                           int64_t n_cols, double *out, void *stream);
+
+/* out[nA x nB] = A[rows,A_cols]^T diag(d) B[rows,B_cols]; A sparse (CSR, n x m), B dense (n x r).
+ * Replaces _csr_dense{C,F}_sandwich (ext/sparse_helpers-tmpl.cpp:23-146) as bound by
+ * csr_dense_sandwich (ext/sparse.pyx:211-260). */
+int tm_csr_dense_sandwich_f32(const float *csr_data, const int32_t *csr_indices,
+                              const int64_t *csr_indptr, int64_t n, int64_t m, const float *B,
+                              int64_t r, int order_f, const float *d, const int32_t *rows,
+                              int64_t n_rows, const int32_t *A_cols, int64_t nA,
+                              const int32_t *B_cols, int64_t nB, float *out, void *stream);
+int tm_csr_dense_sandwich_f64(const double *csr_data, const int32_t *csr_indices,
+                              const int64_t *csr_indptr, int64_t n, int64_t m, const double *B,
+                              int64_t r, int order_f, const double *d, const int32_t *rows,
+                              int64_t n_rows, const int32_t *A_cols, int64_t nA,
+                              const int32_t *B_cols, int64_t nB, double *out, void *stream);
+
+/* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
+ * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
+int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,
+                      const int64_t *csr_indptr, int64_t n, int64_t m, const float *v,
+                      const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                      float *out, void *stream);
+int tm_csr_matvec_f64(const double *csr_data, const int32_t *csr_indices,
+                      const int64_t *csr_indptr, int64_t n, int64_t m, const double *v,
+                      const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                      double *out, void *stream);
+
+/* out[Cj] += sum_{i in rows} X[i, cols[Cj]] * v[i]      (v length n; out length n_cols).
+ * Replaces csc_rmatvec_unrestricted / csc_rmatvec (ext/sparse.pyx:142-199).  The reference
+ * walks CSC columns; on the GPU the CSR twin is streamed row by row (the order rows are
+ * sharded in) and the <= few-thousand output columns are LDS-privatised bins. */
+int tm_csr_rmatvec_f32(const float *csr_data, const int32_t *csr_indices,
+                       const int64_t *csr_indptr, int64_t n, int64_t m, const float *v,
+                       const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                       float *out, void *stream);
+int tm_csr_rmatvec_f64(const double *csr_data, const int32_t *csr_indices,
+                       const int64_t *csr_indptr, int64_t n, int64_t m, const double *v,
+                       const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                       double *out, void *stream);
+
+/* =====================================================================================
+ * Categorical block  (reference: ext/categorical.pyx, ext/split.pyx,
+ * ext/cat_split_helpers-tmpl.cpp).  codes[n] int32: -1 = missing (contributes nothing);
+ * with drop_first the column of code c is c-1 and code 0 contributes nothing
+ * (cat_split_helpers-tmpl.cpp:24-28,68-81,127-129).  n_cols = #categories - drop_first.
+ * ===================================================================================== */
+
+/* out[c] += sum_{i in rows, col(i)==c, c in cols} v[i]; out has length n_cols (full block
+ * width); with cols != NULL only the listed entries are touched.
+ * Replaces _transpose_matvec_all_rows_{fast,complex} (cat_split_helpers-tmpl.cpp:4-41) and the
+ * restricted loops of transpose_matvec_{fast,complex} (ext/categorical.pyx:23-117); also
+ * sandwich_categorical_{fast,complex} (ext/categorical.pyx:183-218) with v = d. */
+int tm_cat_transpose_matvec_f32(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                                const float *v, const int32_t *rows, int64_t n_rows,
+                                const int32_t *cols, int64_t n_cols_sel, float *out,
+                                void *stream);
+int tm_cat_transpose_matvec_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                                const double *v, const int32_t *rows, int64_t n_rows,
+                                const int32_t *cols, int64_t n_cols_sel, double *out,
+                                void *stream);
+
+/* out[i] += v[col(i)] for every row i whose column is in cols (v has length n_cols).
+ * Replaces matvec_{fast,complex} (ext/categorical.pyx:128-180). */
+int tm_cat_matvec_f32(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                      const float *v, const int32_t *cols, int64_t n_cols_sel, float *out,
+                      void *stream);
+int tm_cat_matvec_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                      const double *v, const int32_t *cols, int64_t n_cols_sel, double *out,
+                      void *stream);
+
+/* out[i_ncol x j_ncol] (row-major): out[col_i(k), col_j(k)] = sum_{k in rows} d[k].
+ * Replaces _sandwich_cat_cat_{fast,complex} (cat_split_helpers-tmpl.cpp:44-94) as bound by
+ * sandwich_cat_cat (ext/split.pyx:83-111). */
+int tm_cat_cat_sandwich_f32(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                            const float *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                            int64_t j_ncol, int i_drop_first, int j_drop_first, float *out,
+                            void *stream);
+int tm_cat_cat_sandwich_f64(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                            const double *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                            int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
+                            void *stream);
+
+/* out[i_ncol x n_j] (row-major): out[col(k), jc] = sum_{k in rows} d[k] * M[k, j_cols[jc]].
+ * Replaces _sandwich_cat_dense{C,F}_{fast,complex} (cat_split_helpers-tmpl.cpp:97-151) as bound
+ * by sandwich_cat_dense (ext/split.pyx:32-80). */
+int tm_cat_dense_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                              const float *d, const int32_t *rows, int64_t n_rows, const float *M,
+                              int64_t M_ncol, int order_f, const int32_t *j_cols, int64_t n_j,
+                              float *out, void *stream);
+int tm_cat_dense_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                              const double *d, const int32_t *rows, int64_t n_rows,
+                              const double *M, int64_t M_ncol, int order_f, const int32_t *j_cols,
+                              int64_t n_j, double *out, void *stream);
+
+/* out[i_ncol x n_cols] (row-major): out[col(k), Cj] = sum_{k in rows} d[k] * S[k, cols[Cj]],
+ * S sparse given by its CSR twin.  The reference has no kernel here: CategoricalMatrix.
+ * _cross_sparse (categorical_matrix.py:825-838) builds a scipy CSR of diag(d)*onehot and calls
+ * scipy.sparse matmul; this entry point is that product. */
+int tm_cat_sparse_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                               const float *csr_data, const int32_t *csr_indices,
+                               const int64_t *csr_indptr, int64_t s_ncol, const float *d,
+                               const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, float *out, void *stream);
+int tm_cat_sparse_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                               const double *csr_data, const int32_t *csr_indices,
+                               const int64_t *csr_indptr, int64_t s_ncol, const double *d,
+                               const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, double *out, void *stream);
+
+/* =====================================================================================
+ * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block
+ * result into the float64 p x p output at the block's global column positions,
+ *   out[ri[a], ci[b]] = src[a, b]  (and the transpose when mirror != 0);
+ * diag != 0: src is a length-nr vector added to out[ri[a], ri[a]].
+ * ===================================================================================== */
+int tm_scatter_block_f32(const float *src, int64_t nr, int64_t nc, const int64_t *ri,
+                         const int64_t *ci, double *out, int64_t p, int mirror, int diag,
+                         void *stream);
+int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_t *ri,
+                         const int64_t *ci, double *out, int64_t p, int mirror, int diag,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TABMAT_HIP_H */

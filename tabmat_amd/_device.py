@@ -1,0 +1,94 @@
+"""Device plumbing: torch is used ONLY for HBM allocation, host<->device copies, the
+current HIP stream and (in distributed.py) the RCCL process group.  All arithmetic on
+the hot path happens in libtabmat_hip.so."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_FSUF = {torch.float32: "f32", torch.float64: "f64"}
+_NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.TabmatHipError(
+            "tabmat_amd needs a ROCm GPU (MI355X): there is no CPU fallback for the "
+            "sandwich / matvec path"
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def is_dev(x) -> bool:
+    return isinstance(x, torch.Tensor)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def fsuf(t: torch.Tensor) -> str:
+    try:
+        return _FSUF[t.dtype]
+    except KeyError:
+        raise TypeError(f"only float32/float64 are supported on the device, got {t.dtype}")
+
+
+def torch_dtype(np_dtype) -> torch.dtype:
+    try:
+        return _NP2T[np.dtype(np_dtype)]
+    except KeyError:
+        raise TypeError(f"only float32/float64 are supported on the device, got {np_dtype}")
+
+
+def to_dev(x, dtype=None) -> torch.Tensor:
+    """numpy / torch -> contiguous torch cuda tensor (no copy when already there)."""
+    dev = require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x if x.is_cuda else x.to(dev)
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()
+    a = np.ascontiguousarray(x)
+    if not a.flags.writeable:
+        a = a.copy()  # torch.from_numpy refuses read-only buffers (reference accepts them)
+    t = torch.from_numpy(a).to(dev)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t
+
+
+def idx_dev(idx, dtype=torch.int32) -> Optional[torch.Tensor]:
+    """Row / column list -> int32 device tensor (None stays None = "all")."""
+    if idx is None:
+        return None
+    if isinstance(idx, torch.Tensor):
+        return to_dev(idx, dtype)
+    return to_dev(np.asarray(idx).astype(np.int64 if dtype == torch.int64 else np.int32), dtype)
+
+
+def p(t: Optional[torch.Tensor]) -> Optional[int]:
+    """device pointer for ctypes (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def nlen(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else int(t.numel())
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy()
+
+
+def zeros(shape, dtype) -> torch.Tensor:
+    return torch.zeros(shape, dtype=dtype, device=require_gpu())
+
+
+def empty(shape, dtype) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=require_gpu())

@@ -1,0 +1,563 @@
+// Categorical-block kernels for gfx950: the weighted-histogram family.
+//
+//   K4a/K4b  transpose_matvec / sandwich diagonal : res[col(k)]            += v[k]
+//   K4c      cat x cat cross sandwich             : res[col_i(k),col_j(k)] += d[k]
+//   K4d      cat x dense cross sandwich           : res[col(k), :]         += d[k] * M[k, :]
+//   cat x sparse cross sandwich                   : res[col(k), :]         += d[k] * S[k, :]
+//   K4e      matvec (gather)                      : out[k]                 += v[col(k)]
+//
+// Reference loops: ext/cat_split_helpers-tmpl.cpp:4-151, ext/categorical.pyx:23-218,
+// categorical_matrix.py:825-838.  The reference privatises the output per OpenMP thread and
+// merges; here the output (or a category-range slice of it that fits the CU's 160 KB LDS) is
+// privatised per workgroup in LDS, updated with ds_add (wavefront atomics), written to the
+// workspace and combined by reduce_partials_kernel.  Where the output does not fit LDS it is
+// split by CATEGORY RANGE across blockIdx.y ("parts"): every part scans the 4-byte codes of
+// its rows but touches the wide operand (dense row / sparse row) only for rows whose category
+// falls in its range, so the wide operand is still read exactly once from HBM.
+#include <algorithm>
+
+#include "common.hpp"
+#include "reduce.hpp"
+
+namespace tmh {
+
+__global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void scatter_iota_i32_kernel(int32_t *map, const int32_t *cols, int64_t n_cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cols) map[cols[i]] = (int32_t)i;
+}
+
+int build_col_map(int32_t *map, int64_t m, const int32_t *cols, int64_t n_cols, hipStream_t st) {
+    if (m > 0) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, map,
+                           m, -1);
+        TM_LAUNCH_CHECK();
+    }
+    if (n_cols > 0) {
+        hipLaunchKernelGGL(scatter_iota_i32_kernel, dim3((unsigned)ceil_div(n_cols, 256)),
+                           dim3(256), 0, st, map, cols, n_cols);
+        TM_LAUNCH_CHECK();
+    }
+    return TM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1-D / 2-D weighted histogram with LDS-privatised bins.
+//   TWO = false: bin = col(codes_i[k])                       (optionally masked by col_map)
+//   TWO = true : bin = (col_i(k) - i0) * j_ncol + col_j(k)   for col_i in [i0, i0 + ti)
+// Each block owns rows [blockIdx.x * rows_per_block, ...) of the (possibly restricted) row
+// list and the category range of part blockIdx.y.  LDS bins are flushed to
+// ws[part][blockIdx.x][stride].
+// ---------------------------------------------------------------------------------------
+template <typename F, bool TWO>
+__global__ __launch_bounds__(1024) void hist_lds_kernel(
+    const int32_t *__restrict__ ci, const int32_t *__restrict__ cj, const F *__restrict__ w,
+    const int32_t *__restrict__ rows, int64_t n_iter, int64_t rows_per_block, int drop_i,
+    int drop_j, int i_ncol, int j_ncol, int ti, const int32_t *__restrict__ col_map,
+    F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *bins = reinterpret_cast<F *>(smem_raw);
+    const int part = blockIdx.y;
+    const int i0 = part * ti;
+    const int i1 = min(i0 + ti, i_ncol);
+    const int nbins = TWO ? (i1 - i0) * j_ncol : (i1 - i0);
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) bins[b] = F(0);
+    __syncthreads();
+
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const int64_t k = rows ? (int64_t)rows[t] : t;
+        const int c = ci[k] - drop_i;
+        if (c < i0 || c >= i1) continue;
+        if (TWO) {
+            const int c2 = cj[k] - drop_j;
+            if (c2 < 0) continue;
+            atomic_add(&bins[(c - i0) * j_ncol + c2], w[k]);
+        } else {
+            if (col_map && col_map[c] < 0) continue;
+            atomic_add(&bins[c - i0], w[k]);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) dst[b] = bins[b];
+}
+
+// Fallback when one category row of bins does not fit LDS: global atomics into `out`.
+template <typename F, bool TWO>
+__global__ __launch_bounds__(256) void hist_global_kernel(
+    const int32_t *__restrict__ ci, const int32_t *__restrict__ cj, const F *__restrict__ w,
+    const int32_t *__restrict__ rows, int64_t n_iter, int drop_i, int drop_j, int j_ncol,
+    const int32_t *__restrict__ col_map, F *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_iter; t += stride) {
+        const int64_t k = rows ? (int64_t)rows[t] : t;
+        const int c = ci[k] - drop_i;
+        if (c < 0) continue;
+        if (TWO) {
+            const int c2 = cj[k] - drop_j;
+            if (c2 < 0) continue;
+            atomic_add(&out[(int64_t)c * j_ncol + c2], w[k]);
+        } else {
+            if (col_map && col_map[c] < 0) continue;
+            atomic_add(&out[c], w[k]);
+        }
+    }
+}
+
+constexpr size_t HIST_LDS_MAX = 128 * 1024;
+
+// Generic driver.  For !TWO: out[i_ncol] (accumulate or overwrite).  For TWO: out[i_ncol*j_ncol].
+template <typename F, bool TWO>
+static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int32_t *rows,
+                    int64_t n_iter, int drop_i, int drop_j, int64_t i_ncol, int64_t j_ncol,
+                    const int32_t *col_map, F *out, bool accumulate, hipStream_t st) {
+    const int64_t total = TWO ? i_ncol * j_ncol : i_ncol;
+    if (total == 0) return TM_OK;
+    if (!accumulate) TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    if (n_iter == 0) return TM_OK;
+    const size_t row_bytes = sizeof(F) * (size_t)(TWO ? j_ncol : 1);
+    if (row_bytes > HIST_LDS_MAX || i_ncol > (int64_t)INT32_MAX / (TWO ? j_ncol : 1)) {
+        const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256 * 4), 2048);
+        hipLaunchKernelGGL((hist_global_kernel<F, TWO>), dim3((unsigned)nblk), dim3(256), 0, st, ci,
+                           cj, w, rows, n_iter, drop_i, drop_j, (int)j_ncol, col_map, out);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
+    int64_t ti = std::min<int64_t>(i_ncol, (int64_t)(HIST_LDS_MAX / row_bytes));
+    const int64_t n_parts = ceil_div(i_ncol, ti);
+    if (n_parts > 64) {  // too many passes over the codes: global atomics instead
+        const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256 * 4), 2048);
+        hipLaunchKernelGGL((hist_global_kernel<F, TWO>), dim3((unsigned)nblk), dim3(256), 0, st, ci,
+                           cj, w, rows, n_iter, drop_i, drop_j, (int)j_ncol, col_map, out);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
+    ti = ceil_div(i_ncol, n_parts);  // balance the parts
+    const int64_t stride = ti * (TWO ? j_ncol : 1);
+    const size_t lds = (size_t)stride * sizeof(F);
+    const int threads = lds > 64 * 1024 ? 1024 : 512;
+    const int blocks_per_cu = lds > 64 * 1024 ? 1 : 2;
+    int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / n_parts);
+    nblk = std::min<int64_t>(nblk, ceil_div(n_iter, threads * 4));
+    const int64_t rows_per_block = ceil_div(n_iter, nblk);
+    nblk = ceil_div(n_iter, rows_per_block);
+    void *wsv = nullptr;
+    int rc = get_workspace(sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+    if (rc) return rc;
+    F *ws = reinterpret_cast<F *>(wsv);
+    if (lds > 48 * 1024) {
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_lds_kernel<F, TWO>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL((hist_lds_kernel<F, TWO>), dim3((unsigned)nblk, (unsigned)n_parts),
+                       dim3(threads), lds, st, ci, cj, w, rows, n_iter, rows_per_block, drop_i,
+                       drop_j, (int)i_ncol, (int)j_ncol, (int)ti, col_map, ws, stride);
+    TM_LAUNCH_CHECK();
+    return launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, out, total, accumulate,
+                                     st);
+}
+
+// ---------------------------------------------------------------------------------------
+// K4e gather
+// ---------------------------------------------------------------------------------------
+template <typename F>
+__global__ __launch_bounds__(256) void cat_matvec_kernel(const int32_t *__restrict__ codes,
+                                                         int64_t n, int drop_first,
+                                                         const F *__restrict__ v,
+                                                         const int32_t *__restrict__ col_map,
+                                                         F *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = codes[i] - drop_first;
+        if (c >= 0 && (!col_map || col_map[c] >= 0)) out[i] += v[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4d  cat x dense:   tile[col(k) - i0][jc] += d[k] * M[k, j_cols[jc]]
+// Workgroup = 256 threads; LDS tile = ti x n_j.  C-ordered M: a wave scans 64 codes at a time,
+// ballots the rows that fall in this part's category range and then streams each selected row
+// of M with all 64 lanes (coalesced 512 B / 1 KB segments).  F-ordered M: lane <-> row, loop
+// over columns (coalesced along the rows of one column).
+// ---------------------------------------------------------------------------------------
+template <typename F, bool ORDER_F>
+__global__ __launch_bounds__(256) void cat_dense_kernel(
+    const int32_t *__restrict__ codes, const F *__restrict__ d, const int32_t *__restrict__ rows,
+    int64_t n_iter, int64_t rows_per_block, int drop_first, int i_ncol, int ti,
+    const F *__restrict__ M, int64_t M_nrow, int64_t M_ncol, const int32_t *__restrict__ j_cols,
+    int n_j, F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);
+    const int part = blockIdx.y;
+    const int i0 = part * ti;
+    const int i1 = min(i0 + ti, i_ncol);
+    const int nel = (i1 - i0) * n_j;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+
+    for (int64_t base = t0 + (int64_t)wave * 64; base < t1; base += (int64_t)nwave * 64) {
+        const int64_t t = base + lane;
+        int64_t k = 0;
+        int c = -1;
+        F dk = F(0);
+        if (t < t1) {
+            k = rows ? (int64_t)rows[t] : t;
+            c = codes[k] - drop_first;
+            if (c >= i0 && c < i1) dk = d[k];
+            else c = -1;
+        }
+        if (ORDER_F) {
+            if (c >= 0) {
+                F *trow = tile + (c - i0) * n_j;
+                for (int jc = 0; jc < n_j; ++jc) {
+                    const int64_t j = j_cols ? (int64_t)j_cols[jc] : jc;
+                    atomic_add(&trow[jc], dk * M[j * M_nrow + k]);
+                }
+            }
+        } else {
+            unsigned long long mask = __ballot(c >= 0);
+            while (mask) {
+                const int src = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int64_t kk = __shfl(k, src, 64);
+                const int cc = __shfl(c, src, 64);
+                const F dd = __shfl(dk, src, 64);
+                const F *mrow = M + kk * M_ncol;
+                F *trow = tile + (cc - i0) * n_j;
+                for (int jc = lane; jc < n_j; jc += 64) {
+                    const int64_t j = j_cols ? (int64_t)j_cols[jc] : jc;
+                    atomic_add(&trow[jc], dd * mrow[j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+// ---------------------------------------------------------------------------------------
+// cat x sparse:   tile[col(k) - i0][col_map[j]] += d[k] * S[k, j]   over the CSR row of k.
+// G lanes cooperate on one sparse row (G = 64 / rows-per-wave-step, chosen from nnz/row).
+// ---------------------------------------------------------------------------------------
+template <typename F, int G>
+__global__ __launch_bounds__(256) void cat_sparse_kernel(
+    const int32_t *__restrict__ codes, const F *__restrict__ d, const int32_t *__restrict__ rows,
+    int64_t n_iter, int64_t rows_per_block, int drop_first, int i_ncol, int ti,
+    const F *__restrict__ sdata, const int32_t *__restrict__ sind,
+    const int64_t *__restrict__ sptr, const int32_t *__restrict__ col_map, int n_out_cols,
+    F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);
+    const int part = blockIdx.y;
+    const int i0 = part * ti;
+    const int i1 = min(i0 + ti, i_ncol);
+    const int nel = (i1 - i0) * n_out_cols;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+
+    constexpr int RPS = 64 / G;  // rows per wave step
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / G;    // which row of the step
+    const int sl = lane % G;     // lane within the row group
+    const int wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+
+    for (int64_t base = t0 + (int64_t)wave * 64; base < t1; base += (int64_t)nwave * 64) {
+        // scan 64 codes, keep the rows of this part
+        const int64_t t = base + lane;
+        int64_t k = 0;
+        int c = -1;
+        F dk = F(0);
+        if (t < t1) {
+            k = rows ? (int64_t)rows[t] : t;
+            c = codes[k] - drop_first;
+            if (c >= i0 && c < i1) dk = d[k];
+            else c = -1;
+        }
+        unsigned long long mask = __ballot(c >= 0);
+        while (mask) {
+            // each G-lane group takes the next selected row
+            int src = -1;
+            unsigned long long m2 = mask;
+#pragma unroll
+            for (int s = 0; s < RPS; ++s) {
+                if (m2) {
+                    const int b = __builtin_ctzll(m2);
+                    m2 &= m2 - 1;
+                    if (s == sub) src = b;
+                }
+            }
+            mask = m2;
+            const int srcl = src < 0 ? 0 : src;
+            const int64_t kk = __shfl(k, srcl, 64);
+            const int cc = __shfl(c, srcl, 64);
+            const F dd = __shfl(dk, srcl, 64);
+            if (src >= 0) {
+                F *trow = tile + (cc - i0) * n_out_cols;
+                const int64_t p1 = sptr[kk + 1];
+                for (int64_t p = sptr[kk] + sl; p < p1; p += G) {
+                    const int j = sind[p];
+                    const int oc = col_map ? col_map[j] : j;
+                    if (oc >= 0) atomic_add(&trow[oc], dd * sdata[p]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+// common launch geometry for the LDS-tile kernels: returns parts / blocks / strides
+struct TilePlan {
+    int64_t ti, n_parts, nblk, rows_per_block, stride;
+    size_t lds;
+};
+
+static bool plan_tile(int64_t i_ncol, int64_t row_elems, size_t elem_bytes, int64_t n_iter,
+                      int64_t min_rows_per_block, TilePlan *p) {
+    const size_t row_bytes = elem_bytes * (size_t)row_elems;
+    if (row_bytes == 0 || row_bytes > HIST_LDS_MAX) return false;
+    int64_t ti = std::min<int64_t>(i_ncol, (int64_t)(HIST_LDS_MAX / row_bytes));
+    p->n_parts = ceil_div(i_ncol, ti);
+    p->ti = ceil_div(i_ncol, p->n_parts);
+    p->stride = p->ti * row_elems;
+    p->lds = (size_t)p->stride * elem_bytes;
+    const int blocks_per_cu = p->lds > 64 * 1024 ? 1 : 2;
+    int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / p->n_parts);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, min_rows_per_block)));
+    p->rows_per_block = ceil_div(n_iter, nblk);
+    p->nblk = ceil_div(n_iter, p->rows_per_block);
+    return true;
+}
+
+template <typename F>
+static int run_cat_dense(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                         const F *d, const int32_t *rows, int64_t n_rows, const F *M,
+                         int64_t M_ncol, int order_f, const int32_t *j_cols, int64_t n_j, F *out,
+                         hipStream_t st) {
+    const int64_t total = i_ncol * n_j;
+    if (total == 0) return TM_OK;
+    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_iter == 0) return TM_OK;
+    TilePlan p;
+    if (!plan_tile(i_ncol, n_j, sizeof(F), n_iter, 1024, &p)) {
+        set_error("cat_dense_sandwich: %lld selected dense columns exceed the LDS tile",
+                  (long long)n_j);
+        return TM_EUNSUPPORTED;
+    }
+    void *wsv = nullptr;
+    int rc = get_workspace(sizeof(F) * (size_t)(p.n_parts * p.nblk * p.stride) + 256, &wsv);
+    if (rc) return rc;
+    F *ws = reinterpret_cast<F *>(wsv);
+    auto kern = order_f ? &cat_dense_kernel<F, true> : &cat_dense_kernel<F, false>;
+    if (p.lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk, (unsigned)p.n_parts), dim3(256), p.lds, st,
+                       codes, d, rows, n_iter, p.rows_per_block, drop_first, (int)i_ncol,
+                       (int)p.ti, M, n, M_ncol, j_cols, (int)n_j, ws, p.stride);
+    TM_LAUNCH_CHECK();
+    return launch_reduce_partials<F>(ws, p.stride, (int)p.nblk, (int)p.n_parts, out, total, false,
+                                     st);
+}
+
+template <typename F>
+static int run_cat_sparse(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                          const F *sdata, const int32_t *sind, const int64_t *sptr, int64_t s_ncol,
+                          const F *d, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                          int64_t n_cols, F *out, hipStream_t st) {
+    const int64_t n_out = cols ? n_cols : s_ncol;
+    const int64_t total = i_ncol * n_out;
+    if (total == 0) return TM_OK;
+    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_iter == 0) return TM_OK;
+    TilePlan p;
+    if (!plan_tile(i_ncol, n_out, sizeof(F), n_iter, 1024, &p)) {
+        set_error("cat_sparse_sandwich: %lld selected sparse columns exceed the LDS tile",
+                  (long long)n_out);
+        return TM_EUNSUPPORTED;
+    }
+    const size_t map_bytes = cols ? ((sizeof(int32_t) * (size_t)s_ncol + 255) / 256) * 256 : 0;
+    void *wsv = nullptr;
+    int rc = get_workspace(map_bytes + sizeof(F) * (size_t)(p.n_parts * p.nblk * p.stride) + 256,
+                           &wsv);
+    if (rc) return rc;
+    int32_t *col_map = nullptr;
+    if (cols) {
+        col_map = reinterpret_cast<int32_t *>(wsv);
+        rc = build_col_map(col_map, s_ncol, cols, n_cols, st);
+        if (rc) return rc;
+    }
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + map_bytes);
+    auto kern = &cat_sparse_kernel<F, 32>;
+    if (p.lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk, (unsigned)p.n_parts), dim3(256), p.lds, st,
+                       codes, d, rows, n_iter, p.rows_per_block, drop_first, (int)i_ncol,
+                       (int)p.ti, sdata, sind, sptr, col_map, (int)n_out, ws, p.stride);
+    TM_LAUNCH_CHECK();
+    return launch_reduce_partials<F>(ws, p.stride, (int)p.nblk, (int)p.n_parts, out, total, false,
+                                     st);
+}
+
+template <typename F>
+static int run_cat_tmv(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first, const F *v,
+                       const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                       int64_t n_cols_sel, F *out, hipStream_t st) {
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_cols == 0 || n_iter == 0) return TM_OK;
+    if (cols && n_cols_sel == 0) return TM_OK;
+    int32_t *col_map = nullptr;
+    if (cols) {
+        // the col map lives at the END of the workspace so run_hist's partials (which start
+        // at offset 0) cannot overlap it: reserve both up front.
+        void *wsv = nullptr;
+        const size_t map_bytes = ((sizeof(int32_t) * (size_t)n_cols + 255) / 256) * 256;
+        const size_t part_bytes = sizeof(F) * (size_t)(2 * NUM_CU) * (size_t)n_cols + 4096;
+        int rc = get_workspace(part_bytes + map_bytes, &wsv);
+        if (rc) return rc;
+        col_map = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wsv) + part_bytes);
+        rc = build_col_map(col_map, n_cols, cols, n_cols_sel, st);
+        if (rc) return rc;
+    }
+    return run_hist<F, false>(codes, nullptr, v, rows, n_iter, drop_first, 0, n_cols, 1, col_map,
+                              out, true, st);
+}
+
+template <typename F>
+static int run_cat_matvec(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                          const F *v, const int32_t *cols, int64_t n_cols_sel, F *out,
+                          hipStream_t st) {
+    if (n == 0 || n_cols == 0) return TM_OK;
+    if (cols && n_cols_sel == 0) return TM_OK;
+    int32_t *col_map = nullptr;
+    if (cols) {
+        void *wsv = nullptr;
+        int rc = get_workspace(sizeof(int32_t) * (size_t)n_cols + 256, &wsv);
+        if (rc) return rc;
+        col_map = reinterpret_cast<int32_t *>(wsv);
+        rc = build_col_map(col_map, n_cols, cols, n_cols_sel, st);
+        if (rc) return rc;
+    }
+    const int64_t nblk = std::min<int64_t>(ceil_div(n, 256 * 4), NUM_CU * 8);
+    hipLaunchKernelGGL((cat_matvec_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, codes, n,
+                       drop_first, v, col_map, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+#define TM_CHECK_COMMON(nn) \
+    TM_REQUIRE((nn) >= 0, "negative size")
+
+extern "C" {
+
+int tm_cat_transpose_matvec_f32(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                                const float *v, const int32_t *rows, int64_t n_rows,
+                                const int32_t *cols, int64_t n_cols_sel, float *out, void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_tmv<float>(codes, n, n_cols, drop_first, v, rows, n_rows, cols, n_cols_sel, out,
+                              as_stream(stream));
+}
+int tm_cat_transpose_matvec_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                                const double *v, const int32_t *rows, int64_t n_rows,
+                                const int32_t *cols, int64_t n_cols_sel, double *out,
+                                void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_tmv<double>(codes, n, n_cols, drop_first, v, rows, n_rows, cols, n_cols_sel,
+                               out, as_stream(stream));
+}
+
+int tm_cat_matvec_f32(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                      const float *v, const int32_t *cols, int64_t n_cols_sel, float *out,
+                      void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_matvec<float>(codes, n, n_cols, drop_first, v, cols, n_cols_sel, out,
+                                 as_stream(stream));
+}
+int tm_cat_matvec_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                      const double *v, const int32_t *cols, int64_t n_cols_sel, double *out,
+                      void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_matvec<double>(codes, n, n_cols, drop_first, v, cols, n_cols_sel, out,
+                                  as_stream(stream));
+}
+
+int tm_cat_cat_sandwich_f32(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                            const float *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                            int64_t j_ncol, int i_drop_first, int j_drop_first, float *out,
+                            void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_hist<float, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
+                                 j_drop_first, i_ncol, j_ncol, nullptr, out, false,
+                                 as_stream(stream));
+}
+int tm_cat_cat_sandwich_f64(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                            const double *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                            int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
+                            void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_hist<double, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
+                                  j_drop_first, i_ncol, j_ncol, nullptr, out, false,
+                                  as_stream(stream));
+}
+
+int tm_cat_dense_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                              const float *d, const int32_t *rows, int64_t n_rows, const float *M,
+                              int64_t M_ncol, int order_f, const int32_t *j_cols, int64_t n_j,
+                              float *out, void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_dense<float>(codes, n, i_ncol, drop_first, d, rows, n_rows, M, M_ncol, order_f,
+                                j_cols, j_cols ? n_j : M_ncol, out, as_stream(stream));
+}
+int tm_cat_dense_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                              const double *d, const int32_t *rows, int64_t n_rows,
+                              const double *M, int64_t M_ncol, int order_f, const int32_t *j_cols,
+                              int64_t n_j, double *out, void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_dense<double>(codes, n, i_ncol, drop_first, d, rows, n_rows, M, M_ncol, order_f,
+                                 j_cols, j_cols ? n_j : M_ncol, out, as_stream(stream));
+}
+
+int tm_cat_sparse_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                               const float *csr_data, const int32_t *csr_indices,
+                               const int64_t *csr_indptr, int64_t s_ncol, const float *d,
+                               const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, float *out, void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_sparse<float>(codes, n, i_ncol, drop_first, csr_data, csr_indices, csr_indptr,
+                                 s_ncol, d, rows, n_rows, cols, n_cols, out, as_stream(stream));
+}
+int tm_cat_sparse_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,
+                               const double *csr_data, const int32_t *csr_indices,
+                               const int64_t *csr_indptr, int64_t s_ncol, const double *d,
+                               const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, double *out, void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_cat_sparse<double>(codes, n, i_ncol, drop_first, csr_data, csr_indices, csr_indptr,
+                                  s_ncol, d, rows, n_rows, cols, n_cols, out, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Shared host/device helpers for libtabmat_hip.so (gfx950 / CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tabmat_hip.h"
+
+namespace tmh {
+
+constexpr int WAVE = 64;           // CDNA wavefront
+constexpr int NUM_CU = 256;        // MI355X
+constexpr int NUM_XCD = 8;
+constexpr size_t LDS_BYTES = 160 * 1024;
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define TM_HIP(expr)                                                  \
+    do {                                                              \
+        hipError_t _e = (expr);                                       \
+        if (_e != hipSuccess) return tmh::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define TM_LAUNCH_CHECK() TM_HIP(hipGetLastError())
+
+#define TM_REQUIRE(cond, msg)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            tmh::set_error("%s: %s", __func__, msg); \
+            return TM_EINVAL;                 \
+        }                                     \
+    } while (0)
+
+// Per-device scratch.  get_workspace() returns at least `bytes` of device memory that
+// stays valid until the next get_workspace() call on the same device asks for more.
+int get_workspace(size_t bytes, void **ptr);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void atomic_add(F *p, F v) {
+    // -munsafe-fp-atomics: lowers to ds_add_f32/f64 (LDS) or global_atomic_add_f32/f64.
+    atomicAdd(p, v);
+}
+
+template <typename F>
+__device__ __forceinline__ F wave_sum(F v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// column of a categorical code: code - drop_first, negative = contributes nothing
+__device__ __forceinline__ int cat_col(int code, int drop_first) { return code - drop_first; }
+
+}  // namespace tmh

@@ -1,0 +1,664 @@
+// Dense-block kernels for gfx950.
+//
+//   K1  dense sandwich  out = X[rows,cols]^T diag(d[rows]) X[rows,cols]
+//       (reference: ext/dense_helpers-tmpl.cpp:266-311) as an MFMA row-weighted syrk:
+//       every workgroup streams a contiguous slab of rows through LDS (coalesced 16-byte
+//       global loads, double-buffered), each of its 4 waves keeps a fixed subset of the
+//       lower-triangular 16x16 output tiles in MFMA accumulators for the whole slab
+//       (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, K = 4 rows per instruction), and
+//       the per-workgroup partial k x k matrices are summed in a second, deterministic pass.
+//       Only tiles with bj <= bi are computed (the reference's jmaxinner, 148-151).
+//   K5  restricted / unrestricted dense matvec and transpose-matvec
+//       (reference: ext/dense_helpers-tmpl.cpp:314-417 and the BLAS gemv of
+//       dense_matrix.py:212-217): HBM-bound streaming kernels.
+#include <algorithm>
+#include <utility>
+
+#include "common.hpp"
+#include "reduce.hpp"
+
+namespace tmh {
+
+// -------------------------------------------------------------------------------------------
+// MFMA traits.  A/B operands are one element per lane: A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15]; so for X^T D X the fragment of a 16-column block for a group of
+// 4 rows is simply  frag[lane] = X[row0 + (lane>>4)][16*b + (lane&15)]  for both operands
+// (the A side additionally scaled by d[row]).
+// -------------------------------------------------------------------------------------------
+template <typename F>
+struct Mfma;
+
+template <>
+struct Mfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    static __device__ __forceinline__ int crow(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+
+template <>
+struct Mfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+    static __device__ __forceinline__ int crow(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+constexpr int tri_row(int t) {
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    return r;
+}
+
+enum LoadMode { LOAD_C_VEC = 0, LOAD_C_GEN = 1, LOAD_F_GEN = 2 };
+
+// RECT = false: lower-triangular tiles of one NBLK-block panel (syrk proper).
+// RECT = true : the NBLK/2 x NBLK/2 off-diagonal tiles (row blocks NBLK/2.., column blocks
+//               0..NBLK/2-1) of a virtual panel made of two 8-block column panels.
+template <bool RECT, int NBLK>
+constexpr int tile_bi(int t) { return RECT ? NBLK / 2 + t / (NBLK / 2) : tri_row(t); }
+template <bool RECT, int NBLK>
+constexpr int tile_bj(int t) {
+    return RECT ? t % (NBLK / 2) : t - tri_row(t) * (tri_row(t) + 1) / 2;
+}
+
+template <typename F, int NBLK, bool RECT = false>
+struct SyrkCfg {
+    static constexpr int NWAVES = 4;
+    static constexpr int THREADS = NWAVES * 64;
+    static constexpr int W = NBLK * 16;                 // padded number of columns
+    static constexpr int LDW = W + 16;                  // LDS row stride (bank-conflict free)
+    static constexpr int RS = (W * (int)sizeof(F) >= 2048) ? 16 : 32;  // rows per chunk
+    static constexpr int T = RECT ? (NBLK / 2) * (NBLK / 2) : NBLK * (NBLK + 1) / 2;  // tiles
+    static constexpr int MAXT = (T + NWAVES - 1) / NWAVES;
+    static constexpr int VEC = 16 / (int)sizeof(F);
+    static constexpr int ELEMS = RS * W;
+    static constexpr int PER_THREAD = ELEMS / THREADS;  // elements staged per thread (scalar modes)
+    static constexpr int NVEC = ELEMS / VEC;            // 16-byte vectors per chunk
+    static constexpr int VITER = (NVEC + THREADS - 1) / THREADS;
+    static constexpr int NSTAGE = (PER_THREAD > VITER * VEC) ? PER_THREAD : VITER * VEC;
+    static constexpr size_t LDS = sizeof(F) * (size_t)(2 * RS * LDW + 2 * RS);
+};
+
+template <typename F, int NBLK, bool RECT, int WID, int... S>
+__device__ __forceinline__ void syrk_wave_step(
+    const F (&xa)[NBLK], const F (&xb)[NBLK],
+    typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], std::integer_sequence<int, S...>) {
+    using C = SyrkCfg<F, NBLK, RECT>;
+    (([&] {
+         constexpr int t = WID + S * C::NWAVES;
+         if constexpr (t < C::T) {
+             constexpr int bi = tile_bi<RECT, NBLK>(t);
+             constexpr int bj = tile_bj<RECT, NBLK>(t);
+             acc[S] = Mfma<F>::mma(xa[bi], xb[bj], acc[S]);
+         }
+     }()),
+     ...);
+}
+
+template <typename F, int NBLK, bool RECT, int WID, int... S>
+__device__ __forceinline__ void syrk_wave_store(
+    const typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], F *__restrict__ dst,
+    int lane, std::integer_sequence<int, S...>) {
+    using C = SyrkCfg<F, NBLK, RECT>;
+    (([&] {
+         constexpr int t = WID + S * C::NWAVES;
+         if constexpr (t < C::T) {
+#pragma unroll
+             for (int r = 0; r < 4; ++r)
+                 dst[t * 256 + Mfma<F>::crow(lane, r) * 16 + (lane & 15)] = acc[S][r];
+         }
+     }()),
+     ...);
+}
+
+template <typename F, int NBLK, bool RECT, int WID>
+__device__ __forceinline__ void syrk_wave_main(
+    const F *__restrict__ lbuf, const F *__restrict__ dbuf,
+    typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], int lane) {
+    using C = SyrkCfg<F, NBLK, RECT>;
+#pragma unroll 2
+    for (int g = 0; g < C::RS / 4; ++g) {
+        const int rl = 4 * g + (lane >> 4);
+        const F dv = dbuf[rl];
+        const F *lrow = lbuf + rl * C::LDW + (lane & 15);
+        F xa[NBLK], xb[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            xb[b] = lrow[16 * b];
+            xa[b] = dv * xb[b];
+        }
+        syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc,
+                                           std::make_integer_sequence<int, C::MAXT>{});
+    }
+}
+
+// One workgroup: rows [blockIdx.x * rows_per_block, +rows_per_block) of the row list.
+template <typename F, int NBLK, int MODE, bool RECT>
+__global__ __launch_bounds__(256) void syrk_kernel(const F *__restrict__ X, int64_t n, int64_t m,
+                                                   const F *__restrict__ d,
+                                                   const int32_t *__restrict__ rows,
+                                                   int64_t n_iter, int64_t rows_per_block,
+                                                   const int32_t *__restrict__ cols, int n_cols,
+                                                   F *__restrict__ ws) {
+    using C = SyrkCfg<F, NBLK, RECT>;
+    using acc_t = typename Mfma<F>::acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *lds = reinterpret_cast<F *>(smem_raw);            // [2][RS][LDW]
+    F *dl = lds + 2 * C::RS * C::LDW;                    // [2][RS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+    const int nchunk = (int)((t1 - t0 + C::RS - 1) / C::RS);
+
+    acc_t acc[C::MAXT];
+#pragma unroll
+    for (int s = 0; s < C::MAXT; ++s) acc[s] = acc_t{0, 0, 0, 0};
+
+    F stage[C::NSTAGE];
+    F dstage = F(0);
+
+    auto load_chunk = [&](int ch) {
+        const int64_t tb = t0 + (int64_t)ch * C::RS;
+        if (tid < C::RS) {
+            const int64_t t = tb + tid;
+            dstage = F(0);
+            if (t < t1) dstage = d[rows ? (int64_t)rows[t] : t];
+        }
+        if (MODE == LOAD_C_VEC) {
+            // 16-byte vector loads, row-major: q -> (row, vec-column)
+            constexpr int VPR = C::W / C::VEC;
+#pragma unroll
+            for (int i = 0; i < C::VITER; ++i) {
+                const int q = tid + i * C::THREADS;
+                const int r = q / VPR;
+                const int c = (q % VPR) * C::VEC;
+                const int64_t t = tb + r;
+                typedef F vec_t __attribute__((ext_vector_type(C::VEC)));
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) v[e] = F(0);
+                if (q < C::NVEC && t < t1 && c < n_cols) {
+                    const int64_t row = rows ? (int64_t)rows[t] : t;
+                    v = *reinterpret_cast<const vec_t *>(X + row * m + c);
+                }
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
+            }
+        } else if (MODE == LOAD_C_GEN) {
+#pragma unroll
+            for (int i = 0; i < C::PER_THREAD; ++i) {
+                const int q = tid + i * C::THREADS;
+                const int r = q / C::W;
+                const int c = q % C::W;
+                const int64_t t = tb + r;
+                F v = F(0);
+                if (t < t1 && c < n_cols) {
+                    const int64_t row = rows ? (int64_t)rows[t] : t;
+                    const int64_t col = cols ? (int64_t)cols[c] : c;
+                    v = X[row * m + col];
+                }
+                stage[i] = v;
+            }
+        } else {  // LOAD_F_GEN: consecutive threads walk down one column
+#pragma unroll
+            for (int i = 0; i < C::PER_THREAD; ++i) {
+                const int q = tid + i * C::THREADS;
+                const int c = q / C::RS;
+                const int r = q % C::RS;
+                const int64_t t = tb + r;
+                F v = F(0);
+                if (t < t1 && c < n_cols) {
+                    const int64_t row = rows ? (int64_t)rows[t] : t;
+                    const int64_t col = cols ? (int64_t)cols[c] : c;
+                    v = X[col * n + row];
+                }
+                stage[i] = v;
+            }
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        F *lb = lds + buf * C::RS * C::LDW;
+        if (tid < C::RS) dl[buf * C::RS + tid] = dstage;
+        if (MODE == LOAD_C_VEC) {
+            constexpr int VPR = C::W / C::VEC;
+#pragma unroll
+            for (int i = 0; i < C::VITER; ++i) {
+                const int q = tid + i * C::THREADS;
+                const int r = q / VPR;
+                const int c = (q % VPR) * C::VEC;
+                typedef F vec_t __attribute__((ext_vector_type(C::VEC)));
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) v[e] = stage[i * C::VEC + e];
+                if (q < C::NVEC) *reinterpret_cast<vec_t *>(lb + r * C::LDW + c) = v;
+            }
+        } else if (MODE == LOAD_C_GEN) {
+#pragma unroll
+            for (int i = 0; i < C::PER_THREAD; ++i) {
+                const int q = tid + i * C::THREADS;
+                lb[(q / C::W) * C::LDW + (q % C::W)] = stage[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::PER_THREAD; ++i) {
+                const int q = tid + i * C::THREADS;
+                lb[(q % C::RS) * C::LDW + (q / C::RS)] = stage[i];
+            }
+        }
+    };
+
+    if (nchunk > 0) load_chunk(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (ch + 1 < nchunk) load_chunk(ch + 1);
+        const F *lb = lds + buf * C::RS * C::LDW;
+        const F *db = dl + buf * C::RS;
+        // wave-uniform dispatch to the statically scheduled tile set of this wave
+        if (wave == 0) syrk_wave_main<F, NBLK, RECT, 0>(lb, db, acc, lane);
+        else if (wave == 1) syrk_wave_main<F, NBLK, RECT, 1>(lb, db, acc, lane);
+        else if (wave == 2) syrk_wave_main<F, NBLK, RECT, 2>(lb, db, acc, lane);
+        else syrk_wave_main<F, NBLK, RECT, 3>(lb, db, acc, lane);
+    }
+
+    F *dst = ws + (int64_t)blockIdx.x * (C::T * 256);  // [tile][16][16]
+    constexpr auto seq = std::make_integer_sequence<int, C::MAXT>{};
+    if (wave == 0) syrk_wave_store<F, NBLK, RECT, 0>(acc, dst, lane, seq);
+    else if (wave == 1) syrk_wave_store<F, NBLK, RECT, 1>(acc, dst, lane, seq);
+    else if (wave == 2) syrk_wave_store<F, NBLK, RECT, 2>(acc, dst, lane, seq);
+    else syrk_wave_store<F, NBLK, RECT, 3>(acc, dst, lane, seq);
+}
+
+// Sum the per-workgroup partial tiles in fixed order (double accumulation): one block per
+// lower-triangular tile, thread (e, s) sums partials b = s, s + 4, ...
+template <typename F>
+__global__ __launch_bounds__(1024) void syrk_reduce_kernel(const F *__restrict__ part, int nblk,
+                                                           int T, F *__restrict__ tmp) {
+    __shared__ double red[4][256];
+    const int e = threadIdx.x, s = threadIdx.y, t = blockIdx.x;
+    double acc = 0.0;
+    for (int b = s; b < nblk; b += 4) acc += (double)part[((int64_t)b * T + t) * 256 + e];
+    red[s][e] = acc;
+    __syncthreads();
+    if (s == 0) tmp[t * 256 + e] = (F)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+}
+
+// out[pos[i] * ldo + pos[j]] = tile-major tmp at (max(i,j), min(i,j))   (mirror + scatter)
+template <typename F>
+__global__ void syrk_mirror_kernel(const F *__restrict__ tmp, int nv,
+                                   const int32_t *__restrict__ pos, F *__restrict__ out,
+                                   int64_t ldo) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= nv || j >= nv) return;
+    const int hi = max(i, j), lo = min(i, j);
+    const int bi = hi >> 4, bj = lo >> 4;
+    const int t = bi * (bi + 1) / 2 + bj;
+    const int64_t oi = pos ? pos[i] : i;
+    const int64_t oj = pos ? pos[j] : j;
+    out[oi * ldo + oj] = tmp[t * 256 + (hi & 15) * 16 + (lo & 15)];
+}
+
+// RECT result (virtual rows half..half+nb-1 x virtual cols 0..na-1) -> both off-diagonal blocks
+template <typename F>
+__global__ void syrk_rect_scatter_kernel(const F *__restrict__ tmp, int half, int na, int nb,
+                                         const int32_t *__restrict__ pos, F *__restrict__ out,
+                                         int64_t ldo) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // column in panel a
+    const int i = blockIdx.y;                              // row in panel b
+    if (i >= nb || j >= na) return;
+    const int nbh = half >> 4;
+    const int t = (i >> 4) * nbh + (j >> 4);
+    const F v = tmp[t * 256 + (i & 15) * 16 + (j & 15)];
+    const int64_t oi = pos[half + i], oj = pos[j];
+    out[oi * ldo + oj] = v;
+    out[oj * ldo + oi] = v;
+}
+
+template <typename F, int NBLK, bool RECT = false>
+static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d,
+                       const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
+                       const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
+                       hipStream_t st) {
+    using C = SyrkCfg<F, NBLK, RECT>;
+    const int blocks_per_cu = (2 * C::LDS <= LDS_BYTES) ? 2 : 1;
+    int64_t nblk = std::min<int64_t>((int64_t)NUM_CU * blocks_per_cu,
+                                     std::max<int64_t>(1, ceil_div(n_iter, 4 * C::RS)));
+    int64_t rpb = ceil_div(ceil_div(n_iter, nblk), C::RS) * C::RS;
+    nblk = ceil_div(n_iter, rpb);
+    F *part = reinterpret_cast<F *>(wsbase + ws_off);   // [nblk][T][256]
+    F *tmp = part + (size_t)nblk * C::T * 256;          // [T][256]
+    const bool vec_ok = !order_f && cols == nullptr && (m % C::VEC == 0) &&
+                        ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int mode = order_f ? LOAD_F_GEN : (vec_ok ? LOAD_C_VEC : LOAD_C_GEN);
+    auto go = [&](auto kern) -> int {
+        if (C::LDS > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
+                           rows, n_iter, rpb, cols, n_cols, part);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    };
+    int rc;
+    if (mode == LOAD_C_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_C_VEC, RECT>);
+    else if (mode == LOAD_C_GEN) rc = go(&syrk_kernel<F, NBLK, LOAD_C_GEN, RECT>);
+    else rc = go(&syrk_kernel<F, NBLK, LOAD_F_GEN, RECT>);
+    if (rc) return rc;
+    hipLaunchKernelGGL((syrk_reduce_kernel<F>), dim3(C::T), dim3(256, 4), 0, st, part, (int)nblk,
+                       C::T, tmp);
+    TM_LAUNCH_CHECK();
+    if (RECT) {
+        const int half = C::W / 2;
+        hipLaunchKernelGGL((syrk_rect_scatter_kernel<F>),
+                           dim3((unsigned)ceil_div(half, 64), (unsigned)(n_cols - half)), dim3(64), 0,
+                           st, tmp, half, half, n_cols - half, pos, out, ldo);
+    } else {
+        hipLaunchKernelGGL((syrk_mirror_kernel<F>),
+                           dim3((unsigned)ceil_div(n_cols, 64), (unsigned)n_cols), dim3(64), 0, st,
+                           tmp, n_cols, pos, out, ldo);
+    }
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static size_t syrk_ws_bytes(int W) {
+    return sizeof(F) * (size_t)(2 * NUM_CU + 1) * W * W + 4096;
+}
+
+template <typename F>
+static int syrk_dispatch(const F *X, int64_t n, int64_t m, int order_f, const F *d,
+                         const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
+                         const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
+                         hipStream_t st) {
+    if (n_cols <= 16)
+        return launch_syrk<F, 1>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
+                                 wsbase, ws_off, st);
+    if (n_cols <= 32)
+        return launch_syrk<F, 2>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
+                                 wsbase, ws_off, st);
+    if (n_cols <= 64)
+        return launch_syrk<F, 4>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
+                                 wsbase, ws_off, st);
+    if (n_cols <= 128)
+        return launch_syrk<F, 8>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
+                                 wsbase, ws_off, st);
+    if constexpr (sizeof(F) == 4) {
+        return launch_syrk<F, 16>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
+                                  wsbase, ws_off, st);
+    } else {
+        set_error("internal: f64 syrk panel wider than 128 columns");
+        return TM_EINVAL;
+    }
+}
+
+__global__ void iota_or_copy_i32_kernel(int32_t *dst, const int32_t *src, int32_t start, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src ? src[start + i] : start + i;
+}
+
+template <typename F>
+static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, const F *d,
+                              const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                              int64_t n_cols_in, F *out, hipStream_t st) {
+    const int64_t n_cols = cols ? n_cols_in : m;
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_cols == 0) return TM_OK;
+    if (n_iter == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(n_cols * n_cols), st));
+        return TM_OK;
+    }
+    TM_REQUIRE(n_cols < (1 << 20), "too many columns");
+    void *wsv = nullptr;
+    const int direct_max = sizeof(F) == 4 ? 256 : 128;
+    if (n_cols <= direct_max) {
+        const int W = n_cols <= 16 ? 16 : n_cols <= 32 ? 32 : n_cols <= 64 ? 64 : n_cols <= 128 ? 128 : 256;
+        int rc = get_workspace(syrk_ws_bytes<F>(W), &wsv);
+        if (rc) return rc;
+        return syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, cols, (int)n_cols, nullptr, out,
+                                n_cols, reinterpret_cast<char *>(wsv), 0, st);
+    }
+    // wide blocks: 128-column panels.  Diagonal panels are lower-triangular syrks; every panel
+    // pair (a < b) is one rectangular pass over the 256 virtual columns [panel a | panel b].
+    const int PW = 128;
+    const int np = (int)ceil_div(n_cols, PW);
+    const size_t idx_bytes = 4096;  // 2 x 256 int32 (virtual cols, positions) + slack
+    int rc = get_workspace(idx_bytes + syrk_ws_bytes<F>(256), &wsv);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(wsv);
+    int32_t *vcols = reinterpret_cast<int32_t *>(base);
+    int32_t *vpos = vcols + 256;
+    for (int a = 0; a < np; ++a) {
+        const int wa = (int)std::min<int64_t>(PW, n_cols - (int64_t)a * PW);
+        hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vcols, cols, a * PW,
+                           wa);
+        hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos,
+                           (const int32_t *)nullptr, a * PW, wa);
+        TM_LAUNCH_CHECK();
+        rc = syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, vcols, wa, vpos, out, n_cols, base,
+                              idx_bytes, st);
+        if (rc) return rc;
+        for (int b = a + 1; b < np; ++b) {
+            const int wb = (int)std::min<int64_t>(PW, n_cols - (int64_t)b * PW);
+            hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vcols + PW, cols,
+                               b * PW, wb);
+            hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos + PW,
+                               (const int32_t *)nullptr, b * PW, wb);
+            TM_LAUNCH_CHECK();
+            rc = launch_syrk<F, 16, true>(X, n, m, order_f, d, rows, n_iter, vcols, PW + wb, vpos,
+                                          out, n_cols, base, idx_bytes, st);
+            if (rc) return rc;
+        }
+    }
+    return TM_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// K5  matvec / rmatvec
+// -------------------------------------------------------------------------------------------
+// C-order matvec: one wave per output row, lanes stride over the selected columns.
+template <typename F>
+__global__ __launch_bounds__(256) void dense_matvec_c_kernel(
+    const F *__restrict__ X, int64_t m, const F *__restrict__ v, const int32_t *__restrict__ rows,
+    int64_t n_iter, const int32_t *__restrict__ cols, int n_cols, F *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = wave0; t < n_iter; t += nw) {
+        const int64_t row = rows ? (int64_t)rows[t] : t;
+        const F *xr = X + row * m;
+        F acc = F(0);
+        for (int c = lane; c < n_cols; c += 64) {
+            const int64_t j = cols ? (int64_t)cols[c] : c;
+            acc += xr[j] * v[j];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[t] += acc;
+    }
+}
+
+// F-order matvec: one thread per output row.
+template <typename F>
+__global__ __launch_bounds__(256) void dense_matvec_f_kernel(
+    const F *__restrict__ X, int64_t n, const F *__restrict__ v, const int32_t *__restrict__ rows,
+    int64_t n_iter, const int32_t *__restrict__ cols, int n_cols, F *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_iter; t += stride) {
+        const int64_t row = rows ? (int64_t)rows[t] : t;
+        F acc = F(0);
+        for (int c = 0; c < n_cols; ++c) {
+            const int64_t j = cols ? (int64_t)cols[c] : c;
+            acc += X[j * n + row] * v[j];
+        }
+        out[t] += acc;
+    }
+}
+
+// C-order rmatvec: block owns a slab of rows; lane <-> column (64-column tiles), the 4 waves
+// interleave rows; LDS combine, one global atomic per (block, column).
+template <typename F>
+__global__ __launch_bounds__(256) void dense_rmatvec_c_kernel(
+    const F *__restrict__ X, int64_t m, const F *__restrict__ v, const int32_t *__restrict__ rows,
+    int64_t n_iter, int64_t rows_per_block, const int32_t *__restrict__ cols, int n_cols,
+    F *__restrict__ out) {
+    __shared__ F red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+    for (int c0 = 0; c0 < n_cols; c0 += 64) {
+        const int c = c0 + lane;
+        const int64_t j = c < n_cols ? (cols ? (int64_t)cols[c] : c) : 0;
+        F acc = F(0);
+        if (c < n_cols) {
+#pragma unroll 4
+            for (int64_t t = t0 + wave; t < t1; t += 4) {
+                const int64_t row = rows ? (int64_t)rows[t] : t;
+                acc += X[row * m + j] * v[row];
+            }
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c < n_cols)
+            atomic_add(&out[c], (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+        __syncthreads();
+    }
+}
+
+// F-order rmatvec: (column, row-slab) per wave, lanes stride down the column.
+template <typename F>
+__global__ __launch_bounds__(256) void dense_rmatvec_f_kernel(
+    const F *__restrict__ X, int64_t n, const F *__restrict__ v, const int32_t *__restrict__ rows,
+    int64_t n_iter, int64_t rows_per_block, const int32_t *__restrict__ cols, int n_cols,
+    F *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+    for (int c = wave; c < n_cols; c += 4) {
+        const int64_t j = cols ? (int64_t)cols[c] : c;
+        const F *xc = X + j * n;
+        F acc = F(0);
+        for (int64_t t = t0 + lane; t < t1; t += 64) {
+            const int64_t row = rows ? (int64_t)rows[t] : t;
+            acc += xc[row] * v[row];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomic_add(&out[c], acc);
+    }
+}
+
+template <typename F>
+static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const F *v,
+                            const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                            int64_t n_cols_in, F *out, hipStream_t st) {
+    const int64_t n_cols = cols ? n_cols_in : m;
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_iter == 0 || n_cols == 0) return TM_OK;
+    if (order_f) {
+        const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256), NUM_CU * 8);
+        hipLaunchKernelGGL((dense_matvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, n,
+                           v, rows, n_iter, cols, (int)n_cols, out);
+    } else {
+        const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 4), NUM_CU * 8);
+        hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
+                           v, rows, n_iter, cols, (int)n_cols, out);
+    }
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static int run_dense_rmatvec(const F *X, int64_t n, int64_t m, int order_f, const F *v,
+                             const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                             int64_t n_cols_in, F *out, hipStream_t st) {
+    const int64_t n_cols = cols ? n_cols_in : m;
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_iter == 0 || n_cols == 0) return TM_OK;
+    int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 512)), NUM_CU * 4);
+    const int64_t rpb = ceil_div(n_iter, nblk);
+    nblk = ceil_div(n_iter, rpb);
+    if (order_f)
+        hipLaunchKernelGGL((dense_rmatvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X,
+                           n, v, rows, n_iter, rpb, cols, (int)n_cols, out);
+    else
+        hipLaunchKernelGGL((dense_rmatvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X,
+                           m, v, rows, n_iter, rpb, cols, (int)n_cols, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// SplitMatrix assembly scatter (split_matrix.py:341-354)
+// -------------------------------------------------------------------------------------------
+template <typename F>
+__global__ void scatter_block_kernel(const F *__restrict__ src, int64_t nr, int64_t nc,
+                                     const int64_t *__restrict__ ri,
+                                     const int64_t *__restrict__ ci, double *__restrict__ out,
+                                     int64_t p, int mirror, int diag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (diag) {
+        if (e < nr) out[ri[e] * p + ri[e]] += (double)src[e];
+        return;
+    }
+    if (e >= nr * nc) return;
+    const int64_t a = e / nc, b = e % nc;
+    const double v = (double)src[e];
+    out[ri[a] * p + ci[b]] = v;
+    if (mirror) out[ci[b] * p + ri[a]] = v;
+}
+
+template <typename F>
+static int run_scatter(const F *src, int64_t nr, int64_t nc, const int64_t *ri, const int64_t *ci,
+                       double *out, int64_t p, int mirror, int diag, hipStream_t st) {
+    const int64_t total = diag ? nr : nr * nc;
+    if (total == 0) return TM_OK;
+    hipLaunchKernelGGL((scatter_block_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256),
+                       0, st, src, nr, nc, ri, ci, out, p, mirror, diag);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+
+#define TM_DENSE_ENTRY(NAME, F, RUN)                                                              \
+    int NAME(const F *X, int64_t n, int64_t m, int order_f, const F *dv, const int32_t *rows,     \
+             int64_t n_rows, const int32_t *cols, int64_t n_cols, F *out, void *stream) {         \
+        TM_REQUIRE(n >= 0 && m >= 0, "negative shape");                                           \
+        return RUN<F>(X, n, m, order_f, dv, rows, n_rows, cols, n_cols, out, as_stream(stream));  \
+    }
+
+TM_DENSE_ENTRY(tm_dense_sandwich_f32, float, run_dense_sandwich)
+TM_DENSE_ENTRY(tm_dense_sandwich_f64, double, run_dense_sandwich)
+TM_DENSE_ENTRY(tm_dense_matvec_f32, float, run_dense_matvec)
+TM_DENSE_ENTRY(tm_dense_matvec_f64, double, run_dense_matvec)
+TM_DENSE_ENTRY(tm_dense_rmatvec_f32, float, run_dense_rmatvec)
+TM_DENSE_ENTRY(tm_dense_rmatvec_f64, double, run_dense_rmatvec)
+
+int tm_scatter_block_f32(const float *src, int64_t nr, int64_t nc, const int64_t *ri,
+                         const int64_t *ci, double *out, int64_t p, int mirror, int diag,
+                         void *stream) {
+    return run_scatter<float>(src, nr, nc, ri, ci, out, p, mirror, diag, as_stream(stream));
+}
+int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_t *ri,
+                         const int64_t *ci, double *out, int64_t p, int mirror, int diag,
+                         void *stream) {
+    return run_scatter<double>(src, nr, nc, ri, ci, out, p, mirror, diag, as_stream(stream));
+}
+
+}  // extern "C"

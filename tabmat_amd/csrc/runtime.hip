@@ -1,0 +1,177 @@
+// Runtime plumbing of libtabmat_hip.so: error strings, per-device workspace, thin
+// memory / stream / event wrappers so a plain-C host (ctypes, cgo, JNI ...) can drive
+// the kernels without any other HIP binding.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.hpp"
+
+namespace tmh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
+    return (int)e > 0 ? (int)e : TM_EINVAL;
+}
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    bool external = false;
+};
+static Workspace g_ws[64];
+static std::mutex g_ws_mu;
+
+int get_workspace(size_t bytes, void **ptr) {
+    int dev = 0;
+    TM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        set_error("device id %d out of range", dev);
+        return TM_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace &w = g_ws[dev];
+    if (bytes > w.bytes) {
+        if (w.external) {
+            set_error("caller-provided workspace too small: need %zu bytes, have %zu", bytes,
+                      w.bytes);
+            return TM_ENOMEM;
+        }
+        if (w.ptr) {
+            TM_HIP(hipDeviceSynchronize());
+            TM_HIP(hipFree(w.ptr));
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+        size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes + bytes / 4;
+        TM_HIP(hipMalloc(&w.ptr, want));
+        w.bytes = want;
+    }
+    *ptr = w.ptr;
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+
+int tm_version(void) { return 100; }
+
+const char *tm_last_error(void) { return g_err; }
+
+int tm_device_count(int *count) {
+    TM_REQUIRE(count != nullptr, "count is NULL");
+    TM_HIP(hipGetDeviceCount(count));
+    return TM_OK;
+}
+
+int tm_set_device(int device) {
+    TM_HIP(hipSetDevice(device));
+    return TM_OK;
+}
+
+int tm_device_info(char *name, int name_len, int *compute_units, int64_t *hbm_bytes) {
+    int dev = 0;
+    TM_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    TM_HIP(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return TM_OK;
+}
+
+int tm_malloc(void **ptr, size_t bytes) {
+    TM_REQUIRE(ptr != nullptr, "ptr is NULL");
+    TM_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return TM_OK;
+}
+
+int tm_free(void *ptr) {
+    if (ptr) TM_HIP(hipFree(ptr));
+    return TM_OK;
+}
+
+int tm_memcpy_h2d(void *dst, const void *h_src, size_t bytes, void *stream) {
+    TM_HIP(hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return TM_OK;
+}
+
+int tm_memcpy_d2h(void *h_dst, const void *src, size_t bytes, void *stream) {
+    TM_HIP(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    TM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return TM_OK;
+}
+
+int tm_memset(void *dst, int value, size_t bytes, void *stream) {
+    TM_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
+    return TM_OK;
+}
+
+int tm_stream_synchronize(void *stream) {
+    TM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return TM_OK;
+}
+
+int tm_set_workspace(void *ptr, size_t bytes) {
+    int dev = 0;
+    TM_HIP(hipGetDevice(&dev));
+    TM_REQUIRE(dev >= 0 && dev < 64, "device id out of range");
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    Workspace &w = g_ws[dev];
+    if (!w.external && w.ptr) {
+        TM_HIP(hipDeviceSynchronize());
+        TM_HIP(hipFree(w.ptr));
+    }
+    if (ptr) {
+        w.ptr = ptr;
+        w.bytes = bytes;
+        w.external = true;
+    } else {
+        w.ptr = nullptr;
+        w.bytes = 0;
+        w.external = false;
+    }
+    return TM_OK;
+}
+
+int tm_event_create(void **event) {
+    TM_REQUIRE(event != nullptr, "event is NULL");
+    hipEvent_t e;
+    TM_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return TM_OK;
+}
+
+int tm_event_destroy(void *event) {
+    if (event) TM_HIP(hipEventDestroy((hipEvent_t)event));
+    return TM_OK;
+}
+
+int tm_event_record(void *event, void *stream) {
+    TM_HIP(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+    return TM_OK;
+}
+
+int tm_event_elapsed_ms(void *start, void *stop, float *ms) {
+    TM_REQUIRE(ms != nullptr, "ms is NULL");
+    TM_HIP(hipEventSynchronize((hipEvent_t)stop));
+    TM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return TM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,496 @@
+// Sparse-block kernels for gfx950.  All of them stream the CSR twin of the block
+// (sparse_matrix.py:133-143) row by row -- the natural order for row-sharding -- and
+// accumulate into an LDS-privatised slice of the output with wavefront atomics (ds_add),
+// followed by the deterministic reduce_partials pass.
+//
+//   K2  sparse self sandwich   (reference: ext/sparse.pyx:17-77)
+//   K3  sparse x dense cross   (reference: ext/sparse_helpers-tmpl.cpp:23-146)
+//   K6  CSR matvec / transpose-matvec (reference: ext/sparse.pyx:79-199)
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+#include "reduce.hpp"
+
+namespace tmh {
+
+constexpr size_t SP_LDS_MAX = 128 * 1024;
+
+// ---------------------------------------------------------------------------------------
+// K6a  out[Ci] += sum_j X[rows[Ci], j] v[j]   -- G lanes per row
+// ---------------------------------------------------------------------------------------
+template <typename F, int G>
+__global__ __launch_bounds__(256) void csr_matvec_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ v, const int32_t *__restrict__ rows, int64_t n_iter,
+    const int32_t *__restrict__ col_map, F *__restrict__ out) {
+    const int sl = threadIdx.x % G;
+    const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ng = ((int64_t)gridDim.x * blockDim.x) / G;
+    for (int64_t t = g0; t < n_iter; t += ng) {
+        const int64_t row = rows ? (int64_t)rows[t] : t;
+        const int64_t p1 = ptr[row + 1];
+        F acc = F(0);
+        for (int64_t p = ptr[row] + sl; p < p1; p += G) {
+            const int j = ind[p];
+            if (!col_map || col_map[j] >= 0) acc += data[p] * v[j];
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);
+        if (sl == 0) out[t] += acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K6b  out[col_map[j]] += sum_{i in rows} X[i, j] v[i]  -- LDS bins over the output columns
+// ---------------------------------------------------------------------------------------
+template <typename F, int G, bool USE_LDS>
+__global__ __launch_bounds__(256) void csr_rmatvec_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ v, const int32_t *__restrict__ rows, int64_t n_iter,
+    int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out, F *__restrict__ ws,
+    F *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *bins = reinterpret_cast<F *>(smem_raw);
+    if (USE_LDS) {
+        for (int b = threadIdx.x; b < n_out; b += blockDim.x) bins[b] = F(0);
+        __syncthreads();
+    }
+    const int sl = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    constexpr int NG = 256 / G;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+    for (int64_t t = t0 + grp; t < t1; t += NG) {
+        const int64_t row = rows ? (int64_t)rows[t] : t;
+        const F vi = v[row];
+        const int64_t p1 = ptr[row + 1];
+        for (int64_t p = ptr[row] + sl; p < p1; p += G) {
+            const int j = ind[p];
+            const int oc = col_map ? col_map[j] : j;
+            if (oc >= 0) {
+                if (USE_LDS) atomic_add(&bins[oc], data[p] * vi);
+                else atomic_add(&out[oc], data[p] * vi);
+            }
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        F *dst = ws + (int64_t)blockIdx.x * n_out;
+        for (int b = threadIdx.x; b < n_out; b += blockDim.x) dst[b] = bins[b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3 (v1)  tile[col_map_A[i]][jb] += (A[k,i] * d[k]) * B[k, B_cols[j0 + jb]]
+// The output [nA x nB] is split by B-COLUMN ranges of TB columns (parts = blockIdx.y) so that
+// a whole nA x TB slice sits in LDS; SUB = 64 / TB rows are processed per wave step, the
+// TB lanes of a sub-group hold d[k]*B[k, j0 + jb] in a register and walk the sparse row.
+// ---------------------------------------------------------------------------------------
+template <typename F, int TB, bool ORDER_F>
+__global__ __launch_bounds__(256) void csr_dense_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ B, int64_t n, int64_t r, const F *__restrict__ d,
+    const int32_t *__restrict__ rows, int64_t n_iter, int64_t rows_per_block,
+    const int32_t *__restrict__ a_map, int nA, const int32_t *__restrict__ B_cols, int nB,
+    F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [nA][TB]
+    const int part = blockIdx.y;
+    const int j0 = part * TB;
+    const int nel = nA * TB;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+
+    constexpr int SUB = 64 / TB;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / TB;
+    const int jb = lane % TB;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
+    const int jc = j0 + jb;
+    const bool jok = jc < nB;
+    const int64_t jcol = jok ? (B_cols ? (int64_t)B_cols[jc] : jc) : 0;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+
+    for (int64_t base = t0 + (int64_t)wave * SUB; base < t1; base += (int64_t)nwave * SUB) {
+        const int64_t t = base + sub;
+        const bool rok = t < t1;
+        const int64_t k = rok ? (rows ? (int64_t)rows[t] : t) : 0;
+        F bd = F(0);
+        int64_t p = 0, p1 = 0;
+        if (rok) {
+            p = ptr[k];
+            p1 = ptr[k + 1];
+            if (jok) bd = d[k] * (ORDER_F ? B[jcol * n + k] : B[k * r + jcol]);
+        }
+        for (; p < p1; ++p) {
+            const int a = a_map ? a_map[ind[p]] : ind[p];
+            if (a >= 0 && jok) atomic_add(&tile[a * TB + jb], data[p] * bd);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 (v1)  sparse self sandwich.  Output columns (after col_map) are cut into chunks of TS;
+// part (I, J), J <= I, owns the TS x TS tile out[I-chunk, J-chunk] in LDS.  One wave per row:
+// the row's entries are compacted into the A list (columns in chunk I) and the B list (columns
+// in chunk J) in per-wave LDS scratch, then the lanes enumerate the |A| x |B| pairs.
+// For I == J only pairs with colB <= colA are taken (lower triangle incl. diagonal), exactly
+// the `i > j: break` of ext/sparse.pyx:64-67; the mirror happens after the reduction.
+// ---------------------------------------------------------------------------------------
+template <typename F, int TS>
+__global__ __launch_bounds__(256) void sparse_sandwich_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ d, const int32_t *__restrict__ rows, int64_t n_iter,
+    int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out,
+    F *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);                      // [TS][TS]
+    F *sval = tile + TS * TS;                                       // [4 waves][2][64]
+    int *scol = reinterpret_cast<int *>(sval + 4 * 2 * 64);         // [4 waves][2][64]
+    // part -> (I, J), J <= I:  part = I (I + 1) / 2 + J
+    int I = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) - 1.0f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.y) ++I;
+    while (I * (I + 1) / 2 > (int)blockIdx.y) --I;
+    const int J = (int)blockIdx.y - I * (I + 1) / 2;
+    const int i0 = I * TS, j0 = J * TS;
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    F *va = sval + (wave * 2 + 0) * 64, *vb = sval + (wave * 2 + 1) * 64;
+    int *ca = scol + (wave * 2 + 0) * 64, *cb = scol + (wave * 2 + 1) * 64;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_iter);
+
+    for (int64_t t = t0 + wave; t < t1; t += 4) {
+        const int64_t k = rows ? (int64_t)rows[t] : t;
+        const int64_t p0 = ptr[k], p1 = ptr[k + 1];
+        const F dk = d[k];
+        for (int64_t qa = p0; qa < p1; qa += 64) {
+            // compact the A chunk
+            int col = -1;
+            F val = F(0);
+            if (qa + lane < p1) {
+                const int j = ind[qa + lane];
+                col = col_map ? col_map[j] : j;
+                val = data[qa + lane];
+            }
+            const bool inA = col >= i0 && col < i0 + TS;
+            const unsigned long long mA = __ballot(inA);
+            const int na = __popcll(mA);
+            if (na == 0) continue;
+            if (inA) {
+                const int pos = __popcll(mA & lt_mask);
+                ca[pos] = col - i0;
+                va[pos] = val * dk;
+            }
+            for (int64_t qb = p0; qb < p1; qb += 64) {
+                int colb = -1;
+                F valb = F(0);
+                if (qb + lane < p1) {
+                    const int j = ind[qb + lane];
+                    colb = col_map ? col_map[j] : j;
+                    valb = data[qb + lane];
+                }
+                const bool inB = colb >= j0 && colb < j0 + TS;
+                const unsigned long long mB = __ballot(inB);
+                const int nb = __popcll(mB);
+                if (nb == 0) continue;
+                if (inB) {
+                    const int pos = __popcll(mB & lt_mask);
+                    cb[pos] = colb - j0;
+                    vb[pos] = valb;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int npair = na * nb;
+                for (int e = lane; e < npair; e += 64) {
+                    const int a = e / nb;
+                    const int b = e - a * nb;
+                    const int ra = ca[a], rb = cb[b];
+                    if (I != J || rb <= ra) atomic_add(&tile[ra * TS + rb], va[a] * vb[b]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) dst[b] = tile[b];
+}
+
+// out[i][j] (n_out x n_out) from the reduced tile buffer [part][TS*TS]; mirror included.
+template <typename F, int TS>
+__global__ void sparse_sandwich_assemble_kernel(const F *__restrict__ tiles, int n_out, int nchunk,
+                                                F *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= n_out || j >= n_out) return;
+    const int hi = max(i, j), lo = min(i, j);
+    const int I = hi / TS, J = lo / TS;
+    const int part = I * (I + 1) / 2 + J;
+    (void)nchunk;
+    out[(int64_t)i * n_out + j] = tiles[(int64_t)part * TS * TS + (hi % TS) * TS + (lo % TS)];
+}
+
+template <typename F>
+__global__ void untile_kernel(const F *__restrict__ tmp, int64_t nA, int64_t nB, int TB,
+                              F *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nA * nB) return;
+    const int64_t a = e / nB, j = e % nB;
+    out[e] = tmp[((j / TB) * nA + a) * TB + (j % TB)];
+}
+
+// ---------------------------------------------------------------------------------------
+// host drivers
+// ---------------------------------------------------------------------------------------
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+template <typename F>
+static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
+                          int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
+                          const int32_t *cols, int64_t n_cols, F *out, hipStream_t st) {
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_iter == 0 || m == 0) return TM_OK;
+    if (cols && n_cols == 0) return TM_OK;
+    int32_t *col_map = nullptr;
+    if (cols) {
+        void *wsv = nullptr;
+        int rc = get_workspace(align256(sizeof(int32_t) * (size_t)m), &wsv);
+        if (rc) return rc;
+        col_map = reinterpret_cast<int32_t *>(wsv);
+        rc = build_col_map(col_map, m, cols, n_cols, st);
+        if (rc) return rc;
+    }
+    constexpr int G = 16;
+    const int64_t nblk = std::min<int64_t>(ceil_div(n_iter * G, 256), NUM_CU * 16);
+    hipLaunchKernelGGL((csr_matvec_kernel<F, G>), dim3((unsigned)nblk), dim3(256), 0, st, data, ind,
+                       ptr, v, rows, n_iter, col_map, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
+                           int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
+                           const int32_t *cols, int64_t n_cols, F *out, hipStream_t st) {
+    const int64_t n_iter = rows ? n_rows : n;
+    const int64_t n_out = cols ? n_cols : m;
+    if (n_iter == 0 || n_out == 0) return TM_OK;
+    const size_t map_bytes = cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
+    const bool use_lds = sizeof(F) * (size_t)n_out <= SP_LDS_MAX;
+    int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 2048)), NUM_CU * 2);
+    const int64_t rpb = ceil_div(n_iter, nblk);
+    nblk = ceil_div(n_iter, rpb);
+    void *wsv = nullptr;
+    int rc = get_workspace(map_bytes + (use_lds ? sizeof(F) * (size_t)(nblk * n_out) : 0) + 256,
+                           &wsv);
+    if (rc) return rc;
+    int32_t *col_map = nullptr;
+    if (cols) {
+        col_map = reinterpret_cast<int32_t *>(wsv);
+        rc = build_col_map(col_map, m, cols, n_cols, st);
+        if (rc) return rc;
+    }
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + map_bytes);
+    constexpr int G = 16;
+    if (use_lds) {
+        const size_t lds = sizeof(F) * (size_t)n_out;
+        auto kern = &csr_rmatvec_kernel<F, G, true>;
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
+                           n_iter, rpb, col_map, (int)n_out, ws, out);
+        TM_LAUNCH_CHECK();
+        return launch_reduce_partials<F>(ws, n_out, (int)nblk, 1, out, n_out, true, st);
+    }
+    hipLaunchKernelGGL((csr_rmatvec_kernel<F, G, false>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       data, ind, ptr, v, rows, n_iter, rpb, col_map, (int)n_out, ws, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static int run_csr_dense(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
+                         int64_t m, const F *B, int64_t r, int order_f, const F *d,
+                         const int32_t *rows, int64_t n_rows, const int32_t *A_cols, int64_t nA_in,
+                         const int32_t *B_cols, int64_t nB_in, F *out, hipStream_t st) {
+    const int64_t nA = A_cols ? nA_in : m;
+    const int64_t nB = B_cols ? nB_in : r;
+    const int64_t n_iter = rows ? n_rows : n;
+    const int64_t total = nA * nB;
+    if (total == 0) return TM_OK;
+    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    if (n_iter == 0) return TM_OK;
+    // TB: B-columns per part (power of two <= 64) such that nA x TB fits the LDS budget
+    int TB = 64;
+    while (TB > 1 && sizeof(F) * (size_t)nA * TB > SP_LDS_MAX) TB >>= 1;
+    while (TB > 1 && TB / 2 >= nB) TB >>= 1;
+    if (sizeof(F) * (size_t)nA * TB > SP_LDS_MAX) {
+        set_error("csr_dense_sandwich: %lld selected sparse columns exceed the LDS tile",
+                  (long long)nA);
+        return TM_EUNSUPPORTED;
+    }
+    const int64_t n_parts = ceil_div(nB, TB);
+    const int64_t stride = nA * TB;
+    const size_t lds = sizeof(F) * (size_t)stride;
+    const int blocks_per_cu = lds > 64 * 1024 ? 1 : 2;
+    int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / n_parts);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, 512)));
+    const int64_t rpb = ceil_div(n_iter, nblk);
+    nblk = ceil_div(n_iter, rpb);
+    const size_t map_bytes = A_cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
+    void *wsv = nullptr;
+    int rc = get_workspace(map_bytes + tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256,
+                           &wsv);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(wsv);
+    int32_t *a_map = nullptr;
+    if (A_cols) {
+        a_map = reinterpret_cast<int32_t *>(base);
+        rc = build_col_map(a_map, m, A_cols, nA, st);
+        if (rc) return rc;
+    }
+    F *tmp = reinterpret_cast<F *>(base + map_bytes);       // [n_parts][nA][TB]
+    F *ws = reinterpret_cast<F *>(base + map_bytes + tmp_bytes);
+
+    auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data,
+                           ind, ptr, B, n, r, d, rows, n_iter, rpb, a_map, (int)nA, B_cols, (int)nB,
+                           ws, stride);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    };
+#define TM_CSRD_CASE(TBV)                                                   \
+    case TBV:                                                               \
+        rc = order_f ? go(&csr_dense_kernel<F, TBV, true>) : go(&csr_dense_kernel<F, TBV, false>); \
+        break;
+    switch (TB) {
+        TM_CSRD_CASE(64)
+        TM_CSRD_CASE(32)
+        TM_CSRD_CASE(16)
+        TM_CSRD_CASE(8)
+        TM_CSRD_CASE(4)
+        TM_CSRD_CASE(2)
+        TM_CSRD_CASE(1)
+        default:
+            rc = TM_EINVAL;
+    }
+#undef TM_CSRD_CASE
+    if (rc) return rc;
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, tmp, n_parts * stride,
+                                   false, st);
+    if (rc) return rc;
+    // tmp is [part][nA][TB] -> out[nA][nB]
+    hipLaunchKernelGGL((untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, tmp,
+                       nA, nB, TB, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
+                               int64_t m, const F *d, const int32_t *rows, int64_t n_rows,
+                               const int32_t *cols, int64_t n_cols, F *out, hipStream_t st) {
+    const int64_t n_out = cols ? n_cols : m;
+    const int64_t n_iter = rows ? n_rows : n;
+    if (n_out == 0) return TM_OK;
+    if (n_iter == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(n_out * n_out), st));
+        return TM_OK;
+    }
+    constexpr int TS = (sizeof(F) == 8) ? 120 : 176;   // TS*TS*sizeof(F) + scratch <= 128 KB
+    const int nchunk = (int)ceil_div(n_out, TS);
+    const int n_parts = nchunk * (nchunk + 1) / 2;
+    TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
+    const size_t lds = sizeof(F) * (size_t)(TS * TS + 4 * 2 * 64) + sizeof(int) * 4 * 2 * 64;
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, 256)));
+    const int64_t rpb = ceil_div(n_iter, nblk);
+    nblk = ceil_div(n_iter, rpb);
+    const size_t map_bytes = cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
+    const size_t ij_bytes = 0;
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)n_parts * TS * TS);
+    void *wsv = nullptr;
+    int rc = get_workspace(map_bytes + ij_bytes + tmp_bytes +
+                               sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS + 256,
+                           &wsv);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(wsv);
+    int32_t *col_map = nullptr;
+    if (cols) {
+        col_map = reinterpret_cast<int32_t *>(base);
+        rc = build_col_map(col_map, m, cols, n_cols, st);
+        if (rc) return rc;
+    }
+    F *tmp = reinterpret_cast<F *>(base + map_bytes + ij_bytes);
+    F *ws = reinterpret_cast<F *>(base + map_bytes + ij_bytes + tmp_bytes);
+    auto kern = &sparse_sandwich_kernel<F, TS>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data, ind,
+                       ptr, d, rows, n_iter, rpb, col_map, (int)n_out, ws);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,
+                                   (int64_t)n_parts * TS * TS, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sparse_sandwich_assemble_kernel<F, TS>),
+                       dim3((unsigned)ceil_div(n_out, 64), (unsigned)n_out), dim3(64), 0, st, tmp,
+                       (int)n_out, nchunk, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+
+#define TM_CSR_MV_ENTRY(NAME, F, RUN)                                                           \
+    int NAME(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n, int64_t m,       \
+             const F *v, const int32_t *rows, int64_t n_rows, const int32_t *cols,              \
+             int64_t n_cols, F *out, void *stream) {                                            \
+        TM_REQUIRE(n >= 0 && m >= 0, "negative shape");                                         \
+        return RUN<F>(data, ind, ptr, n, m, v, rows, n_rows, cols, n_cols, out,                 \
+                      as_stream(stream));                                                       \
+    }
+
+TM_CSR_MV_ENTRY(tm_csr_matvec_f32, float, run_csr_matvec)
+TM_CSR_MV_ENTRY(tm_csr_matvec_f64, double, run_csr_matvec)
+TM_CSR_MV_ENTRY(tm_csr_rmatvec_f32, float, run_csr_rmatvec)
+TM_CSR_MV_ENTRY(tm_csr_rmatvec_f64, double, run_csr_rmatvec)
+TM_CSR_MV_ENTRY(tm_sparse_sandwich_f32, float, run_sparse_sandwich)
+TM_CSR_MV_ENTRY(tm_sparse_sandwich_f64, double, run_sparse_sandwich)
+
+int tm_csr_dense_sandwich_f32(const float *csr_data, const int32_t *csr_indices,
+                              const int64_t *csr_indptr, int64_t n, int64_t m, const float *B,
+                              int64_t r, int order_f, const float *d, const int32_t *rows,
+                              int64_t n_rows, const int32_t *A_cols, int64_t nA,
+                              const int32_t *B_cols, int64_t nB, float *out, void *stream) {
+    return run_csr_dense<float>(csr_data, csr_indices, csr_indptr, n, m, B, r, order_f, d, rows,
+                                n_rows, A_cols, nA, B_cols, nB, out, as_stream(stream));
+}
+int tm_csr_dense_sandwich_f64(const double *csr_data, const int32_t *csr_indices,
+                              const int64_t *csr_indptr, int64_t n, int64_t m, const double *B,
+                              int64_t r, int order_f, const double *d, const int32_t *rows,
+                              int64_t n_rows, const int32_t *A_cols, int64_t nA,
+                              const int32_t *B_cols, int64_t nB, double *out, void *stream) {
+    return run_csr_dense<double>(csr_data, csr_indices, csr_indptr, n, m, B, r, order_f, d, rows,
+                                 n_rows, A_cols, nA, B_cols, nB, out, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+"""DenseMatrix: a C- or F-contiguous 2-D array resident in HBM (reference:
+/root/reference/src/tabmat/dense_matrix.py).  sandwich -> MFMA row-weighted syrk,
+matvec / transpose_matvec -> streaming gemv kernels (tabmat_amd/csrc/dense.hip)."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+from . import _device as D
+from .ext import dense as xd
+from .ext._types import DenseDev
+from .matrix_base import MatrixBase
+from .util import (
+    check_indexer,
+    check_matvec_dimensions,
+    check_matvec_out_shape,
+    check_sandwich_compatible,
+    check_transpose_matvec_out_shape,
+    normalize_index,
+    np_dtype_of,
+)
+
+
+class DenseMatrix(MatrixBase):
+    """Dense block.  Construct from a numpy array (kept on the host, uploaded lazily on the
+    first product) or from an (n, m) torch cuda tensor (no host copy)."""
+
+    def __init__(self, input_array, column_names=None, term_names=None):
+        self._devblk = None
+        if isinstance(input_array, torch.Tensor):
+            t = input_array.reshape(-1, 1) if input_array.ndim == 1 else input_array
+            if t.ndim != 2:
+                raise ValueError("Input array must be 1- or 2-dimensional")
+            self._array = None
+            self._devblk = DenseDev.from_tensor(D.to_dev(t) if not t.is_cuda else t)
+            self._shape = tuple(t.shape)
+            self._dtype = np_dtype_of(t)
+        else:
+            a = np.asarray(input_array)
+            if a.ndim == 1:
+                a = a.reshape(-1, 1)
+            elif a.ndim > 2:
+                raise ValueError("Input array must be 1- or 2-dimensional")
+            if not (a.flags["C_CONTIGUOUS"] or a.flags["F_CONTIGUOUS"]):
+                # dense_matrix.py:47-58
+                warnings.warn("Input array is not contiguous; making a copy.", UserWarning,
+                              stacklevel=2)
+                a = np.asfortranarray(a)
+            self._array = a
+            self._shape = a.shape
+            self._dtype = a.dtype
+        width = self._shape[1]
+        if column_names is not None and len(column_names) != width:
+            raise ValueError(f"Expected {width} column names, got {len(column_names)}")
+        if term_names is not None and len(term_names) != width:
+            raise ValueError(f"Expected {width} term names, got {len(term_names)}")
+        self._colnames = list(column_names) if column_names is not None else [None] * width
+        self._terms = list(term_names) if term_names is not None else self._colnames
+
+    # ---- storage ------------------------------------------------------------------------
+    def _dev(self) -> DenseDev:
+        if self._devblk is None:
+            self._devblk = DenseDev.from_host(self._array)
+        return self._devblk
+
+    def to_device(self):
+        """Upload now (otherwise the first product does it)."""
+        self._dev()
+        return self
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def ndim(self):
+        return 2
+
+    __array_ufunc__ = None
+
+    def toarray(self) -> np.ndarray:
+        if self._array is None:
+            self._array = D.to_host(self._devblk.as_2d())
+        return self._array
+
+    def unpack(self):
+        return self.toarray()
+
+    def transpose(self):
+        return type(self)(self.toarray().T)
+
+    T = property(transpose)
+
+    def astype(self, dtype, order="K", casting="unsafe", copy=True):
+        return type(self)(self.toarray().astype(dtype, order, casting, copy),
+                          column_names=self._colnames, term_names=self._terms)
+
+    def getcol(self, i):
+        return type(self)(self.toarray()[:, [i]], column_names=[self._colnames[i]],
+                          term_names=[self._terms[i]])
+
+    def __getitem__(self, key):
+        row, col = check_indexer(key)
+        names = np.array(self._colnames, dtype=object)[col].ravel().tolist()
+        terms = np.array(self._terms, dtype=object)[col].ravel().tolist()
+        return type(self)(self.toarray()[row, col], column_names=names, term_names=terms)
+
+    def __matmul__(self, other):
+        return self.matvec(other)
+
+    def __str__(self):
+        return "{}x{} DenseMatrix:\n\n".format(*self.shape) + np.array_str(self.toarray())
+
+    def __repr__(self):
+        return f"DenseMatrix({np.array2string(self.toarray(), separator=', ')})"
+
+    def multiply(self, other):
+        other = np.asanyarray(other)
+        arr = self.toarray() * (other[:, None] if other.ndim == 1 else other)
+        return type(self)(arr, column_names=self._colnames, term_names=self._terms)
+
+    # ---- hot path -----------------------------------------------------------------------
+    def _sandwich_dev(self, d, rows, cols):
+        return xd.dense_sandwich(self._dev(), d, rows, cols)
+
+    def sandwich(self, d, rows=None, cols=None):
+        """X[rows, cols].T @ diag(d[rows]) @ X[rows, cols] (dense_matrix.py:153-163)."""
+        on_dev = D.is_dev(d)
+        if not on_dev:
+            d = np.asarray(d)
+        check_sandwich_compatible(self, d)
+        rows = normalize_index(rows, self.shape[0])
+        cols = normalize_index(cols, self.shape[1])
+        res = self._sandwich_dev(D.to_dev(d), D.idx_dev(rows), D.idx_dev(cols))
+        return res if on_dev else D.to_host(res)
+
+    def _cross_sandwich_dev(self, other, d, rows, L_cols, R_cols):
+        from .categorical_matrix import CategoricalMatrix
+        from .sparse_matrix import SparseMatrix
+
+        if isinstance(other, (SparseMatrix, CategoricalMatrix)):
+            return other._cross_sandwich_dev(self, d, rows, R_cols, L_cols).T
+        raise TypeError
+
+    def _cross_sandwich(self, other, d, rows=None, L_cols=None, R_cols=None):
+        """dense_matrix.py:165-178."""
+        on_dev = D.is_dev(d)
+        res = self._cross_sandwich_dev(
+            other, D.to_dev(d if on_dev else np.asarray(d)), D.idx_dev(normalize_index(rows, self.shape[0])),
+            D.idx_dev(normalize_index(L_cols, self.shape[1])),
+            D.idx_dev(normalize_index(R_cols, other.shape[1])))
+        return res if on_dev else D.to_host(res)
+
+    def _get_col_stds(self, weights, col_means):
+        """sqrt(sum_i w_i (x_ij - mean_j)^2) (dense_matrix.py:180-187; the reference's
+        transpose_square_dot_weights, ext/dense.pyx:103-122).  Evaluated from device products:
+        sum w x^2 = diag(X' W X), sum w x = X' w."""
+        w = np.asarray(weights, dtype=self.dtype)
+        ex2 = np.diag(self.sandwich(w))
+        ex = self.transpose_matvec(w)
+        arg = ex2 - 2 * col_means * ex + col_means**2 * w.sum()
+        arg[arg < 0] = 0
+        return np.sqrt(arg)
+
+    def _matvec_dev(self, vec, rows, cols, out, transpose):
+        """vec / out are 1-D device tensors; accumulates into out (created when None)."""
+        fn = xd.dense_rmatvec if transpose else xd.dense_matvec
+        return fn(self._dev(), vec, rows, cols, out)
+
+    def _matvec_helper(self, vec, rows, cols, out, transpose):
+        on_dev = D.is_dev(vec)
+        if not on_dev:
+            vec = np.asarray(vec)
+        check_matvec_dimensions(self, vec, transpose=transpose)
+        n, m = self.shape
+        rows_n = normalize_index(rows, n)
+        cols_n = normalize_index(cols, m)
+        # "we assume that rows and cols are unique" (dense_matrix.py:208-210)
+        if rows_n is not None and len(rows_n) == n:
+            rows_n = None
+        if cols_n is not None and len(cols_n) == m:
+            cols_n = None
+        tdt = D.torch_dtype(self.dtype)
+        v_dev = D.to_dev(vec, tdt)
+        rd, cd = D.idx_dev(rows_n), D.idx_dev(cols_n)
+        if v_dev.ndim == 1:
+            res = self._matvec_dev(v_dev, rd, cd, None, transpose)
+        else:
+            cols_out = [self._matvec_dev(v_dev[:, j].contiguous(), rd, cd, None, transpose)
+                        for j in range(v_dev.shape[1])]
+            res = torch.stack(cols_out, dim=1) if cols_out else D.zeros(
+                (m if transpose else n, 0), tdt)
+        if not on_dev:
+            res = D.to_host(res)
+            if np.issubdtype(vec.dtype, np.floating) and vec.dtype != self.dtype:
+                res = res.astype(np.result_type(vec.dtype, self.dtype))
+        if out is None:
+            return res
+        if transpose and cols_n is not None:
+            out[cols_n if not D.is_dev(out) else D.idx_dev(cols_n, torch.int64)] += res
+        else:
+            out += res
+        return out
+
+    def transpose_matvec(self, vec, rows=None, cols=None, out=None):
+        """self[rows, cols].T @ vec[rows] (dense_matrix.py:238-247)."""
+        check_transpose_matvec_out_shape(self, out)
+        return self._matvec_helper(vec, rows, cols, out, True)
+
+    def matvec(self, vec, cols=None, out=None):
+        """self[:, cols] @ vec[cols] (dense_matrix.py:249-257)."""
+        check_matvec_out_shape(self, out)
+        return self._matvec_helper(vec, None, cols, out, False)

@@ -1,0 +1,44 @@
+"""Mirror of tabmat.ext.dense (reference: src/tabmat/ext/dense.pyx)."""
+from __future__ import annotations
+
+from .. import _device as D
+from .._lib import call
+from ._types import DenseDev
+
+
+def dense_sandwich(X: DenseDev, d, rows, cols):
+    """ext/dense.pyx:19-44.  rows/cols: int32 device tensors or None (= all)."""
+    out_m = X.m if cols is None else D.nlen(cols)
+    in_n = X.n if rows is None else D.nlen(rows)
+    out = D.zeros((out_m, out_m), X.dtype)
+    if in_n == 0 or out_m == 0:  # ext/dense.pyx:26-27
+        return out
+    call(f"tm_dense_sandwich_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(d), D.p(rows),
+         D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
+def dense_rmatvec(X: DenseDev, v, rows, cols, out=None):
+    """ext/dense.pyx:48-73: X[rows, cols].T @ v[rows] (length len(cols)); accumulates into out."""
+    n_cols = X.m if cols is None else D.nlen(cols)
+    n_rows = X.n if rows is None else D.nlen(rows)
+    if out is None:
+        out = D.zeros((n_cols,), X.dtype)
+    if n_rows == 0 or n_cols == 0:
+        return out
+    call(f"tm_dense_rmatvec_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(v), D.p(rows),
+         D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
+def dense_matvec(X: DenseDev, v, rows, cols, out=None):
+    """ext/dense.pyx:76-101: X[rows, cols] @ v[cols] (length len(rows)); accumulates into out."""
+    n_cols = X.m if cols is None else D.nlen(cols)
+    n_rows = X.n if rows is None else D.nlen(rows)
+    if out is None:
+        out = D.zeros((n_rows,), X.dtype)
+    if n_rows == 0 or n_cols == 0:
+        return out
+    call(f"tm_dense_matvec_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(v), D.p(rows),
+         D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out

@@ -1,0 +1,61 @@
+"""Mirror of tabmat.ext.sparse (reference: src/tabmat/ext/sparse.pyx).  Only the CSR twin of
+a sparse block is kept on the device; see include/tabmat_hip.h."""
+from __future__ import annotations
+
+from .. import _device as D
+from .._lib import call
+from ._types import CsrDev, DenseDev
+
+
+def _csr_args(A: CsrDev):
+    return (D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n, A.m)
+
+
+def sparse_sandwich(A: CsrDev, d, rows, cols):
+    """ext/sparse.pyx:17-77."""
+    m = A.m if cols is None else D.nlen(cols)
+    out = D.zeros((m, m), A.dtype)
+    if m == 0 or (rows is not None and D.nlen(rows) == 0):
+        return out
+    call(f"tm_sparse_sandwich_{D.fsuf(A.data)}", *_csr_args(A), D.p(d), D.p(rows), D.nlen(rows),
+         D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
+def csr_dense_sandwich(A: CsrDev, B: DenseDev, d, rows, A_cols, B_cols):
+    """ext/sparse.pyx:211-260."""
+    nA = A.m if A_cols is None else D.nlen(A_cols)
+    nB = B.m if B_cols is None else D.nlen(B_cols)
+    nr = A.n if rows is None else D.nlen(rows)
+    out = D.zeros((nA, nB), A.dtype)
+    if nr == 0 or nA == 0 or nB == 0 or A.data.numel() == 0:  # ext/sparse.pyx:236-237
+        return out
+    call(f"tm_csr_dense_sandwich_{D.fsuf(A.data)}", *_csr_args(A), D.p(B.buf), B.m, B.order_f,
+         D.p(d), D.p(rows), D.nlen(rows), D.p(A_cols), D.nlen(A_cols), D.p(B_cols),
+         D.nlen(B_cols), D.p(out), D.stream_ptr())
+    return out
+
+
+def csr_matvec(X: CsrDev, v, rows, cols, out=None):
+    """ext/sparse.pyx:79-140 (csr_matvec_unrestricted with rows = cols = None)."""
+    n_rows = X.n if rows is None else D.nlen(rows)
+    if out is None:
+        out = D.zeros((n_rows,), X.dtype)
+    if n_rows == 0 or (cols is not None and D.nlen(cols) == 0):
+        return out
+    call(f"tm_csr_matvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
+         D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
+def csc_rmatvec(X: CsrDev, v, rows, cols, out=None):
+    """ext/sparse.pyx:142-199 (csc_rmatvec_unrestricted with rows = cols = None); evaluated on
+    the CSR twin."""
+    n_cols = X.m if cols is None else D.nlen(cols)
+    if out is None:
+        out = D.zeros((n_cols,), X.dtype)
+    if n_cols == 0 or (rows is not None and D.nlen(rows) == 0):
+        return out
+    call(f"tm_csr_rmatvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
+         D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out

@@ -1,0 +1,93 @@
+"""Mirror of tabmat.ext.split (reference: src/tabmat/ext/split.pyx)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _device as D
+from .._lib import call
+from ._types import CsrDev, DenseDev
+
+
+def sandwich_cat_dense(i_indices, i_ncol, d, mat_j: DenseDev, rows, j_cols, drop_first=False):
+    """ext/split.pyx:32-80."""
+    n_j = mat_j.m if j_cols is None else D.nlen(j_cols)
+    res = D.zeros((i_ncol, n_j), mat_j.dtype)
+    n_rows = i_indices.numel() if rows is None else D.nlen(rows)
+    if d.numel() == 0 or n_rows == 0 or n_j == 0 or i_ncol == 0:  # ext/split.pyx:51-52
+        return res
+    call(f"tm_cat_dense_sandwich_{D.fsuf(mat_j.buf)}", D.p(i_indices), i_indices.numel(), i_ncol,
+         int(drop_first), D.p(d), D.p(rows), D.nlen(rows), D.p(mat_j.buf), mat_j.m, mat_j.order_f,
+         D.p(j_cols), D.nlen(j_cols), D.p(res), D.stream_ptr())
+    return res
+
+
+def sandwich_cat_cat(i_indices, j_indices, i_ncol, j_ncol, d, rows, i_drop_first=False,
+                     j_drop_first=False):
+    """ext/split.pyx:83-111."""
+    res = D.zeros((i_ncol, j_ncol), d.dtype)
+    if i_ncol == 0 or j_ncol == 0 or (rows is not None and D.nlen(rows) == 0):
+        return res
+    call(f"tm_cat_cat_sandwich_{D.fsuf(d)}", D.p(i_indices), D.p(j_indices), i_indices.numel(),
+         D.p(d), D.p(rows), D.nlen(rows), i_ncol, j_ncol, int(i_drop_first), int(j_drop_first),
+         D.p(res), D.stream_ptr())
+    return res
+
+
+def sandwich_cat_sparse(i_indices, i_ncol, d, S: CsrDev, rows, cols, drop_first=False):
+    """The kernel behind CategoricalMatrix._cross_sparse (categorical_matrix.py:825-838), which in
+    the reference is a scipy.sparse product."""
+    n_cols = S.m if cols is None else D.nlen(cols)
+    res = D.zeros((i_ncol, n_cols), S.dtype)
+    if i_ncol == 0 or n_cols == 0 or (rows is not None and D.nlen(rows) == 0):
+        return res
+    call(f"tm_cat_sparse_sandwich_{D.fsuf(S.data)}", D.p(i_indices), i_indices.numel(), i_ncol,
+         int(drop_first), D.p(S.data), D.p(S.indices), D.p(S.indptr), S.m, D.p(d), D.p(rows),
+         D.nlen(rows), D.p(cols), D.nlen(cols), D.p(res), D.stream_ptr())
+    return res
+
+
+def scatter_block(src, ri, ci, out, mirror=False, diag=False):
+    """out[ri[a], ci[b]] = src[a, b] (+ transpose); diag: out[ri[a], ri[a]] += src[a].
+    Device form of split_matrix.py:341-354."""
+    p = out.shape[0]
+    if diag:
+        nr, nc = src.numel(), 1
+    else:
+        nr, nc = src.shape
+    if nr == 0 or nc == 0:
+        return
+    call(f"tm_scatter_block_{D.fsuf(src)}", D.p(src), nr, nc, D.p(ri), D.p(ci), D.p(out), p,
+         int(mirror), int(diag), D.stream_ptr())
+
+
+def split_col_subsets(self, cols: np.ndarray):
+    """ext/split.pyx:157-209: host-side index bookkeeping (p-sized), same outputs:
+    (subset_cols_indices, subset_cols, n_cols)."""
+    cols = np.asarray(cols, dtype=np.int32)
+    n_blocks = len(self.indices)
+    next_idx = [0] * n_blocks
+    sub_idx = [[] for _ in range(n_blocks)]
+    sub_cols = [[] for _ in range(n_blocks)]
+    for i, c in enumerate(cols.tolist()):
+        for j in range(n_blocks):
+            ind = self.indices[j]
+            k = next_idx[j]
+            while k < len(ind) and ind[k] < c:
+                k += 1
+            next_idx[j] = k
+            if k < len(ind) and ind[k] == c:
+                sub_idx[j].append(i)
+                sub_cols[j].append(k)
+                next_idx[j] = k + 1
+                break
+    return (
+        [np.array(s, dtype=np.int32) for s in sub_idx],
+        [np.array(s, dtype=np.int32) for s in sub_cols],
+        len(cols),
+    )
+
+
+def is_sorted(a) -> bool:
+    """ext/split.pyx:211-217."""
+    a = np.asarray(a)
+    return bool(np.all(a[1:] >= a[:-1]))

@@ -1,0 +1,262 @@
+"""SparseMatrix: a sorted CSC matrix on the host whose CSR twin is resident in HBM (reference:
+/root/reference/src/tabmat/sparse_matrix.py).  Kernels: tabmat_amd/csrc/sparse.hip."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy import sparse as sps
+
+from . import _device as D
+from .ext import sparse as xs
+from .ext._types import CsrDev
+from .matrix_base import MatrixBase
+from .util import (
+    check_indexer,
+    check_matvec_dimensions,
+    check_matvec_out_shape,
+    check_sandwich_compatible,
+    check_transpose_matvec_out_shape,
+    normalize_index,
+)
+
+
+class SparseMatrix(MatrixBase):
+    """Instantiated like scipy.sparse.csc_matrix (sparse_matrix.py:35-79), or from a ready
+    CsrDev (device CSR twin) via SparseMatrix.from_device."""
+
+    def __init__(self, input_array, shape=None, dtype=None, copy=False, column_names=None,
+                 term_names=None):
+        if isinstance(input_array, np.ndarray):
+            if input_array.ndim == 1:
+                input_array = input_array.reshape(-1, 1)
+            elif input_array.ndim > 2:
+                raise ValueError("Input array must be 1- or 2-dimensional")
+        self._array = sps.csc_matrix(input_array, shape, dtype, copy)
+        self.idx_dtype = max(self._array.indices.dtype, self._array.indptr.dtype)
+        if self._array.indices.dtype != self.idx_dtype:
+            self._array.indices = self._array.indices.astype(self.idx_dtype)
+        if self._array.indptr.dtype != self.idx_dtype:
+            self._array.indptr = self._array.indptr.astype(self.idx_dtype)
+        if not self._array.has_sorted_indices:
+            self._array.sort_indices()
+        self._array_csr = None
+        self._devblk = None
+        self._shape = self._array.shape
+        self._dtype = self._array.dtype
+        self._init_names(column_names, term_names)
+
+    def _init_names(self, column_names, term_names):
+        width = self._shape[1]
+        if column_names is not None and len(column_names) != width:
+            raise ValueError(f"Expected {width} column names, got {len(column_names)}")
+        if term_names is not None and len(term_names) != width:
+            raise ValueError(f"Expected {width} term names, got {len(term_names)}")
+        self._colnames = list(column_names) if column_names is not None else [None] * width
+        self._terms = list(term_names) if term_names is not None else self._colnames
+
+    @classmethod
+    def from_device(cls, csr: CsrDev):
+        """Wrap a CSR twin that already lives in HBM (no host copy)."""
+        self = cls.__new__(cls)
+        self._array = None
+        self._array_csr = None
+        self._devblk = csr
+        self._shape = (csr.n, csr.m)
+        self._dtype = np.dtype(np.float64 if csr.data.dtype == torch.float64 else np.float32)
+        self.idx_dtype = np.dtype(np.int32)
+        self._init_names(None, None)
+        return self
+
+    # ---- storage ------------------------------------------------------------------------
+    def _host(self):
+        if self._array is None:
+            c = self._devblk
+            csr = sps.csr_matrix((D.to_host(c.data), D.to_host(c.indices), D.to_host(c.indptr)),
+                                 shape=self._shape)
+            self._array = csr.tocsc()
+            self._array.sort_indices()
+        return self._array
+
+    @property
+    def array_csc(self):
+        return self._host()
+
+    @property
+    def array_csr(self):
+        """Host CSR twin (sparse_matrix.py:133-143)."""
+        if self._array_csr is None:
+            self._array_csr = self._host().tocsr(copy=False)
+        return self._array_csr
+
+    def _dev(self) -> CsrDev:
+        if self._devblk is None:
+            self._devblk = CsrDev.from_scipy(self.array_csr)
+        return self._devblk
+
+    def to_device(self):
+        self._dev()
+        return self
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def indices(self):
+        return self._host().indices
+
+    @property
+    def indptr(self):
+        return self._host().indptr
+
+    @property
+    def data(self):
+        return self._host().data
+
+    __array_ufunc__ = None
+
+    def tocsc(self, copy=False):
+        return self._host().tocsc(copy=copy)
+
+    def unpack(self):
+        return self._host()
+
+    def toarray(self):
+        return self._host().toarray()
+
+    def dot(self, other):
+        return self._host().dot(other)
+
+    def transpose(self):
+        return type(self)(self._host().T)
+
+    T = property(transpose)
+
+    def getcol(self, i):
+        return type(self)(self._host()[:, [i]], column_names=[self._colnames[i]],
+                          term_names=[self._terms[i]])
+
+    def astype(self, dtype, order="K", casting="unsafe", copy=True):
+        return type(self)(self._host().astype(dtype, casting, copy))
+
+    def __getitem__(self, key):
+        row, col = check_indexer(key)
+        names = np.array(self._colnames, dtype=object)[col].ravel().tolist()
+        terms = np.array(self._terms, dtype=object)[col].ravel().tolist()
+        return type(self)(self._host()[row, col], column_names=names, term_names=terms)
+
+    def __matmul__(self, other):
+        return self.matvec(other)
+
+    def multiply(self, other):
+        if other.ndim == 1:
+            return type(self)(self._host().multiply(other[:, np.newaxis]))
+        return type(self)(self._host().multiply(other))
+
+    # ---- hot path -----------------------------------------------------------------------
+    def _sandwich_dev(self, d, rows, cols):
+        return xs.sparse_sandwich(self._dev(), d, rows, cols)
+
+    def sandwich(self, d, rows=None, cols=None):
+        """sparse_matrix.py:175-185."""
+        on_dev = D.is_dev(d)
+        if not on_dev:
+            d = np.asarray(d)
+        check_sandwich_compatible(self, d)
+        res = self._sandwich_dev(D.to_dev(d), D.idx_dev(normalize_index(rows, self.shape[0])),
+                                 D.idx_dev(normalize_index(cols, self.shape[1])))
+        return res if on_dev else D.to_host(res)
+
+    def _cross_sandwich_dev(self, other, d, rows, L_cols, R_cols):
+        from .categorical_matrix import CategoricalMatrix
+        from .dense_matrix import DenseMatrix
+
+        if isinstance(other, DenseMatrix):
+            if other.dtype != self.dtype:
+                raise TypeError(
+                    "self, B and d all need to be of same dtype, either np.float64 or "
+                    f"np.float32. This matrix is of type {self.dtype}, B is of type "
+                    f"{other.dtype}.")
+            return xs.csr_dense_sandwich(self._dev(), other._dev(), d, rows, L_cols, R_cols)
+        if isinstance(other, CategoricalMatrix):
+            return other._cross_sandwich_dev(self, d, rows, R_cols, L_cols).T
+        raise TypeError
+
+    def _cross_sandwich(self, other, d, rows, L_cols=None, R_cols=None):
+        """sparse_matrix.py:187-204."""
+        on_dev = D.is_dev(d)
+        if not on_dev:
+            d = np.asarray(d)
+        check_sandwich_compatible(self, d)  # dtype rule of sparse_matrix.py:218-223
+        res = self._cross_sandwich_dev(
+            other, D.to_dev(d), D.idx_dev(normalize_index(rows, self.shape[0])),
+            D.idx_dev(normalize_index(L_cols, self.shape[1])),
+            D.idx_dev(normalize_index(R_cols, other.shape[1])))
+        return res if on_dev else D.to_host(res)
+
+    def sandwich_dense(self, B, d, rows, L_cols, R_cols):
+        """self.T @ diag(d) @ B for a dense ndarray / DenseMatrix B (sparse_matrix.py:206-229)."""
+        from .dense_matrix import DenseMatrix
+
+        Bm = B if isinstance(B, DenseMatrix) else DenseMatrix(B)
+        return self._cross_sandwich(Bm, d, rows, L_cols, R_cols)
+
+    def _matvec_dev(self, vec, rows, cols, out, transpose):
+        fn = xs.csc_rmatvec if transpose else xs.csr_matvec
+        return fn(self._dev(), vec, rows, cols, out)
+
+    def _matvec_helper(self, vec, rows, cols, out, transpose):
+        on_dev = D.is_dev(vec)
+        if not on_dev:
+            vec = np.asarray(vec)
+        check_matvec_dimensions(self, vec, transpose)
+        n, m = self.shape
+        rows_n = normalize_index(rows, n)
+        cols_n = normalize_index(cols, m)
+        if rows_n is not None and len(rows_n) == n:
+            rows_n = None
+        if cols_n is not None and len(cols_n) == m:
+            cols_n = None
+        tdt = D.torch_dtype(self.dtype)
+        v_dev = D.to_dev(vec, tdt)
+        rd, cd = D.idx_dev(rows_n), D.idx_dev(cols_n)
+        if v_dev.ndim == 1:
+            res = self._matvec_dev(v_dev, rd, cd, None, transpose)
+        else:
+            parts = [self._matvec_dev(v_dev[:, j].contiguous(), rd, cd, None, transpose)
+                     for j in range(v_dev.shape[1])]
+            res = torch.stack(parts, dim=1) if parts else D.zeros((m if transpose else n, 0), tdt)
+        if not on_dev:
+            res = D.to_host(res)
+        if out is None:
+            return res
+        if transpose and cols_n is not None:
+            out[cols_n if not D.is_dev(out) else D.idx_dev(cols_n, torch.int64)] += res
+        else:
+            out += res
+        return out
+
+    def matvec(self, vec, cols=None, out=None):
+        """sparse_matrix.py:277-282."""
+        check_matvec_out_shape(self, out)
+        return self._matvec_helper(vec, None, cols, out, False)
+
+    def transpose_matvec(self, vec, rows=None, cols=None, out=None):
+        """sparse_matrix.py:284-293."""
+        check_transpose_matvec_out_shape(self, out)
+        return self._matvec_helper(vec, rows, cols, out, True)
+
+    def _get_col_stds(self, weights, col_means):
+        """sparse_matrix.py:295-311 (ext/sparse.pyx:262-282): sum_i w_i x_ij^2 = diag(X' W X)."""
+        w = np.asarray(weights, dtype=self.dtype)
+        arg = np.diag(self.sandwich(w)) - col_means**2
+        arg[arg < 0] = 0
+        return np.sqrt(arg)

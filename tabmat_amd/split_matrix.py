@@ -1,0 +1,347 @@
+"""SplitMatrix: column-wise union of one dense, one sparse and any number of categorical
+blocks (reference: /root/reference/src/tabmat/split_matrix.py).  The cross-block assembly of
+sandwich / matvec / transpose_matvec runs on ONE GPU: every block product is a HIP kernel and
+the block results are scattered into the float64 p x p (or length-p / length-n) device buffer
+by tm_scatter_block -- no host round trip inside a call."""
+from __future__ import annotations
+
+import warnings
+from collections.abc import Sequence
+from typing import Optional, Union
+
+import numpy as np
+import torch
+from scipy import sparse as sps
+
+from . import _device as D
+from .categorical_matrix import CategoricalMatrix
+from .dense_matrix import DenseMatrix
+from .ext import split as xsplit
+from .matrix_base import MatrixBase
+from .sparse_matrix import SparseMatrix
+from .standardized_mat import StandardizedMatrix
+from .util import (
+    check_matvec_dimensions,
+    check_matvec_out_shape,
+    check_sandwich_compatible,
+    check_transpose_matvec_out_shape,
+    normalize_index,
+    set_up_rows_or_cols,
+)
+
+
+def as_tabmat(a):
+    """split_matrix.py:22-37."""
+    if isinstance(a, (MatrixBase, StandardizedMatrix)):
+        return a
+    if sps.issparse(a):
+        return SparseMatrix(a.tocsc(copy=False))
+    if isinstance(a, np.ndarray):
+        return DenseMatrix(a)
+    raise ValueError(f"Cannot convert type {type(a)} to Matrix.")
+
+
+def hstack(tup: Sequence) -> MatrixBase:
+    """split_matrix.py:40-62."""
+    mats = [as_tabmat(a) for a in tup]
+    if not mats:
+        raise ValueError("Need at least one array to concatenate.")
+    if all(isinstance(m, SparseMatrix) for m in mats):
+        return SparseMatrix(sps.hstack([m.array_csc for m in mats]))
+    if all(isinstance(m, DenseMatrix) for m in mats):
+        return DenseMatrix(np.hstack([m.toarray() for m in mats]))
+    return SplitMatrix(mats)
+
+
+def _merge_same_kind(matrices, indices):
+    """All dense blocks -> one DenseMatrix, all sparse blocks -> one SparseMatrix, columns
+    ordered by global index; categoricals untouched (split_matrix.py:85-141)."""
+    for kind in (DenseMatrix, SparseMatrix):
+        which = [i for i, m in enumerate(matrices) if isinstance(m, kind)]
+        if len(which) <= 1:
+            continue
+        gidx = np.concatenate([indices[i] for i in which])
+        order = np.argsort(gidx)
+        names = np.concatenate([np.array(matrices[i]._colnames, dtype=object) for i in which])
+        terms = np.concatenate([np.array(matrices[i]._terms, dtype=object) for i in which])
+        if kind is DenseMatrix:
+            merged = DenseMatrix(np.hstack([matrices[i].toarray() for i in which])[:, order])
+        else:
+            merged = SparseMatrix(sps.hstack([matrices[i].array_csc for i in which]).tocsc()[:, order])
+        merged._colnames = names[order].tolist()
+        merged._terms = terms[order].tolist()
+        matrices[which[0]] = merged
+        indices[which[0]] = gidx[order]
+        drop = set(which[1:])
+        matrices = [m for i, m in enumerate(matrices) if i not in drop]
+        indices = [x for i, x in enumerate(indices) if i not in drop]
+    return matrices, indices
+
+
+class SplitMatrix(MatrixBase):
+    """matrices: the blocks; indices: for each block the (sorted) global columns it covers."""
+
+    def __init__(self, matrices: Sequence[MatrixBase], indices: Optional[list] = None):
+        flat, corrections = [], []
+        for mat in matrices:
+            if not isinstance(mat, MatrixBase):
+                raise ValueError(
+                    "Expected all elements of matrices to be subclasses of MatrixBase.")
+            if isinstance(mat, SplitMatrix):
+                offset = 0
+                for iind, imat in zip(mat.indices, mat.matrices):
+                    flat.append(imat)
+                    corrections.append(iind - np.arange(len(iind), dtype=np.int64) - offset)
+                    offset += len(iind)
+            else:
+                flat.append(mat)
+                corrections.append(np.zeros(mat.shape[1], dtype=np.int64))
+        self.dtype = flat[0].dtype
+        n_row = flat[0].shape[0]
+        for i, mat in enumerate(flat):
+            if mat.dtype != self.dtype:
+                warnings.warn("Matrices do not all have the same dtype. Dtypes are "
+                              f"{[elt.dtype for elt in flat]}.")
+            if mat.shape[0] != n_row:
+                raise ValueError(
+                    "All matrices should have the same first dimension, "
+                    f"but the first matrix has first dimension {n_row} and matrix {i} "
+                    f"has first dimension {mat.shape[0]}.")
+        if indices is None:
+            indices, cur = [], 0
+            for mat, corr in zip(flat, corrections):
+                indices.append(np.arange(cur, cur + mat.shape[1], dtype=np.int64) + corr)
+                cur += mat.shape[1]
+            n_col = cur
+        else:
+            indices = [np.asarray(ix) for ix in indices]
+            allidx = np.concatenate(indices) if indices else np.zeros(0, dtype=np.int64)
+            n_col = len(allidx)
+            if (np.arange(n_col, dtype=np.int64) != np.sort(allidx)).any():
+                raise ValueError("Indices should contain all integers from 0 to one less than "
+                                 "the number of columns.")
+            for i, ix in enumerate(indices):
+                if not xsplit.is_sorted(ix):
+                    raise ValueError(
+                        f"Each index block should be sorted, but indices[{i}] was not sorted")
+        for i, (mat, ix) in enumerate(zip(flat, indices)):
+            if mat.shape[1] != len(ix):
+                raise ValueError(
+                    f"Element {i} of indices should should have length {mat.shape[1]}, "
+                    f"but it has shape {np.asarray(ix).shape}")
+        keep = [i for i, m in enumerate(flat) if m.shape[1] > 0]
+        mats, idxs = _merge_same_kind([flat[i] for i in keep], [indices[i] for i in keep])
+        self.matrices = mats
+        self.indices = [np.asarray(ix, dtype=np.int64) for ix in idxs]
+        self.shape = (n_row, n_col)
+        self._dev_indices = None
+        assert self.shape[1] > 0
+
+    # ---- bookkeeping ----------------------------------------------------------------------
+    def _split_col_subsets(self, cols):
+        """split_matrix.py:269-291: (positions in the result, local columns per block, n_cols)."""
+        if cols is None:
+            return self.indices, [None] * len(self.indices), self.shape[1]
+        return xsplit.split_col_subsets(self, set_up_rows_or_cols(cols, self.shape[1]))
+
+    def _dev_idx(self, arrs):
+        return [D.idx_dev(a, torch.int64) for a in arrs]
+
+    def _full_dev_indices(self):
+        if self._dev_indices is None:
+            self._dev_indices = self._dev_idx(self.indices)
+        return self._dev_indices
+
+    def to_device(self):
+        for m in self.matrices:
+            m.to_device()
+        self._full_dev_indices()
+        return self
+
+    def astype(self, dtype, order="K", casting="unsafe", copy=True):
+        return SplitMatrix([m.astype(dtype=dtype, order=order, casting=casting, copy=copy)
+                            for m in self.matrices], self.indices)
+
+    def toarray(self) -> np.ndarray:
+        out = np.empty(self.shape)
+        for mat, idx in zip(self.matrices, self.indices):
+            out[:, idx] = mat.toarray()
+        return out
+
+    def getcol(self, i: int):
+        i %= self.shape[1]
+        for mat, idx in zip(self.matrices, self.indices):
+            loc = np.where(idx == i)[0]
+            if len(loc):
+                return mat.getcol(int(loc[0]))
+        raise RuntimeError(f"Column {i} was not found.")
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            row, col = key
+        else:
+            row, col = key, slice(None)
+        if not (isinstance(col, slice) and col == slice(None)):
+            raise NotImplementedError(f"Only row indexing is supported. Index passed was {key}.")
+        if isinstance(row, int):
+            row = [row]
+        return SplitMatrix([m[row, :] for m in self.matrices], self.indices)
+
+    def __repr__(self):
+        return "SplitMatrix(" + ", ".join(type(m).__name__ + str(m.shape) for m in self.matrices) + ")"
+
+    def multiply(self, other):
+        return SplitMatrix([m.multiply(other) for m in self.matrices], self.indices)
+
+    def get_names(self, type="column", missing_prefix=None, indices=None):
+        names = np.empty(self.shape[1], dtype=object)
+        for idx, mat in zip(self.indices, self.matrices):
+            names[idx] = mat.get_names(type, missing_prefix, idx)
+        return list(names)
+
+    def set_names(self, names, type="column"):
+        names = np.asarray([names] if isinstance(names, str) else names, dtype=object)
+        if len(names) != self.shape[1]:
+            raise ValueError(f"Length of names must be {self.shape[1]}")
+        for idx, mat in zip(self.indices, self.matrices):
+            mat.set_names(names[idx].tolist(), type)
+
+    def _get_col_means(self, weights):
+        means = np.empty(self.shape[1], dtype=self.dtype)
+        for idx, mat in zip(self.indices, self.matrices):
+            means[idx] = mat._get_col_means(weights)
+        return means
+
+    def _get_col_stds(self, weights, col_means):
+        stds = np.empty(self.shape[1], dtype=self.dtype)
+        for idx, mat in zip(self.indices, self.matrices):
+            stds[idx] = mat._get_col_stds(weights, col_means[idx])
+        return stds
+
+    # ---- hot path -------------------------------------------------------------------------
+    def _sandwich_dev(self, d, rows, cols_host):
+        """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
+        Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356)."""
+        pos, sub_cols, n_cols = self._split_col_subsets(cols_host)
+        pos_d = self._full_dev_indices() if cols_host is None else self._dev_idx(pos)
+        sub_d = [None if sc is None else D.idx_dev(sc) for sc in sub_cols]
+        out = D.zeros((n_cols, n_cols), torch.float64)
+        for i, mi in enumerate(self.matrices):
+            if sub_d[i] is not None and D.nlen(sub_d[i]) == 0:
+                continue
+            if isinstance(mi, CategoricalMatrix):
+                diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
+                xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
+            else:
+                res = mi._sandwich_dev(d, rows, sub_d[i])
+                xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+            for j in range(i + 1, len(self.matrices)):
+                if sub_d[j] is not None and D.nlen(sub_d[j]) == 0:
+                    continue
+                res = mi._cross_sandwich_dev(self.matrices[j], d, rows, sub_d[i], sub_d[j])
+                xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
+        return out
+
+    def sandwich(self, d, rows=None, cols=None):
+        """X[rows, cols].T @ diag(d[rows]) @ X[rows, cols]; always float64 like the reference
+        (split_matrix.py:336)."""
+        on_dev = D.is_dev(d)
+        if not on_dev:
+            d = np.asarray(d)
+        check_sandwich_compatible(self, d)
+        rows_n = normalize_index(rows, self.shape[0])
+        cols_n = normalize_index(cols, self.shape[1])
+        out = self._sandwich_dev(D.to_dev(d), D.idx_dev(rows_n), cols_n)
+        return out if on_dev else D.to_host(out)
+
+    def matvec(self, v, cols=None, out=None):
+        """split_matrix.py:373-420."""
+        assert not sps.issparse(v)
+        on_dev = D.is_dev(v)
+        if not on_dev:
+            v = np.asarray(v)
+        check_matvec_dimensions(self, v, transpose=False)
+        check_matvec_out_shape(self, out)
+        if v.ndim > 1 and any(isinstance(m, CategoricalMatrix) for m in self.matrices):
+            raise NotImplementedError(
+                "CategoricalMatrix.matvec is only implemented for 1d arrays.")
+        cols_n = normalize_index(cols, self.shape[1])
+        _, sub_cols, _ = self._split_col_subsets(cols_n)
+        tdt = D.torch_dtype(self.dtype)
+        v_dev = D.to_dev(v, tdt)
+        idx_d = self._full_dev_indices()
+        if v_dev.ndim == 1:
+            res = D.zeros((self.shape[0],), tdt)
+            for mat, idx, sc in zip(self.matrices, idx_d, sub_cols):
+                if sc is not None and len(sc) == 0:
+                    continue
+                vb = v_dev[idx]
+                scd = D.idx_dev(sc)
+                if isinstance(mat, CategoricalMatrix):
+                    mat._matvec_dev(vb, scd, res)
+                else:
+                    if scd is not None and D.nlen(scd) == mat.shape[1]:
+                        scd = None
+                    mat._matvec_dev(vb, None, scd, res, False)
+        else:
+            parts = [self.matvec(v_dev[:, j].contiguous(), cols) for j in range(v_dev.shape[1])]
+            res = torch.stack(parts, dim=1)
+        if not on_dev:
+            res = D.to_host(res)
+            if np.issubdtype(v.dtype, np.floating):
+                res = res.astype(np.result_type(self.dtype, v.dtype), copy=False)
+        if out is None:
+            return res
+        out += res
+        return out
+
+    def transpose_matvec(self, v, rows=None, cols=None, out=None):
+        """split_matrix.py:422-460."""
+        on_dev = D.is_dev(v)
+        if not on_dev:
+            v = np.asarray(v)
+        check_matvec_dimensions(self, v, transpose=True)
+        check_transpose_matvec_out_shape(self, out)
+        if v.ndim > 1 and any(isinstance(m, CategoricalMatrix) for m in self.matrices):
+            raise NotImplementedError(
+                "CategoricalMatrix.transpose_matvec is only implemented for 1d arrays.")
+        rows_n = normalize_index(rows, self.shape[0])
+        cols_n = normalize_index(cols, self.shape[1])
+        pos, sub_cols, n_cols = self._split_col_subsets(cols_n)
+        tdt = D.torch_dtype(self.dtype)
+        v_dev = D.to_dev(v, tdt)
+        rd = D.idx_dev(rows_n)
+        if rows_n is not None and len(rows_n) == self.shape[0]:
+            rd = None
+        if v_dev.ndim == 1:
+            res = D.zeros((n_cols,), tdt)
+            pos_d = self._full_dev_indices() if cols_n is None else self._dev_idx(pos)
+            empty_rows = rows_n is not None and len(rows_n) == 0
+            for mat, pd, sc in zip(self.matrices, pos_d, sub_cols):
+                if empty_rows or (sc is not None and len(sc) == 0):
+                    continue
+                scd = D.idx_dev(sc)
+                if isinstance(mat, CategoricalMatrix):
+                    full = D.zeros((mat.shape[1],), tdt)
+                    mat._transpose_matvec_dev(v_dev, rd, scd, full)
+                    part = full if scd is None else full[scd.to(torch.int64)]
+                else:
+                    if scd is not None and D.nlen(scd) == mat.shape[1]:
+                        scd = None  # sorted unique columns covering the block = all of them
+                    part = mat._matvec_dev(v_dev, rd, scd, None, True)
+                res[pd] += part
+        else:
+            parts = [self.transpose_matvec(v_dev[:, j].contiguous(), rows, cols)
+                     for j in range(v_dev.shape[1])]
+            res = torch.stack(parts, dim=1)
+        if not on_dev:
+            res = D.to_host(res)
+            if np.issubdtype(v.dtype, np.floating):
+                res = res.astype(np.result_type(self.dtype, v.dtype), copy=False)
+        if out is None:
+            return res
+        if cols_n is None:
+            out += res
+        else:
+            out[cols_n if not D.is_dev(out) else D.idx_dev(cols_n, torch.int64)] += res
+        return out

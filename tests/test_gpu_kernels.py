@@ -1,0 +1,388 @@
+"""-m gpu parity tests, part 2: every HIP kernel against the CPU oracle on seeded random
+inputs at sizes the oracle finishes in seconds.  Bars (BASELINE.json north_star): categorical
+counts bit-exact; fp64 sandwich <= 1e-10 relative; fp32 paths are compared with the fp64
+oracle at a tolerance that covers fp32 accumulation of n terms (stated per test)."""
+import numpy as np
+import pytest
+from scipy import sparse as sps
+
+import _cases as cs
+from _gpu_util import rel_err, to_tm_block, to_tm_split
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 1e-10
+
+
+def _orc():
+    from oracle import oracle as orc
+
+    return orc
+
+
+def _rows_subset(rng, n, frac=0.6):
+    return np.sort(rng.choice(n, size=int(n * frac), replace=False)).astype(np.int32)
+
+
+# ------------------------------------------------------------------ K1 dense sandwich
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 3), (1000, 17), (4097, 64), (20000, 128), (3001, 100),
+                                 (2500, 200), (1200, 300), (900, 700)])
+def test_dense_sandwich_f64(order, n, k):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n * 31 + k)
+    X = rng.standard_normal((n, k))
+    X = np.asfortranarray(X) if order == "F" else X
+    d = rng.random(n)
+    res = tm.DenseMatrix(X).sandwich(d)
+    ref = _orc().dense_sandwich(X, d, None, None)
+    assert rel_err(res, ref) < F64_TOL
+    assert np.array_equal(res, res.T)
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_dense_sandwich_rows_cols(order):
+    """rows = the nonzero-d subset, cols = a random subset (tests/test_fast_sandwich.py:51-98)."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(11)
+    for n, k in [(777, 45), (5000, 150), (2000, 400)]:
+        X = rng.standard_normal((n, k))
+        X = np.asfortranarray(X) if order == "F" else X
+        d = rng.random(n)
+        d[rng.choice(n, size=n // 3, replace=False)] = 0.0
+        rows = np.where(np.abs(d) > 1e-14)[0].astype(np.int32)
+        cols = rng.choice(k, size=max(1, k // 2), replace=False).astype(np.int32)
+        res = tm.DenseMatrix(X).sandwich(d, rows, cols)
+        ref = _orc().dense_sandwich(X, d, rows, cols)
+        assert rel_err(res, ref) < F64_TOL
+        Xs = X[:, cols]
+        assert rel_err(res, (Xs.T * d) @ Xs) < F64_TOL
+
+
+@pytest.mark.parametrize("n,k", [(3000, 32), (50000, 256), (1500, 300)])
+def test_dense_sandwich_f32(n, k):
+    """fp32 block: compared with the fp64 oracle on the same fp32 data.  Tolerance 2e-5 relative
+    to max|out| covers fp32 products accumulated over <= 5e4 rows (sqrt(n) * eps_f32 ~ 3e-5)."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, k)).astype(np.float32)
+    d = rng.random(n).astype(np.float32)
+    res = tm.DenseMatrix(X).sandwich(d)
+    assert res.dtype == np.float32
+    ref = _orc().dense_sandwich(X.astype(np.float64), d.astype(np.float64), None, None)
+    assert rel_err(res, ref) < 2e-5
+
+
+# ------------------------------------------------------------------ K5 dense matvec
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_matvec_rmatvec(order, dtype):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(3)
+    n, k = 10007, 77
+    X = rng.standard_normal((n, k)).astype(dtype)
+    X = np.asfortranarray(X) if order == "F" else X
+    mat = tm.DenseMatrix(X)
+    v, w = rng.standard_normal(k).astype(dtype), rng.standard_normal(n).astype(dtype)
+    rows, cols = _rows_subset(rng, n), np.sort(rng.choice(k, 30, replace=False)).astype(np.int32)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    X64 = X.astype(np.float64)
+    assert rel_err(mat.matvec(v), X64 @ v) < tol
+    assert rel_err(mat.matvec(v, cols), X64[:, cols] @ v[cols].astype(np.float64)) < tol
+    assert rel_err(mat.transpose_matvec(w), X64.T @ w) < tol
+    assert rel_err(mat.transpose_matvec(w, rows, cols),
+                   X64[np.ix_(rows, cols)].T @ w[rows].astype(np.float64)) < tol
+    orc = _orc()
+    assert rel_err(mat.transpose_matvec(w, rows, cols), orc.dense_rmatvec(X, w, rows, cols)) < tol
+
+
+# ------------------------------------------------------------------ K2 sparse sandwich
+@pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("n,m,dens", [(200, 50, 0.05), (5000, 130, 0.05), (20000, 512, 0.05),
+                                      (3000, 300, 0.3), (1000, 7, 0.9)])
+def test_sparse_sandwich(idx_dtype, n, m, dens):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng)
+    S = sps.csc_matrix((S.data, S.indices.astype(idx_dtype), S.indptr.astype(idx_dtype)),
+                       shape=S.shape)
+    d = rng.random(n)
+    mat = tm.SparseMatrix(S)
+    ref = _orc().sparse_sandwich(S, S.tocsr(), d, None, None)
+    res = mat.sandwich(d)
+    assert rel_err(res, ref) < F64_TOL
+    assert np.array_equal(res, res.T)
+    rows = _rows_subset(rng, n)
+    cols = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
+    ref = _orc().sparse_sandwich(S, S.tocsr(), d, rows, cols)
+    assert rel_err(mat.sandwich(d, rows, cols), ref) < F64_TOL
+
+
+def test_sparse_sandwich_reference_seeds():
+    """tests/test_fast_sandwich.py:12-31 (both dtypes; atol sqrt(eps) as in the reference)."""
+    import tabmat_amd as tm
+
+    for dtype in (np.float64, np.float32):
+        np.random.seed(123)
+        for _ in range(10):
+            nrows, ncols = np.random.randint(200, size=2)
+            A = cs.simulate_matrix(shape=(nrows, ncols), seed=None, dtype=dtype).tocsc()
+            d = np.random.rand(A.shape[0]).astype(dtype)
+            true = (A.T.multiply(d)).dot(A).toarray()
+            if ncols == 0 or nrows == 0:
+                continue
+            out = tm.SparseMatrix(A).sandwich(d)
+            np.testing.assert_allclose(true, out, atol=np.sqrt(np.finfo(dtype).eps))
+
+
+# ------------------------------------------------------------------ K3 sparse x dense
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("n,m,r", [(100, 2, 4), (5000, 64, 33), (20000, 512, 128), (3000, 700, 20)])
+def test_csr_dense_sandwich(order, n, m, r):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n + m + r)
+    S = sps.random(n, m, density=0.05, format="csc", random_state=rng)
+    B = rng.standard_normal((n, r))
+    B = np.asfortranarray(B) if order == "F" else B
+    d = rng.random(n)
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
+    orc = _orc()
+    ref = orc.csr_dense_sandwich(S.tocsr(), B, d, None, None, None)
+    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < F64_TOL
+    assert rel_err(dm._cross_sandwich(sm, d, None), ref.T) < F64_TOL
+    rows = _rows_subset(rng, n)
+    Ac = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
+    Bc = np.sort(rng.choice(r, size=max(1, r // 2), replace=False)).astype(np.int32)
+    ref = orc.csr_dense_sandwich(S.tocsr(), B, d, rows, Ac, Bc)
+    assert rel_err(sm._cross_sandwich(dm, d, rows, Ac, Bc), ref) < F64_TOL
+
+
+# ------------------------------------------------------------------ K6 sparse matvec
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_matvec_rmatvec(dtype):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(9)
+    n, m = 30011, 213
+    S = sps.random(n, m, density=0.04, format="csc", random_state=rng).astype(dtype)
+    mat = tm.SparseMatrix(S)
+    v, w = rng.standard_normal(m).astype(dtype), rng.standard_normal(n).astype(dtype)
+    rows, cols = _rows_subset(rng, n), np.sort(rng.choice(m, 100, replace=False)).astype(np.int32)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    S64 = S.astype(np.float64)
+    assert rel_err(mat.matvec(v), S64 @ v.astype(np.float64)) < tol
+    assert rel_err(mat.matvec(v, cols), S64[:, cols] @ v[cols].astype(np.float64)) < tol
+    assert rel_err(mat.transpose_matvec(w), S64.T @ w.astype(np.float64)) < tol
+    assert rel_err(mat.transpose_matvec(w, rows, cols),
+                   S64[rows][:, cols].T @ w[rows].astype(np.float64)) < tol
+    orc = _orc()
+    assert rel_err(mat.transpose_matvec(w, rows, cols), orc.csc_rmatvec(S, w, rows, cols)) < tol
+
+
+# ------------------------------------------------------------------ K4 categorical family
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ncat", [3, 1000, 10_000, 58_059])
+@pytest.mark.parametrize("drop_first,missing", [(False, False), (True, False), (False, True),
+                                                (True, True)])
+def test_categorical_counts_bit_exact(dtype, ncat, drop_first, missing):
+    """d == 1: sandwich diagonal and transpose_matvec are exact integer counts -> bit-exact."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(ncat)
+    n = 400_000
+    codes = rng.integers(0, ncat, n).astype(np.int32)
+    if missing:
+        codes[rng.random(n) < 0.03] = -1
+    mat = to_tm_block(("cat", codes, ncat, drop_first), dtype)
+    ones = np.ones(n, dtype=dtype)
+    counts = np.bincount(codes[codes >= 0], minlength=ncat)[int(drop_first):].astype(dtype)
+    diag = mat.sandwich(ones).diagonal()
+    assert diag.dtype == dtype and np.array_equal(diag, counts)
+    assert np.array_equal(mat.transpose_matvec(ones), counts)
+    rows = _rows_subset(rng, n, 0.5)
+    c2 = codes[rows]
+    counts_r = np.bincount(c2[c2 >= 0], minlength=ncat)[int(drop_first):].astype(dtype)
+    assert np.array_equal(mat.sandwich(ones, rows).diagonal(), counts_r)
+    orc = _orc()
+    assert np.array_equal(counts_r, orc.sandwich_categorical(codes, ones, rows, mat.shape[1], drop_first))
+
+
+@pytest.mark.parametrize("drop_first,missing", [(False, False), (True, True)])
+def test_categorical_weighted(drop_first, missing):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(2)
+    n, ncat = 300_000, 5000
+    codes = rng.integers(0, ncat, n).astype(np.int32)
+    if missing:
+        codes[rng.random(n) < 0.03] = -1
+    mat = to_tm_block(("cat", codes, ncat, drop_first))
+    A = cs.spec_toarray(("cat", codes[:2000], ncat, drop_first))
+    d = rng.random(n)
+    orc = _orc()
+    k = mat.shape[1]
+    ref = orc.sandwich_categorical(codes, d, None, k, drop_first)
+    assert rel_err(mat.sandwich(d).diagonal(), ref) < F64_TOL
+    rows = _rows_subset(rng, n)
+    cols = np.sort(rng.choice(k, 700, replace=False)).astype(np.int32)
+    out = np.zeros(k)
+    orc.cat_transpose_matvec(codes, d, k, rows, cols, out, drop_first)
+    assert rel_err(mat.transpose_matvec(d, rows, cols), out[cols]) < F64_TOL
+    # matvec (gather) is exact
+    v = rng.standard_normal(k)
+    ref = np.zeros(n)
+    orc.cat_matvec(codes, v, n, None, k, ref, drop_first)
+    assert np.array_equal(mat.matvec(v), ref)
+    ref = np.zeros(n)
+    orc.cat_matvec(codes, v, n, cols, k, ref, drop_first)
+    assert np.array_equal(mat.matvec(v, cols), ref)
+    del A
+
+
+@pytest.mark.parametrize("ni,nj", [(3, 4), (256, 96), (1000, 300), (58_059, 27)])
+@pytest.mark.parametrize("drops", [(False, False), (True, False), (True, True)])
+def test_cat_cat(ni, nj, drops):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(ni + nj)
+    n = 200_000
+    ci = rng.integers(0, ni, n).astype(np.int32)
+    cj = rng.integers(0, nj, n).astype(np.int32)
+    cj[rng.random(n) < 0.02] = -1
+    mi = to_tm_block(("cat", ci, ni, drops[0]))
+    mj = to_tm_block(("cat", cj, nj, drops[1]))
+    d = rng.random(n)
+    rows = _rows_subset(rng, n)
+    orc = _orc()
+    for r in (None, rows):
+        ref = orc.sandwich_cat_cat(ci, cj, mi.shape[1], mj.shape[1], d, r, drops[0], drops[1])
+        assert rel_err(mi._cross_sandwich(mj, d, r), ref) < F64_TOL
+    ones = np.ones(n)
+    ref = orc.sandwich_cat_cat(ci, cj, mi.shape[1], mj.shape[1], ones, None, drops[0], drops[1])
+    assert np.array_equal(mi._cross_sandwich(mj, ones, None), ref)  # counts: bit-exact
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("ncat,k", [(5, 3), (256, 128), (1000, 40), (20_000, 16)])
+def test_cat_dense(order, ncat, k):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(ncat + k)
+    n = 60_000
+    codes = rng.integers(0, ncat, n).astype(np.int32)
+    codes[rng.random(n) < 0.02] = -1
+    X = rng.standard_normal((n, k))
+    X = np.asfortranarray(X) if order == "F" else X
+    cm, dm = to_tm_block(("cat", codes, ncat, True)), tm.DenseMatrix(X)
+    d = rng.random(n)
+    orc = _orc()
+    ref = orc.sandwich_cat_dense(codes, cm.shape[1], d, X, None, None, True)
+    assert rel_err(cm._cross_sandwich(dm, d), ref) < F64_TOL
+    assert rel_err(dm._cross_sandwich(cm, d), ref.T) < F64_TOL
+    rows = _rows_subset(rng, n)
+    jc = np.sort(rng.choice(k, size=max(1, k // 2), replace=False)).astype(np.int32)
+    lc = np.sort(rng.choice(cm.shape[1], size=max(1, cm.shape[1] // 3), replace=False)).astype(np.int32)
+    ref = orc.sandwich_cat_dense(codes, cm.shape[1], d, X, rows, jc, True)[lc]
+    assert rel_err(cm._cross_sandwich(dm, d, rows, lc, jc), ref) < F64_TOL
+
+
+@pytest.mark.parametrize("ncat,m", [(5, 3), (256, 512), (1000, 100), (3000, 2000)])
+def test_cat_sparse(ncat, m):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(ncat + m)
+    n = 50_000
+    codes = rng.integers(0, ncat, n).astype(np.int32)
+    codes[rng.random(n) < 0.02] = -1
+    S = sps.random(n, m, density=0.05, format="csc", random_state=rng)
+    cm, sm = to_tm_block(("cat", codes, ncat, False)), tm.SparseMatrix(S)
+    d = rng.random(n)
+    orc = _orc()
+    ref = orc.sandwich_cat_sparse(codes, ncat, d, S.tocsr(), None, None, None)
+    assert rel_err(cm._cross_sandwich(sm, d), ref) < F64_TOL
+    assert rel_err(sm._cross_sandwich(cm, d, None), ref.T) < F64_TOL
+    rows = _rows_subset(rng, n)
+    rc = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
+    lc = np.sort(rng.choice(ncat, size=max(1, ncat // 3), replace=False)).astype(np.int32)
+    ref = orc.sandwich_cat_sparse(codes, ncat, d, S.tocsr(), rows, lc, rc)
+    assert rel_err(cm._cross_sandwich(sm, d, rows, lc, rc), ref) < F64_TOL
+    # the reference computes this term with scipy.sparse (categorical_matrix.py:825-838)
+    onehot = sps.csr_matrix((d[codes >= 0], (np.nonzero(codes >= 0)[0], codes[codes >= 0])),
+                            shape=(n, ncat))
+    assert rel_err(cm._cross_sandwich(sm, d), (onehot.T @ S.tocsr()).toarray()) < F64_TOL
+
+
+# ------------------------------------------------------------------ SplitMatrix, cfg4 shape
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_split_mixed_cfg4_shape(dtype, order):
+    """BASELINE.json config 4 at 40k rows: dense 128 + CSC 512 @5% + cats (256, 96, 32)."""
+    specs, idx = cs.mixed_specs(40_000, 128, 512, (256, 96, 32), seed=3, dtype=dtype, order=order)
+    mat = to_tm_split(specs, idx, dtype)
+    blocks = [cs.to_oracle_block(s) for s in specs]
+    orc = _orc()
+    rng = np.random.default_rng(0)
+    n, p = mat.shape
+    assert p == 1024
+    d = rng.random(n).astype(dtype)
+    res = mat.sandwich(d)
+    assert res.dtype == np.float64 and res.shape == (p, p)
+    ref = orc.split_sandwich(blocks, idx, d)
+    tol = F64_TOL if dtype == np.float64 else 5e-5
+    assert rel_err(res, ref) < tol
+    assert np.array_equal(res, res.T)
+    rows = _rows_subset(rng, n)
+    cols = np.sort(rng.choice(p, size=300, replace=False))
+    assert rel_err(mat.sandwich(d, rows, cols), orc.split_sandwich(blocks, idx, d, rows, cols)) < tol
+    v = rng.standard_normal(p).astype(dtype)
+    w = rng.standard_normal(n).astype(dtype)
+    mtol = F64_TOL if dtype == np.float64 else 1e-4
+    assert rel_err(mat.matvec(v), orc.split_matvec(blocks, idx, v)) < mtol
+    assert rel_err(mat.matvec(v, cols), orc.split_matvec(blocks, idx, v, cols)) < mtol
+    assert rel_err(mat.transpose_matvec(w), orc.split_transpose_matvec(blocks, idx, w)) < mtol
+    assert rel_err(mat.transpose_matvec(w, rows, cols),
+                   orc.split_transpose_matvec(blocks, idx, w, rows, cols)) < mtol
+
+
+def test_device_in_device_out():
+    """torch cuda tensors in -> torch cuda tensors out (no host round trip)."""
+    import torch
+
+    specs, idx = cs.mixed_specs(5000, 16, 40, (7, 5), seed=1)
+    mat = to_tm_split(specs, idx)
+    rng = np.random.default_rng(0)
+    d = rng.random(mat.shape[0])
+    host = mat.sandwich(d)
+    dev = mat.sandwich(torch.from_numpy(d).cuda())
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda
+    assert np.array_equal(dev.cpu().numpy(), host)
+    v = rng.random(mat.shape[1])
+    assert np.array_equal(mat.matvec(torch.from_numpy(v).cuda()).cpu().numpy(), mat.matvec(v))
+    assert np.array_equal(mat.transpose_matvec(torch.from_numpy(d).cuda()).cpu().numpy(),
+                          mat.transpose_matvec(d))
+
+
+def test_standardized_split():
+    """StandardizedMatrix on device blocks (tests/test_standardized_mat.py style)."""
+    specs, idx = cs.mixed_specs(3000, 6, 9, (4, 3), seed=4)
+    mat = to_tm_split(specs, idx)
+    rng = np.random.default_rng(1)
+    n, p = mat.shape
+    w = rng.random(n)
+    w /= w.sum()
+    std, means, stds = mat.standardize(w, True, True)
+    A = mat.toarray()
+    np.testing.assert_allclose(means, A.T @ w, rtol=1e-10)
+    np.testing.assert_allclose(stds, np.sqrt(((A - means) ** 2).T @ w), rtol=1e-8, atol=1e-12)
+    S = std.toarray()
+    d = rng.random(n)
+    np.testing.assert_allclose(std.sandwich(d), (S.T * d) @ S, rtol=1e-8, atol=1e-9)
+    v = rng.random(p)
+    np.testing.assert_allclose(std.matvec(v), S @ v, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(std.transpose_matvec(d), S.T @ d, rtol=1e-9, atol=1e-9)
