@@ -1,0 +1,318 @@
+#!/usr/bin/env python
+"""bench.py -- SplitMatrix.sandwich throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one SplitMatrix.sandwich(d) over one batch of synthetic rows resident in HBM:
+the default workload is BASELINE.json configs[3] -- dense 128 cols + CSC-sparse 512 cols @5% +
+3 categoricals (256, 96, 32 levels) => p = 1024, 10M rows per GPU, float64 -- the configuration
+the metric ("10M x 1k mixed") is quoted on.  With N > 1 every rank owns its own 10M-row shard
+(weak scaling, configs[4]) and the p x p partials are summed with one RCCL all-reduce per step.
+
+Rank 0 prints ONE JSON line.  value = algorithmic bytes of the whole job (every operand read
+once, result written once) / wall time of a step, in GB/s; gflops is reported
+next to it.  `roofline` describes the dominant kernel, timed live with HIP events on the
+launch stream (tm_profile_* in the C ABI); `cpu_baseline` is the CPU oracle ("port") timed on
+this box's host cores on a bounded row sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (AMD datasheet; not in the guide's table)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2", "cfg3"])
+    ap.add_argument("--cpu-rows", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="per-op kernel times to stderr")
+    ap.add_argument("--out", default=None, help="also write the JSON (+breakdown) to this file")
+    return ap.parse_args()
+
+
+def build_workload(name, n, seed):
+    from tabmat_amd import synth
+
+    if name == "cfg4":
+        return synth.mixed_split(n, 128, 512, (256, 96, 32), 0.05, torch.float64, seed), torch.float64
+    if name == "cfg2":
+        return synth.dense_block(n, 256, torch.float32, seed), torch.float32
+    if name == "cfg3":
+        return synth.cat_block(n if n != 10_000_000 else 50_000_000, 10_000, seed), torch.float64
+    raise ValueError(name)
+
+
+def kernel_breakdown(mat, d, reps=3):
+    """Main-kernel time of every block / block-pair op of one sandwich, via tm_profile_*."""
+    import ctypes as C
+
+    import tabmat_amd as tm
+    from tabmat_amd import _lib
+
+    lib = _lib.lib()
+    mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
+    ops = []
+    for i, mi in enumerate(mats):
+        ki = type(mi).__name__.replace("Matrix", "").lower()
+        if isinstance(mi, tm.CategoricalMatrix):
+            ops.append((f"{ki}{i}.self", lambda mi=mi: mi._sandwich_diag_dev(d, None, None)))
+        else:
+            ops.append((f"{ki}{i}.self", lambda mi=mi: mi._sandwich_dev(d, None, None)))
+        for j in range(i + 1, len(mats)):
+            kj = type(mats[j]).__name__.replace("Matrix", "").lower()
+            ops.append((f"{ki}{i}x{kj}{j}", lambda mi=mi, mj=mats[j]: mi._cross_sandwich_dev(
+                mj, d, None, None, None)))
+    out = {}
+    _lib.call("tm_profile_enable", 1)
+    try:
+        for name, fn in ops:
+            ts = []
+            for _ in range(reps):
+                fn()
+                ms = C.c_float(0)
+                _lib.call("tm_profile_last_ms", C.byref(ms))
+                ts.append(ms.value)
+            out[name] = float(np.mean(ts[1:] if len(ts) > 1 else ts))
+    finally:
+        _lib.call("tm_profile_enable", 0)
+    return out
+
+
+def op_algorithmic_bytes(mat, name):
+    """Algorithmic HBM bytes of ONE launch of the named op's main kernel: each operand of that
+    kernel read once + its output written once ('algorithmic bytes')."""
+    import tabmat_amd as tm
+
+    mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
+    isz = np.dtype(mat.dtype).itemsize
+    n = mat.shape[0]
+
+    def blk_bytes(m):
+        if isinstance(m, tm.DenseMatrix):
+            return n * m.shape[1] * isz
+        if isinstance(m, tm.SparseMatrix):
+            c = m._dev()
+            return c.data.numel() * (isz + 4) + (n + 1) * 8
+        return n * 4
+
+    if name.endswith(".self"):
+        i = int("".join(ch for ch in name.split(".")[0] if ch.isdigit()))
+        k = mats[i].shape[1]
+        outb = k * isz if isinstance(mats[i], tm.CategoricalMatrix) else k * k * isz
+        return blk_bytes(mats[i]) + n * isz + outb
+    a, b = name.split("x")
+    i = int("".join(ch for ch in a if ch.isdigit()))
+    j = int("".join(ch for ch in b if ch.isdigit()))
+    return blk_bytes(mats[i]) + blk_bytes(mats[j]) + n * isz + mats[i].shape[1] * mats[j].shape[1] * isz
+
+
+def op_flops(mat, name):
+    import tabmat_amd as tm
+
+    mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
+    n = mat.shape[0]
+    if name.endswith(".self"):
+        i = int("".join(ch for ch in name.split(".")[0] if ch.isdigit()))
+        m = mats[i]
+        if isinstance(m, tm.DenseMatrix):
+            return float(n) * m.shape[1] * (m.shape[1] + 1)
+        return None
+    return None
+
+
+def cpu_baseline(workload, rows, seed):
+    """Time the CPU oracle ("port") on a bounded sample: the first `rows` rows of the same
+    recipe, all host cores (OpenMP).  Returns the JSON object or None."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _cases as cs
+        from oracle import oracle as orc
+    except Exception as e:  # oracle not built
+        return {"error": f"oracle unavailable: {e}"}
+    threads = orc.num_threads()
+    if workload == "cfg4":
+        specs, idx = cs.mixed_specs(rows, 128, 512, (256, 96, 32), seed=seed)
+        blocks = [cs.to_oracle_block(s) for s in specs]
+        d = np.random.default_rng(seed).random(rows)
+        nnz = blocks[1].csc.nnz
+        alg_bytes = rows * 128 * 8 + nnz * 12 + (rows + 1) * 8 + 3 * rows * 4 + rows * 8 + 1024 * 1024 * 8
+        fn = lambda: orc.split_sandwich(blocks, idx, d)
+    elif workload == "cfg2":
+        X = np.random.default_rng(seed).standard_normal((rows, 256), dtype=np.float32)
+        d = np.random.default_rng(seed + 1).random(rows, dtype=np.float32)
+        alg_bytes = rows * 256 * 4 + rows * 4 + 256 * 256 * 4
+        fn = lambda: orc.dense_sandwich(X, d, None, None)
+    else:
+        codes = np.random.default_rng(seed).integers(0, 10_000, rows).astype(np.int32)
+        d = np.random.default_rng(seed + 1).random(rows)
+        alg_bytes = rows * 12 + 10_000 * 8
+        fn = lambda: orc.sandwich_categorical(codes, d, None, 10_000)
+    fn()  # warm (threads, page faults)
+    best = float("inf")
+    t_all = time.time()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+        if time.time() - t_all > 25:
+            break
+    return {
+        "value": round(alg_bytes / best / 1e9, 4),
+        "unit": "GB/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"{workload} recipe, first {rows} rows, min of <=3 runs, {best * 1e3:.1f} ms",
+        "seconds": round(best, 4),
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from tabmat_amd import synth
+    from tabmat_amd.distributed import RowShardedMatrix
+
+    seed = 3 + rank
+    mat, tdt = build_workload(args.workload, args.rows, seed)
+    n_local, p = mat.shape
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + rank)
+    d = torch.rand(n_local, dtype=tdt, device="cuda", generator=g)
+    sharded = RowShardedMatrix(mat)
+
+    import tabmat_amd as tm
+
+    def step():
+        if isinstance(mat, tm.CategoricalMatrix):
+            out = mat._sandwich_diag_dev(d, None, None)
+        elif isinstance(mat, tm.SplitMatrix):
+            out = mat._sandwich_dev(d, None, None)
+        else:
+            out = mat._sandwich_dev(d, None, None)
+        if world > 1:
+            dist.all_reduce(out)  # RCCL over xGMI: p x p float64 (8 MB at p = 1024)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    alg_bytes = synth.algorithmic_bytes(mat)
+    flops = synth.algorithmic_flops(mat) if isinstance(mat, tm.SplitMatrix) else (
+        float(n_local) * p * (p + 1) if isinstance(mat, tm.DenseMatrix) else float(n_local))
+    if world > 1:
+        tot = torch.tensor([alg_bytes, flops], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        alg_bytes, flops = float(tot[0].item()), float(tot[1].item())
+
+    result = None
+    if rank == 0:
+        bd = kernel_breakdown(mat, d)
+        dom = max(bd, key=bd.get)
+        dom_ms = bd[dom]
+        dom_bytes = op_algorithmic_bytes(mat, dom)
+        dom_flops = op_flops(mat, dom)
+        hbm_time = dom_bytes / (HBM_PEAK_GBS * 1e9)
+        peak_tf = MFMA_F64_PEAK_TFLOPS if tdt == torch.float64 else MFMA_F32_PEAK_TFLOPS
+        mfma_time = (dom_flops / (peak_tf * 1e12)) if dom_flops else 0.0
+        if mfma_time > hbm_time:
+            roof = {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 3),
+                    "peak": peak_tf, "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"] = None  # PMC passes: see profiles/ (FETCH_SIZE x2 correction, gfx950)
+        roof["kernel"] = dom
+        roof["kernel_ms"] = round(dom_ms, 4)
+        roof["algorithmic_bytes_per_launch"] = int(dom_bytes)
+        wl_names = {
+            "cfg4": f"SplitMatrix.sandwich: dense128 + csr512@5% + cats(256,96,32), {n_local} rows/GPU, p={p}, float64 (BASELINE configs[3])",
+            "cfg2": f"DenseMatrix.sandwich float32 {n_local}x256 (BASELINE configs[1])",
+            "cfg3": f"CategoricalMatrix.sandwich {n_local} rows x 10k categories float64 (BASELINE configs[2])",
+        }
+        result = {
+            "metric": "SplitMatrix.sandwich GFLOP/s + effective HBM GB/s, 10M x 1k mixed",
+            "value": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+            "unit": "GB/s",
+            "gflops": round(flops / (ms_per_step * 1e-3) / 1e9, 1),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if tdt == torch.float64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": wl_names[args.workload], "rows_per_gpu": n_local, "p": p,
+                       "sharding": "rows" if world > 1 else "none",
+                       "collective": "all_reduce(p*p f64)" if world > 1 else "none"},
+            "roofline": roof,
+            "hbm_frac_whole_job": round(alg_bytes / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "sum_kernel_ms": round(sum(bd.values()), 4),
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rows, 3)
+        if args.breakdown:
+            for k, v in sorted(bd.items(), key=lambda kv: -kv[1]):
+                print(f"  {k:24s} {v:9.4f} ms", file=sys.stderr)
+        result_full = dict(result, breakdown_ms={k: round(v, 4) for k, v in bd.items()})
+        if args.out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+            with open(args.out, "w") as f:
+                json.dump(result_full, f, indent=1)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,10 @@ int tm_event_destroy(void *event);
 int tm_event_record(void *event, void *stream);
 int tm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
 
+/* ---- in-library timing of an op's MAIN kernel (events on the launch stream) ---- */
+int tm_profile_enable(int on);
+int tm_profile_last_ms(float *ms); /* duration of the last recorded main kernel; synchronises */
+
 /* =====================================================================================
  * Dense block  (reference: ext/dense.pyx + ext/dense_helpers-tmpl.cpp)
  * ===================================================================================== */

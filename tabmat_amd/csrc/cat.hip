@@ -155,9 +155,11 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
         TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_lds_kernel<F, TWO>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    prof_begin(st);
     hipLaunchKernelGGL((hist_lds_kernel<F, TWO>), dim3((unsigned)nblk, (unsigned)n_parts),
                        dim3(threads), lds, st, ci, cj, w, rows, n_iter, rows_per_block, drop_i,
                        drop_j, (int)i_ncol, (int)j_ncol, (int)ti, col_map, ws, stride);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, out, total, accumulate,
                                      st);
@@ -370,9 +372,11 @@ static int run_cat_dense(const int32_t *codes, int64_t n, int64_t i_ncol, int dr
     if (p.lds > 48 * 1024)
         TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk, (unsigned)p.n_parts), dim3(256), p.lds, st,
                        codes, d, rows, n_iter, p.rows_per_block, drop_first, (int)i_ncol,
                        (int)p.ti, M, n, M_ncol, j_cols, (int)n_j, ws, p.stride);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return launch_reduce_partials<F>(ws, p.stride, (int)p.nblk, (int)p.n_parts, out, total, false,
                                      st);
@@ -411,9 +415,11 @@ static int run_cat_sparse(const int32_t *codes, int64_t n, int64_t i_ncol, int d
     if (p.lds > 48 * 1024)
         TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.nblk, (unsigned)p.n_parts), dim3(256), p.lds, st,
                        codes, d, rows, n_iter, p.rows_per_block, drop_first, (int)i_ncol,
                        (int)p.ti, sdata, sind, sptr, col_map, (int)n_out, ws, p.stride);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return launch_reduce_partials<F>(ws, p.stride, (int)p.nblk, (int)p.n_parts, out, total, false,
                                      st);
@@ -459,8 +465,10 @@ static int run_cat_matvec(const int32_t *codes, int64_t n, int64_t n_cols, int d
         if (rc) return rc;
     }
     const int64_t nblk = std::min<int64_t>(ceil_div(n, 256 * 4), NUM_CU * 8);
+    prof_begin(st);
     hipLaunchKernelGGL((cat_matvec_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, codes, n,
                        drop_first, v, col_map, out);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return TM_OK;
 }

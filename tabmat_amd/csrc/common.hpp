@@ -37,6 +37,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // stays valid until the next get_workspace() call on the same device asks for more.
 int get_workspace(size_t bytes, void **ptr);
 
+// Optional in-library kernel timing (tm_profile_enable): HIP events recorded on the launch
+// stream immediately around the MAIN kernel of an op, so bench.py can quote the dominant
+// kernel's duration without a profiler attached.
+void prof_begin(hipStream_t st);
+void prof_end(hipStream_t st);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -345,8 +345,10 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
         if (C::LDS > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
+        prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
                            rows, n_iter, rpb, cols, n_cols, part);
+    prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
     };
@@ -568,12 +570,16 @@ static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const
     if (n_iter == 0 || n_cols == 0) return TM_OK;
     if (order_f) {
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256), NUM_CU * 8);
-        hipLaunchKernelGGL((dense_matvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, n,
+        prof_begin(st);
+    hipLaunchKernelGGL((dense_matvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, n,
                            v, rows, n_iter, cols, (int)n_cols, out);
+    prof_end(st);
     } else {
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 4), NUM_CU * 8);
-        hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
+        prof_begin(st);
+    hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
                            v, rows, n_iter, cols, (int)n_cols, out);
+    prof_end(st);
     }
     TM_LAUNCH_CHECK();
     return TM_OK;
@@ -589,12 +595,14 @@ static int run_dense_rmatvec(const F *X, int64_t n, int64_t m, int order_f, cons
     int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 512)), NUM_CU * 4);
     const int64_t rpb = ceil_div(n_iter, nblk);
     nblk = ceil_div(n_iter, rpb);
+    prof_begin(st);
     if (order_f)
         hipLaunchKernelGGL((dense_rmatvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X,
                            n, v, rows, n_iter, rpb, cols, (int)n_cols, out);
     else
         hipLaunchKernelGGL((dense_rmatvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X,
                            m, v, rows, n_iter, rpb, cols, (int)n_cols, out);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return TM_OK;
 }

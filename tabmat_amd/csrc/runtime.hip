@@ -61,6 +61,25 @@ int get_workspace(size_t bytes, void **ptr) {
     return TM_OK;
 }
 
+static bool g_prof_on = false;
+static hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
+static bool g_prof_valid = false;
+
+void prof_begin(hipStream_t st) {
+    if (!g_prof_on) return;
+    if (!g_prof_a) {
+        (void)hipEventCreate(&g_prof_a);
+        (void)hipEventCreate(&g_prof_b);
+    }
+    (void)hipEventRecord(g_prof_a, st);
+}
+
+void prof_end(hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_prof_b, st);
+    g_prof_valid = true;
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -146,6 +165,23 @@ int tm_set_workspace(void *ptr, size_t bytes) {
         w.bytes = 0;
         w.external = false;
     }
+    return TM_OK;
+}
+
+int tm_profile_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_valid = false;
+    return TM_OK;
+}
+
+int tm_profile_last_ms(float *ms) {
+    TM_REQUIRE(ms != nullptr, "ms is NULL");
+    if (!g_prof_valid) {
+        set_error("tm_profile_last_ms: no kernel recorded (call tm_profile_enable(1) first)");
+        return TM_EINVAL;
+    }
+    TM_HIP(hipEventSynchronize(g_prof_b));
+    TM_HIP(hipEventElapsedTime(ms, g_prof_a, g_prof_b));
     return TM_OK;
 }
 

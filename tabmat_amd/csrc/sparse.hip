@@ -272,8 +272,10 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     }
     constexpr int G = 16;
     const int64_t nblk = std::min<int64_t>(ceil_div(n_iter * G, 256), NUM_CU * 16);
+    prof_begin(st);
     hipLaunchKernelGGL((csr_matvec_kernel<F, G>), dim3((unsigned)nblk), dim3(256), 0, st, data, ind,
                        ptr, v, rows, n_iter, col_map, out);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     return TM_OK;
 }
@@ -308,8 +310,10 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
+        prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
                            n_iter, rpb, col_map, (int)n_out, ws, out);
+    prof_end(st);
         TM_LAUNCH_CHECK();
         return launch_reduce_partials<F>(ws, n_out, (int)nblk, 1, out, n_out, true, st);
     }
@@ -368,9 +372,11 @@ static int run_csr_dense(const F *data, const int32_t *ind, const int64_t *ptr, 
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data,
+        prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data,
                            ind, ptr, B, n, r, d, rows, n_iter, rpb, a_map, (int)nA, B_cols, (int)nB,
                            ws, stride);
+    prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
     };
@@ -441,8 +447,10 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
     auto kern = &sparse_sandwich_kernel<F, TS>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data, ind,
                        ptr, d, rows, n_iter, rpb, col_map, (int)n_out, ws);
+    prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,
                                    (int64_t)n_parts * TS * TS, false, st);

@@ -10,6 +10,8 @@ def transpose_matvec(indices, other, n_cols, rows, cols, out, drop_first=False):
     """ext/categorical.pyx:23-117 (transpose_matvec_fast/_complex): out[c] += ... in place;
     `out` has full block width n_cols, only columns in `cols` are touched."""
     n = indices.numel()
+    if (rows is not None and D.nlen(rows) == 0) or (cols is not None and D.nlen(cols) == 0):
+        return  # an empty tensor has a NULL data pointer, which the C ABI reads as "all"
     if rows is not None and D.nlen(rows) == n:
         rows = None
     if cols is not None and D.nlen(cols) == n_cols:
@@ -20,6 +22,8 @@ def transpose_matvec(indices, other, n_cols, rows, cols, out, drop_first=False):
 
 def matvec(indices, other, n_rows, cols, n_cols, out_vec, drop_first=False):
     """ext/categorical.pyx:128-180 (matvec_fast/_complex): out_vec[i] += other[col(i)]."""
+    if cols is not None and D.nlen(cols) == 0:
+        return
     call(f"tm_cat_matvec_{D.fsuf(out_vec)}", D.p(indices), n_rows, n_cols, int(drop_first),
          D.p(other), D.p(cols), D.nlen(cols), D.p(out_vec), D.stream_ptr())
 

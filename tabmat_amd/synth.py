@@ -1,0 +1,109 @@
+"""Synthetic tabular designs generated directly in HBM (SURVEY.md 8d recipes), so the 10M-row
+benchmark configurations never exist as 13 GB host arrays.  Used by bench.py and by the
+full-size property tests; NOT part of the sandwich / matvec path itself."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _device as D
+from .categorical_matrix import CategoricalMatrix
+from .dense_matrix import DenseMatrix
+from .ext._types import CsrDev
+from .sparse_matrix import SparseMatrix
+from .split_matrix import SplitMatrix
+
+
+def _gen(seed: int) -> torch.Generator:
+    g = torch.Generator(device=D.require_gpu())
+    g.manual_seed(int(seed))
+    return g
+
+
+def dense_block(n: int, k: int, dtype=torch.float64, seed: int = 0, order: str = "C") -> DenseMatrix:
+    g = _gen(seed)
+    if order == "C":
+        t = torch.randn((n, k), dtype=dtype, device=g.device, generator=g)
+        return DenseMatrix(t)
+    t = torch.randn((k, n), dtype=dtype, device=g.device, generator=g)
+    return DenseMatrix(t.T)
+
+
+def sparse_block(n: int, m: int, density: float = 0.05, dtype=torch.float64, seed: int = 0,
+                 chunk: int = 1 << 20) -> SparseMatrix:
+    """Bernoulli(density) pattern, U(0,1) values, built chunk-wise as a CSR twin in HBM."""
+    g = _gen(seed)
+    dev = g.device
+    datas, inds, counts = [], [], []
+    for r0 in range(0, n, chunk):
+        r = min(chunk, n - r0)
+        mask = torch.rand((r, m), device=dev, generator=g) < density
+        counts.append(mask.sum(dim=1))
+        nz = mask.nonzero(as_tuple=False)          # row-major => sorted by (row, col)
+        inds.append(nz[:, 1].to(torch.int32))
+        datas.append(torch.rand((nz.shape[0],), dtype=dtype, device=dev, generator=g))
+        del mask, nz
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.cat(counts), dim=0, out=indptr[1:])
+    csr = CsrDev(torch.cat(datas), torch.cat(inds), indptr, n, m)
+    return SparseMatrix.from_device(csr)
+
+
+def cat_block(n: int, n_categories: int, seed: int = 0, dtype=np.float64, drop_first=False,
+              zipf: float = 0.0) -> CategoricalMatrix:
+    g = _gen(seed)
+    if zipf > 0:
+        w = 1.0 / torch.arange(1, n_categories + 1, dtype=torch.float64, device=g.device) ** zipf
+        codes = torch.multinomial(w / w.sum(), n, replacement=True, generator=g).to(torch.int32)
+    else:
+        codes = torch.randint(0, n_categories, (n,), dtype=torch.int32, device=g.device, generator=g)
+    return CategoricalMatrix(codes, categories=np.arange(n_categories), drop_first=drop_first,
+                             dtype=dtype)
+
+
+def mixed_split(n: int, k_dense: int = 128, k_sparse: int = 512, cats=(256, 96, 32),
+                density: float = 0.05, dtype=torch.float64, seed: int = 3) -> SplitMatrix:
+    """BASELINE.json config 4: block order [dense, sparse, cat, cat, cat] => p = 1024."""
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    blocks = [dense_block(n, k_dense, dtype, seed), sparse_block(n, k_sparse, density, dtype, seed + 1000)]
+    for i, c in enumerate(cats):
+        blocks.append(cat_block(n, c, seed + 2000 + i, npdt))
+    return SplitMatrix(blocks)
+
+
+def algorithmic_bytes(mat) -> int:
+    """Bytes of every operand read once + the output written once."""
+    total = 0
+    mats = mat.matrices if isinstance(mat, SplitMatrix) else [mat]
+    isz = np.dtype(mat.dtype).itemsize
+    n = mat.shape[0]
+    for m in mats:
+        if isinstance(m, DenseMatrix):
+            total += m.shape[0] * m.shape[1] * isz
+        elif isinstance(m, SparseMatrix):
+            c = m._dev()
+            total += c.data.numel() * (isz + 4) + (n + 1) * 8
+        else:
+            total += n * 4
+    total += n * isz                       # d
+    total += mat.shape[1] ** 2 * 8         # float64 p x p result
+    return int(total)
+
+
+def algorithmic_flops(mat) -> float:
+    """FMA = 2 flops, symmetric half only."""
+    mats = mat.matrices if isinstance(mat, SplitMatrix) else [mat]
+    n = mat.shape[0]
+    fl = 0.0
+    dense_k = sum(m.shape[1] for m in mats if isinstance(m, DenseMatrix))
+    nnz = sum(m._dev().data.numel() for m in mats if isinstance(m, SparseMatrix))
+    n_cat = sum(1 for m in mats if isinstance(m, CategoricalMatrix))
+    fl += n * dense_k * (dense_k + 1)
+    for m in mats:
+        if isinstance(m, SparseMatrix):
+            c = m._dev()
+            per_row = (c.indptr[1:] - c.indptr[:-1]).to(torch.float64)
+            fl += float((per_row * (per_row + 1)).sum().item())
+    fl += 2.0 * nnz * dense_k + n_cat * 2.0 * n * dense_k + n_cat * 2.0 * nnz
+    fl += n * (n_cat + n_cat * (n_cat - 1) / 2)
+    return fl
