@@ -142,6 +142,23 @@ int tm_csr_dense_sandwich_f64(const double *csr_data, const int32_t *csr_indices
                               int64_t n_rows, const int32_t *A_cols, int64_t nA,
                               const int32_t *B_cols, int64_t nB, double *out, void *stream);
 
+/* Same product as tm_csr_dense_sandwich_* with rows = A_cols = B_cols = NULL and a C-ordered B,
+ * on the slab-blocked column-major twin of the sparse block (the fast path; restrictions are
+ * applied by the host side through a masked d and sub-selection of the small result).
+ * Layout: rows cut into slabs of tm_slab_rows() rows; within a slab nonzeros ordered by
+ * (column, row); vals[e] = A[k,i]; koff[e] = (k - slab*R) * 64 * sizeof(F);
+ * cnt[slab][mpad] run length per (slab, column), mpad = C*ceil(m/C), C = tm_slab_group_cols();
+ * gptr[slab*G + g] start of column-group g (C columns) of that slab, G = ceil(m/C),
+ * with one trailing total.  out is [m x r] row-major. */
+int tm_slab_rows(void);
+int tm_slab_group_cols(void);
+int tm_csr_dense_sandwich_slab_f32(const float *vals, const uint32_t *koff, const uint16_t *cnt,
+                                   const int64_t *gptr, int64_t n, int64_t m, const float *B,
+                                   int64_t r, const float *d, float *out, void *stream);
+int tm_csr_dense_sandwich_slab_f64(const double *vals, const uint32_t *koff, const uint16_t *cnt,
+                                   const int64_t *gptr, int64_t n, int64_t m, const double *B,
+                                   int64_t r, const double *d, double *out, void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

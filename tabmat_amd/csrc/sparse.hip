@@ -502,3 +502,290 @@ int tm_csr_dense_sandwich_f64(const double *csr_data, const int32_t *csr_indices
 }
 
 }  // extern "C"
+
+namespace tmh {
+
+// =======================================================================================
+// K3 (v2)  sparse x dense cross sandwich as a slab-blocked GATHER with static register
+// accumulators ("segmented wavefront reduction over column nonzeros").
+//
+// Format (built once per sparse block, see tabmat_amd/ext/_types.py SlabCsc): rows are cut
+// into slabs of SLAB_R rows; inside a slab the nonzeros are ordered by (column, row), so the
+// entries of one (slab, column) pair are one contiguous run:
+//     vals[e]  value A[k, i]
+//     koff[e]  (k - slab*SLAB_R) * 64 * sizeof(F)   -- byte offset of row k in the LDS slab
+//     cnt [slab][column]   run length (uint16), columns padded to a multiple of 64
+//     gptr[slab][group]    start of the run of column-group `group` (64 columns) in that slab
+//
+// Kernel: a workgroup of 8 waves owns a range of slabs and a 64-column part of the dense
+// operand.  Per slab it stages  dB[k, j] = d[k] * B[k, j0 + j]  (SLAB_R x 64) into LDS with
+// coalesced 16-byte loads (double-buffered, one barrier per slab).  Wave w owns sparse
+// columns [64 w, 64 w + 64): lane <-> dense column j, and the 64 accumulators
+// out[64 w + c, j0 + lane], c = 0..63, are STATIC registers (the column loop is fully
+// unrolled), kept for the whole slab range.  Each nonzero costs one ds_read_b64 of the LDS slab
+// row and one v_fma_f64; the (value, offset) stream is fetched 64 entries at a time with one
+// coalesced vector load and broadcast with v_readlane.  No atomics, no LDS writes in the
+// inner loop; partial results are reduced by reduce_partials_kernel.
+// =======================================================================================
+constexpr int SLAB_R = 128;
+
+template <typename F>
+__device__ __forceinline__ F readlane_f(F v, int l);
+
+template <>
+__device__ __forceinline__ double readlane_f<double>(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <>
+__device__ __forceinline__ float readlane_f<float>(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+constexpr int GATHER_CPW = 32;                      // sparse columns (static accumulators) per wave
+constexpr int GATHER_NW = 16;                       // waves per workgroup -> 512 sparse columns
+constexpr int GATHER_THREADS = GATHER_NW * 64;
+
+// One entry step: broadcast (value, row offset) of stream position p from the 64-entry
+// register chunk, read the LDS slab row, fused multiply-add into the STATIC accumulator.
+#define TM_GATHER_LOAD(A, X, LIDX)                                                        \
+    const F A = readlane_f<F>(va, (LIDX));                                                \
+    const F X = *reinterpret_cast<const F *>(                                             \
+        slab + (unsigned)__builtin_amdgcn_readlane((int)vk, (LIDX)) + lane_off);
+
+template <typename F, int C>
+struct ColLoop {
+    // processes static column C of the wave's group, then recurses to C + 1
+    static __device__ __forceinline__ void run(F (&acc)[GATHER_CPW],
+                                               const unsigned char *__restrict__ slab, int cntv,
+                                               int &pos, F &va, unsigned &vk, F &na, unsigned &nk,
+                                               const F *__restrict__ vals,
+                                               const unsigned *__restrict__ koff, int64_t base,
+                                               int total, int lane, int lane_off) {
+        int nc = __builtin_amdgcn_readlane(cntv, C);
+        while (nc > 0) {
+            // stay inside the current 64-entry chunk: no rotation test in the hot loop
+            const int l0 = pos & 63;
+            const int m = min(nc, 64 - l0);
+            int t = 0;
+            for (; t + 4 <= m; t += 4) {   // 4 independent LDS reads in flight
+                TM_GATHER_LOAD(a0, x0, l0 + t)
+                TM_GATHER_LOAD(a1, x1, l0 + t + 1)
+                TM_GATHER_LOAD(a2, x2, l0 + t + 2)
+                TM_GATHER_LOAD(a3, x3, l0 + t + 3)
+                acc[C] = fma(a0, x0, acc[C]);
+                acc[C] = fma(a1, x1, acc[C]);
+                acc[C] = fma(a2, x2, acc[C]);
+                acc[C] = fma(a3, x3, acc[C]);
+            }
+            for (; t < m; ++t) {
+                TM_GATHER_LOAD(a0, x0, l0 + t)
+                acc[C] = fma(a0, x0, acc[C]);
+            }
+            pos += m;
+            nc -= m;
+            if ((pos & 63) == 0) {
+                // chunk exhausted: rotate in the prefetched chunk, issue the next prefetch
+                va = na;
+                vk = nk;
+                const int nxt = pos + 64 + lane;
+                if (nxt < total) {
+                    na = vals[base + nxt];
+                    nk = koff[base + nxt];
+                }
+            }
+        }
+        if constexpr (C + 1 < GATHER_CPW)
+            ColLoop<F, C + 1>::run(acc, slab, cntv, pos, va, vk, na, nk, vals, koff, base, total,
+                                   lane, lane_off);
+    }
+};
+
+template <typename F>
+__global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
+    const F *__restrict__ vals, const unsigned *__restrict__ koff,
+    const unsigned short *__restrict__ cnt, const int64_t *__restrict__ gptr, int n_groups,
+    int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
+    int nB, const F *__restrict__ d, F *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int VEC = 16 / (int)sizeof(F);
+    constexpr int ROWB = 64 * (int)sizeof(F);            // bytes per LDS slab row
+    constexpr int SLABB = SLAB_R * ROWB;                 // bytes per LDS buffer
+    constexpr int NV = SLAB_R * 64 / VEC / GATHER_THREADS;  // 16-byte vectors staged per thread
+    static_assert(NV >= 1, "staging needs at least one vector per thread");
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int group = blockIdx.z * GATHER_NW + wave;
+    const bool active = group < n_groups;
+    const int j0 = blockIdx.y * 64;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const int lane_off = lane * (int)sizeof(F);
+
+    F acc[GATHER_CPW];
+#pragma unroll
+    for (int c = 0; c < GATHER_CPW; ++c) acc[c] = F(0);
+
+    vec_t stage[NV];
+    auto load_slab = [&](int64_t s) {
+        constexpr int VPR = 64 / VEC;  // vectors per slab row
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = tid + i * GATHER_THREADS;
+            const int row = q / VPR;
+            const int c = (q % VPR) * VEC;
+            const int64_t k = s * SLAB_R + row;
+            vec_t v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = F(0);
+            if (k < n) {
+                const F dk = d[k];
+                const F *src = B + k * r + j0 + c;
+                if (j0 + c + VEC <= nB && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                    v = *reinterpret_cast<const vec_t *>(src);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] *= dk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (j0 + c + e < nB) v[e] = dk * src[e];
+                }
+            }
+            stage[i] = v;
+        }
+    };
+    auto store_slab = [&](int buf) {
+        constexpr int VPR = 64 / VEC;
+        unsigned char *dst = smem_raw + buf * SLABB;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = tid + i * GATHER_THREADS;
+            const int row = q / VPR;
+            const int c = (q % VPR) * VEC;
+            *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = stage[i];
+        }
+    };
+
+    if (s0 < s1) {
+        load_slab(s0);
+        store_slab(0);
+    }
+    __syncthreads();
+    for (int64_t s = s0; s < s1; ++s) {
+        const int buf = (int)((s - s0) & 1);
+        if (s + 1 < s1) load_slab(s + 1);
+        if (active) {
+            const int cntv = lane < GATHER_CPW ? (int)cnt[(s * n_groups + group) * GATHER_CPW + lane] : 0;
+            const int64_t base = gptr[s * n_groups + group];
+            const int total = (int)(gptr[s * n_groups + group + 1] - base);
+            if (total > 0) {
+                F va = F(0), na = F(0);
+                unsigned vk = 0, nk = 0;
+                if (lane < total) {
+                    va = vals[base + lane];
+                    vk = koff[base + lane];
+                }
+                if (64 + lane < total) {
+                    na = vals[base + 64 + lane];
+                    nk = koff[base + 64 + lane];
+                }
+                int pos = 0;
+                ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, cntv, pos, va, vk, na, nk, vals,
+                                   koff, base, total, lane, lane_off);
+            }
+        }
+        if (s + 1 < s1) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+    if (active) {
+        // ws layout: [part = blockIdx.y][blockIdx.x][n_groups * CPW cols][64]
+        F *dst = ws + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_groups + group) *
+                          (GATHER_CPW * 64);
+#pragma unroll
+        for (int c = 0; c < GATHER_CPW; ++c) dst[c * 64 + lane] = acc[c];
+    }
+}
+
+// tmp [part][n_groups*64][64] -> out[m][nB]
+template <typename F>
+__global__ void gather_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t nB,
+                                     int64_t mpad, F *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * nB) return;
+    const int64_t i = e / nB, j = e % nB;
+    out[e] = tmp[((j / 64) * mpad + i) * 64 + (j % 64)];
+}
+
+template <typename F>
+static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsigned short *cnt,
+                                const int64_t *gptr, int64_t n, int64_t m, const F *B, int64_t r,
+                                const F *d, F *out, hipStream_t st) {
+    const int64_t nB = r;
+    const int64_t total = m * nB;
+    if (total == 0) return TM_OK;
+    const int64_t n_slabs = ceil_div(n, SLAB_R);
+    const int n_groups = (int)ceil_div(m, GATHER_CPW);
+    const int64_t mpad = (int64_t)n_groups * GATHER_CPW;
+    const int n_parts = (int)ceil_div(nB, 64);
+    const int nz = (int)ceil_div(n_groups, GATHER_NW);
+    if (n_slabs == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / ((int64_t)n_parts * nz));
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const int64_t stride = mpad * 64;  // per (part, block)
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
+    void *wsv = nullptr;
+    int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
+                           &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F);
+    auto kern = &csr_dense_gather_kernel<F>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS), lds,
+                       st, vals, koff, cnt, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false,
+                                   st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gather_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                       st, tmp, m, nB, mpad, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+extern "C" {
+
+int tm_slab_rows(void) { return tmh::SLAB_R; }
+int tm_slab_group_cols(void) { return tmh::GATHER_CPW; }
+
+int tm_csr_dense_sandwich_slab_f32(const float *vals, const uint32_t *koff, const uint16_t *cnt,
+                                   const int64_t *gptr, int64_t n, int64_t m, const float *B,
+                                   int64_t r, const float *d, float *out, void *stream) {
+    return tmh::run_csr_dense_gather<float>(vals, koff, cnt, gptr, n, m, B, r, d, out,
+                                            tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_slab_f64(const double *vals, const uint32_t *koff, const uint16_t *cnt,
+                                   const int64_t *gptr, int64_t n, int64_t m, const double *B,
+                                   int64_t r, const double *d, double *out, void *stream) {
+    return tmh::run_csr_dense_gather<double>(vals, koff, cnt, gptr, n, m, B, r, d, out,
+                                             tmh::as_stream(stream));
+}
+
+}  // extern "C"

@@ -74,3 +74,53 @@ class CsrDev:
             n,
             m,
         )
+
+
+@dataclass
+class SlabCsc:
+    """Slab-blocked column-major twin of a sparse block (see tm_csr_dense_sandwich_slab_* in
+    include/tabmat_hip.h): rows cut into slabs of R rows, nonzeros inside a slab ordered by
+    (column, row).  Built once per block from the CSR twin; the format conversion is one-off
+    ingest work (a key sort) and uses torch's device sort, the products never do."""
+
+    vals: torch.Tensor     # F[nnz]
+    koff: torch.Tensor     # int32[nnz]  byte offset of the entry's row inside the LDS slab part
+    cnt: torch.Tensor      # int16[S * mpad] (read as uint16) run length per (slab, column)
+    gptr: torch.Tensor     # int64[S * G + 1]
+    n: int
+    m: int
+
+    @staticmethod
+    def from_csr(csr: CsrDev) -> "SlabCsc":
+        from .._lib import lib
+
+        R = int(lib().tm_slab_rows())
+        C = int(lib().tm_slab_group_cols())
+        n, m = csr.n, csr.m
+        dev = csr.data.device
+        fbytes = csr.data.element_size()
+        S = (n + R - 1) // R
+        G = (m + C - 1) // C
+        mpad = G * C
+        counts = csr.indptr[1:] - csr.indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
+        slab = torch.div(rows, R, rounding_mode="floor")
+        key = slab * mpad + csr.indices.to(torch.int64)
+        del slab
+        # CSR order is (row, column)-sorted, so a STABLE sort by (slab, column) leaves the rows
+        # of every (slab, column) run ascending
+        key_sorted, perm = torch.sort(key, stable=True)
+        del key
+        vals = csr.data[perm].contiguous()
+        rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
+        del rows, perm
+        koff = (rloc * (64 * fbytes)).to(torch.int32).contiguous()
+        del rloc
+        cnt64 = torch.bincount(key_sorted, minlength=S * mpad) if key_sorted.numel() else \
+            torch.zeros(S * mpad, dtype=torch.int64, device=dev)
+        del key_sorted
+        gptr = torch.zeros(S * G + 1, dtype=torch.int64, device=dev)
+        if S * G:
+            torch.cumsum(cnt64.view(S * G, C).sum(dim=1), dim=0, out=gptr[1:])
+        cnt = cnt64.to(torch.int16).contiguous()   # <= R = 128, bit pattern == uint16
+        return SlabCsc(vals, koff, cnt, gptr, n, m)

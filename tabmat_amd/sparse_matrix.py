@@ -8,7 +8,7 @@ from scipy import sparse as sps
 
 from . import _device as D
 from .ext import sparse as xs
-from .ext._types import CsrDev
+from .ext._types import CsrDev, SlabCsc
 from .matrix_base import MatrixBase
 from .util import (
     check_indexer,
@@ -41,6 +41,7 @@ class SparseMatrix(MatrixBase):
             self._array.sort_indices()
         self._array_csr = None
         self._devblk = None
+        self._slabblk = None
         self._shape = self._array.shape
         self._dtype = self._array.dtype
         self._init_names(column_names, term_names)
@@ -61,6 +62,7 @@ class SparseMatrix(MatrixBase):
         self._array = None
         self._array_csr = None
         self._devblk = csr
+        self._slabblk = None
         self._shape = (csr.n, csr.m)
         self._dtype = np.dtype(np.float64 if csr.data.dtype == torch.float64 else np.float32)
         self.idx_dtype = np.dtype(np.int32)
@@ -93,8 +95,16 @@ class SparseMatrix(MatrixBase):
             self._devblk = CsrDev.from_scipy(self.array_csr)
         return self._devblk
 
+    def _slab(self) -> SlabCsc:
+        """Slab-blocked column-major twin used by the sparse x dense gather kernel (built on
+        first use; the reference likewise materialises its CSR twin lazily)."""
+        if getattr(self, "_slabblk", None) is None:
+            self._slabblk = SlabCsc.from_csr(self._dev())
+        return self._slabblk
+
     def to_device(self):
         self._dev()
+        self._slab()
         return self
 
     @property
@@ -185,7 +195,22 @@ class SparseMatrix(MatrixBase):
                     "self, B and d all need to be of same dtype, either np.float64 or "
                     f"np.float32. This matrix is of type {self.dtype}, B is of type "
                     f"{other.dtype}.")
-            return xs.csr_dense_sandwich(self._dev(), other._dev(), d, rows, L_cols, R_cols)
+            Bd = other._dev()
+            if Bd.order_f == 0 and self.shape[0] > 0 and self._dev().data.numel() > 0:
+                # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded
+                # rows contribute exactly 0), column restrictions select from the small result
+                if rows is not None:
+                    dm = torch.zeros_like(d)
+                    r64 = rows.to(torch.int64)
+                    dm[r64] = d[r64]
+                    d = dm
+                res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)
+                if L_cols is not None:
+                    res = res[L_cols.to(torch.int64)]
+                if R_cols is not None:
+                    res = res[:, R_cols.to(torch.int64)]
+                return res
+            return xs.csr_dense_sandwich(self._dev(), Bd, d, rows, L_cols, R_cols)
         if isinstance(other, CategoricalMatrix):
             return other._cross_sandwich_dev(self, d, rows, R_cols, L_cols).T
         raise TypeError
