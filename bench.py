@@ -81,6 +81,23 @@ def kernel_breakdown(mat, d, reps=3):
             kj = type(mats[j]).__name__.replace("Matrix", "").lower()
             ops.append((f"{ki}{i}x{kj}{j}", lambda mi=mi, mj=mats[j]: mi._cross_sandwich_dev(
                 mj, d, None, None, None)))
+    if isinstance(mat, tm.SplitMatrix):
+        from tabmat_amd.ext import split as xsplit
+
+        cat_ms = [m for m in mats if isinstance(m, tm.CategoricalMatrix)]
+        if len(cat_ms) >= 2:
+            cats = [(m._dev(), m.shape[1], m.drop_first) for m in cat_ms]
+            fused = []
+            for i, mw in enumerate(mats):
+                if isinstance(mw, tm.DenseMatrix):
+                    fused.append((f"allcats_x_dense{i}", lambda mw=mw: xsplit.multi_cat_dense_sandwich(
+                        cats, d, mw._dev())))
+                elif isinstance(mw, tm.SparseMatrix):
+                    fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
+                        cats, d, mw._slab())))
+            # the fused kernels replace the per-pair categorical cross terms
+            ops = [o for o in ops if not (("categorical" in o[0]) and ("dense" in o[0] or "sparse" in o[0])
+                                          and "x" in o[0])] + fused
     out = {}
     _lib.call("tm_profile_enable", 1)
     try:
@@ -119,6 +136,11 @@ def op_algorithmic_bytes(mat, name):
         k = mats[i].shape[1]
         outb = k * isz if isinstance(mats[i], tm.CategoricalMatrix) else k * k * isz
         return blk_bytes(mats[i]) + n * isz + outb
+    if name.startswith("allcats_x_"):
+        w = int("".join(ch for ch in name if ch.isdigit()))
+        cat_ms = [m for m in mats if isinstance(m, tm.CategoricalMatrix)]
+        return (blk_bytes(mats[w]) + sum(blk_bytes(m) for m in cat_ms) + n * isz
+                + sum(m.shape[1] for m in cat_ms) * mats[w].shape[1] * isz)
     a, b = name.split("x")
     i = int("".join(ch for ch in a if ch.isdigit()))
     j = int("".join(ch for ch in b if ch.isdigit()))

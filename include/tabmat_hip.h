@@ -252,6 +252,35 @@ int tm_cat_sparse_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, 
                                const int32_t *rows, int64_t n_rows, const int32_t *cols,
                                int64_t n_cols, double *out, void *stream);
 
+/* Fused cross terms of ALL categorical blocks of a SplitMatrix with its dense block (or with
+ * its sparse block in slab form): one pass over the wide operand serves every categorical, so it
+ * is read from HBM once instead of once per categorical.  Replaces n_cats calls of
+ * sandwich_cat_dense (ext/split.pyx:32-80) resp. of the scipy product of
+ * categorical_matrix.py:825-838 made by the loop of split_matrix.py:346-354.
+ * h_codes / h_ncols / h_drop_first are HOST arrays of length n_cats (<= 16) holding the device
+ * pointer of each code vector, its number of columns and its drop_first flag.  All rows, all
+ * columns (restrictions: masked d + sub-selection on the host side).
+ * out is [sum(h_ncols) x M_ncol] (resp. x m) row-major: the blocks of the categoricals stacked. */
+int tm_multi_cat_dense_sandwich_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                    const int32_t *h_drop_first, int n_cats, int64_t n,
+                                    const float *d, const float *M, int64_t M_ncol, int order_f,
+                                    float *out, void *stream);
+int tm_multi_cat_dense_sandwich_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                    const int32_t *h_drop_first, int n_cats, int64_t n,
+                                    const double *d, const double *M, int64_t M_ncol, int order_f,
+                                    double *out, void *stream);
+/* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
+int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n,
+                                          const float *d, const float *vals, const uint32_t *koff,
+                                          const uint8_t *ecol, const int64_t *gptr, int64_t m,
+                                          float *out, void *stream);
+int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n,
+                                          const double *d, const double *vals, const uint32_t *koff,
+                                          const uint8_t *ecol, const int64_t *gptr, int64_t m,
+                                          double *out, void *stream);
+
 /* =====================================================================================
  * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block
  * result into the float64 p x p output at the block's global column positions,

@@ -473,6 +473,280 @@ static int run_cat_matvec(const int32_t *codes, int64_t n, int64_t n_cols, int d
     return TM_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// FUSED cross terms of ALL categorical blocks of a SplitMatrix with its dense / sparse block.
+// One pass over the wide operand serves every categorical: the LDS tile holds the stacked
+// outputs [sum_c ncol_c][TJ] of a TJ-column slice of the wide operand (parts = column slices),
+// so the dense block is read from HBM exactly once for all categoricals together (instead of
+// once per categorical) and the 4-byte codes are re-read once per part.
+// ---------------------------------------------------------------------------------------
+constexpr int MAX_CATS = 16;
+struct CatSet {
+    const int32_t *codes[MAX_CATS];
+    int ncol[MAX_CATS];
+    int drop[MAX_CATS];
+    int off[MAX_CATS];   // row offset of categorical c in the stacked output
+    int n_cats;
+    int total;           // sum of ncol
+};
+
+// C-ordered dense: TJ lanes per row (64 / TJ rows per wave step), lane <-> dense column.
+template <typename F, int TJ>
+__global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
+    int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][TJ]
+    const int nel = cs.total * TJ;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+    constexpr int RPW = 64 / TJ;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / TJ, jl = lane % TJ;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int64_t j = (int64_t)blockIdx.y * TJ + jl;
+    const bool jok = j < m;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    const int64_t step = (int64_t)nwave * RPW;
+    for (int64_t k = t0 + (int64_t)wave * RPW + sub; k < t1; k += 2 * step) {
+        // two independent rows per iteration: more loads in flight
+        const int64_t k2 = k + step;
+        const bool ok2 = k2 < t1;
+        F x1 = F(0), x2 = F(0);
+        if (jok) {
+            x1 = d[k] * M[k * m + j];
+            if (ok2) x2 = d[k2] * M[k2 * m + j];
+        }
+#pragma unroll 1
+        for (int c = 0; c < cs.n_cats; ++c) {
+            const int c1 = cs.codes[c][k] - cs.drop[c];
+            const int c2 = ok2 ? cs.codes[c][k2] - cs.drop[c] : -1;
+            if (jok && c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * TJ + jl], x1);
+            if (jok && c2 >= 0) atomic_add(&tile[(cs.off[c] + c2) * TJ + jl], x2);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+// F-ordered dense: lane <-> row, loop over the TJ columns of the part.
+template <typename F, int TJ>
+__global__ __launch_bounds__(1024) void multi_cat_dense_f_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
+    int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);
+    const int nel = cs.total * TJ;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+    const int64_t j0 = (int64_t)blockIdx.y * TJ;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    for (int64_t k = t0 + threadIdx.x; k < t1; k += blockDim.x) {
+        const F dk = d[k];
+        int col[MAX_CATS];
+#pragma unroll
+        for (int c = 0; c < MAX_CATS; ++c)
+            col[c] = c < cs.n_cats ? cs.codes[c][k] - cs.drop[c] : -1;
+        for (int jl = 0; jl < TJ && j0 + jl < m; ++jl) {
+            const F x = dk * M[(j0 + jl) * n + k];
+#pragma unroll
+            for (int c = 0; c < MAX_CATS; ++c)
+                if (col[c] >= 0) atomic_add(&tile[(cs.off[c] + col[c]) * TJ + jl], x);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+// tmp [part][total][TJ] -> out[total][m]
+template <typename F>
+__global__ void multi_cat_untile_kernel(const F *__restrict__ tmp, int64_t total, int64_t m,
+                                        int TJ, F *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total * m) return;
+    const int64_t a = e / m, j = e % m;
+    out[e] = tmp[((j / TJ) * total + a) * TJ + (j % TJ)];
+}
+
+// Sparse operand in slab-blocked column-major form (sparse.hip): part = one 32-column group,
+// lane <-> nonzero of the (slab, group) stream.
+template <typename F>
+__global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals,
+    const unsigned *__restrict__ koff, const unsigned char *__restrict__ ecol,
+    const int64_t *__restrict__ gptr, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
+    int slab_rows, int group_cols, F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols]
+    const int nel = cs.total * group_cols;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+    const int g = blockIdx.y;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const unsigned rowb = 64u * (unsigned)sizeof(F);
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t base = gptr[s * n_groups + g];
+        const int64_t end = gptr[s * n_groups + g + 1];
+        for (int64_t e = base + threadIdx.x; e < end; e += blockDim.x) {
+            const int64_t k = s * slab_rows + (int64_t)(koff[e] / rowb);
+            const F x = d[k] * vals[e];
+            const int ec = ecol[e];
+#pragma unroll 1
+            for (int c = 0; c < cs.n_cats; ++c) {
+                const int cc = cs.codes[c][k] - cs.drop[c];
+                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * group_cols + ec], x);
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+}
+
+static int make_catset(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
+                       int n_cats, CatSet *cs) {
+    if (n_cats < 1 || n_cats > MAX_CATS) {
+        set_error("multi-cat call supports 1..%d categoricals, got %d", MAX_CATS, n_cats);
+        return TM_EINVAL;
+    }
+    int off = 0;
+    for (int c = 0; c < MAX_CATS; ++c) {
+        cs->codes[c] = c < n_cats ? reinterpret_cast<const int32_t *>(h_codes[c]) : nullptr;
+        cs->ncol[c] = c < n_cats ? (int)h_ncols[c] : 0;
+        cs->drop[c] = c < n_cats ? h_drop[c] : 0;
+        cs->off[c] = off;
+        off += cs->ncol[c];
+    }
+    cs->n_cats = n_cats;
+    cs->total = off;
+    return TM_OK;
+}
+
+template <typename F>
+static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncols,
+                               const int32_t *h_drop, int n_cats, int64_t n, const F *d, const F *M,
+                               int64_t m, int order_f, F *out, hipStream_t st) {
+    CatSet cs;
+    int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
+    if (rc) return rc;
+    const int64_t total = (int64_t)cs.total * m;
+    if (total == 0) return TM_OK;
+    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    if (n == 0) return TM_OK;
+    int TJ = 64;
+    while (TJ > 1 && sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) TJ >>= 1;
+    while (TJ > 1 && TJ / 2 >= m) TJ >>= 1;
+    if (sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) {
+        set_error("multi_cat_dense: %d stacked categories exceed the LDS tile", cs.total);
+        return TM_EUNSUPPORTED;
+    }
+    const int64_t n_parts = ceil_div(m, TJ);
+    const int64_t stride = (int64_t)cs.total * TJ;
+    const size_t lds = sizeof(F) * (size_t)stride;
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 4096)));
+    const int64_t rpb = ceil_div(n, nblk);
+    nblk = ceil_div(n, rpb);
+    const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_parts * stride) + 255) / 256) * 256;
+    void *wsv = nullptr;
+    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(1024), lds, st, cs, d,
+                           M, n, m, rpb, ws, stride);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    };
+#define TM_MCD_CASE(V)                                                                          \
+    case V:                                                                                     \
+        rc = order_f ? go(&multi_cat_dense_f_kernel<F, V>) : go(&multi_cat_dense_c_kernel<F, V>); \
+        break;
+    switch (TJ) {
+        TM_MCD_CASE(64)
+        TM_MCD_CASE(32)
+        TM_MCD_CASE(16)
+        TM_MCD_CASE(8)
+        TM_MCD_CASE(4)
+        TM_MCD_CASE(2)
+        TM_MCD_CASE(1)
+        default:
+            rc = TM_EINVAL;
+    }
+#undef TM_MCD_CASE
+    if (rc) return rc;
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, tmp, n_parts * stride, false,
+                                   st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((multi_cat_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)),
+                       dim3(256), 0, st, tmp, (int64_t)cs.total, m, TJ, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
+static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_ncols,
+                                const int32_t *h_drop, int n_cats, int64_t n, const F *d,
+                                const F *vals, const unsigned *koff, const unsigned char *ecol,
+                                const int64_t *gptr, int64_t m, int slab_rows, int group_cols,
+                                F *out, hipStream_t st) {
+    CatSet cs;
+    int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
+    if (rc) return rc;
+    const int64_t total = (int64_t)cs.total * m;
+    if (total == 0) return TM_OK;
+    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    if (n == 0) return TM_OK;
+    const int64_t stride = (int64_t)cs.total * group_cols;
+    const size_t lds = sizeof(F) * (size_t)stride;
+    if (lds > HIST_LDS_MAX) {
+        set_error("multi_cat_sparse: %d stacked categories exceed the LDS tile", cs.total);
+        return TM_EUNSUPPORTED;
+    }
+    const int n_groups = (int)ceil_div(m, group_cols);
+    const int64_t n_slabs = ceil_div(n, slab_rows);
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_groups);
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_groups * stride) + 255) / 256) * 256;
+    void *wsv = nullptr;
+    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_groups * nblk * stride) + 256,
+                       &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    auto kern = &multi_cat_sparse_kernel<F>;
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs, d,
+                       vals, koff, ecol, gptr, n_groups, n_slabs, spb, slab_rows, group_cols, ws,
+                       stride);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_groups, tmp,
+                                   (int64_t)n_groups * stride, false, st);
+    if (rc) return rc;
+    // tmp [group][total][group_cols] -> out[total][m]
+    hipLaunchKernelGGL((multi_cat_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)),
+                       dim3(256), 0, st, tmp, (int64_t)cs.total, m, group_cols, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -566,6 +840,39 @@ int tm_cat_sparse_sandwich_f64(const int32_t *codes, int64_t n, int64_t i_ncol, 
     TM_CHECK_COMMON(n);
     return run_cat_sparse<double>(codes, n, i_ncol, drop_first, csr_data, csr_indices, csr_indptr,
                                   s_ncol, d, rows, n_rows, cols, n_cols, out, as_stream(stream));
+}
+
+int tm_multi_cat_dense_sandwich_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                    const int32_t *h_drop_first, int n_cats, int64_t n,
+                                    const float *d, const float *M, int64_t M_ncol, int order_f,
+                                    float *out, void *stream) {
+    return run_multi_cat_dense<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol,
+                                      order_f, out, as_stream(stream));
+}
+int tm_multi_cat_dense_sandwich_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                    const int32_t *h_drop_first, int n_cats, int64_t n,
+                                    const double *d, const double *M, int64_t M_ncol, int order_f,
+                                    double *out, void *stream) {
+    return run_multi_cat_dense<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol,
+                                       order_f, out, as_stream(stream));
+}
+int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n,
+                                          const float *d, const float *vals, const uint32_t *koff,
+                                          const uint8_t *ecol, const int64_t *gptr, int64_t m,
+                                          float *out, void *stream) {
+    return run_multi_cat_sparse<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, koff,
+                                       ecol, gptr, m, tm_slab_rows(), tm_slab_group_cols(), out,
+                                       as_stream(stream));
+}
+int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n,
+                                          const double *d, const double *vals, const uint32_t *koff,
+                                          const uint8_t *ecol, const int64_t *gptr, int64_t m,
+                                          double *out, void *stream) {
+    return run_multi_cat_sparse<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, koff,
+                                        ecol, gptr, m, tm_slab_rows(), tm_slab_group_cols(), out,
+                                        as_stream(stream));
 }
 
 }  // extern "C"

@@ -672,33 +672,52 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         }
     };
 
+    // stream head of a (slab, group): run lengths, base, total and the first two 64-entry
+    // chunks.  The head of slab s + 1 is requested BEFORE slab s is processed, so neither its
+    // HBM latency nor the staging loads of the next dB slab sit in front of the hot loop in
+    // the in-order vmcnt queue.
+    int h_cnt = 0, h_total = 0;
+    int64_t h_base = 0;
+    F h_va = F(0), h_na = F(0);
+    unsigned h_vk = 0, h_nk = 0;
+    auto load_head = [&](int64_t s) {
+        h_cnt = 0; h_total = 0; h_base = 0;
+        h_va = F(0); h_na = F(0); h_vk = 0; h_nk = 0;
+        if (!active) return;
+        h_cnt = lane < GATHER_CPW ? (int)cnt[(s * n_groups + group) * GATHER_CPW + lane] : 0;
+        h_base = gptr[s * n_groups + group];
+        h_total = (int)(gptr[s * n_groups + group + 1] - h_base);
+        if (lane < h_total) {
+            h_va = vals[h_base + lane];
+            h_vk = koff[h_base + lane];
+        }
+        if (64 + lane < h_total) {
+            h_na = vals[h_base + 64 + lane];
+            h_nk = koff[h_base + 64 + lane];
+        }
+    };
+
     if (s0 < s1) {
+        load_head(s0);
         load_slab(s0);
         store_slab(0);
     }
     __syncthreads();
     for (int64_t s = s0; s < s1; ++s) {
         const int buf = (int)((s - s0) & 1);
-        if (s + 1 < s1) load_slab(s + 1);
-        if (active) {
-            const int cntv = lane < GATHER_CPW ? (int)cnt[(s * n_groups + group) * GATHER_CPW + lane] : 0;
-            const int64_t base = gptr[s * n_groups + group];
-            const int total = (int)(gptr[s * n_groups + group + 1] - base);
-            if (total > 0) {
-                F va = F(0), na = F(0);
-                unsigned vk = 0, nk = 0;
-                if (lane < total) {
-                    va = vals[base + lane];
-                    vk = koff[base + lane];
-                }
-                if (64 + lane < total) {
-                    na = vals[base + 64 + lane];
-                    nk = koff[base + 64 + lane];
-                }
-                int pos = 0;
-                ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, cntv, pos, va, vk, na, nk, vals,
-                                   koff, base, total, lane, lane_off);
-            }
+        // take over the prefetched head of this slab, then request the next one
+        const int cntv = h_cnt, total = h_total;
+        const int64_t base = h_base;
+        F va = h_va, na = h_na;
+        unsigned vk = h_vk, nk = h_nk;
+        if (s + 1 < s1) {
+            load_head(s + 1);
+            load_slab(s + 1);
+        }
+        if (active && total > 0) {
+            int pos = 0;
+            ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, cntv, pos, va, vk, na, nk, vals, koff,
+                               base, total, lane, lane_off);
         }
         if (s + 1 < s1) store_slab(buf ^ 1);
         __syncthreads();

@@ -87,6 +87,7 @@ class SlabCsc:
     koff: torch.Tensor     # int32[nnz]  byte offset of the entry's row inside the LDS slab part
     cnt: torch.Tensor      # int16[S * mpad] (read as uint16) run length per (slab, column)
     gptr: torch.Tensor     # int64[S * G + 1]
+    ecol: torch.Tensor     # uint8[nnz] column of the entry inside its column group
     n: int
     m: int
 
@@ -112,6 +113,7 @@ class SlabCsc:
         key_sorted, perm = torch.sort(key, stable=True)
         del key
         vals = csr.data[perm].contiguous()
+        ecol = torch.remainder(key_sorted, C).to(torch.uint8).contiguous()
         rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
         del rows, perm
         koff = (rloc * (64 * fbytes)).to(torch.int32).contiguous()
@@ -123,4 +125,4 @@ class SlabCsc:
         if S * G:
             torch.cumsum(cnt64.view(S * G, C).sum(dim=1), dim=0, out=gptr[1:])
         cnt = cnt64.to(torch.int16).contiguous()   # <= R = 128, bit pattern == uint16
-        return SlabCsc(vals, koff, cnt, gptr, n, m)
+        return SlabCsc(vals, koff, cnt, gptr, ecol, n, m)

@@ -1,11 +1,13 @@
 """Mirror of tabmat.ext.split (reference: src/tabmat/ext/split.pyx)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from .. import _device as D
 from .._lib import call
-from ._types import CsrDev, DenseDev
+from ._types import CsrDev, DenseDev, SlabCsc
 
 
 def sandwich_cat_dense(i_indices, i_ncol, d, mat_j: DenseDev, rows, j_cols, drop_first=False):
@@ -91,3 +93,41 @@ def is_sorted(a) -> bool:
     """ext/split.pyx:211-217."""
     a = np.asarray(a)
     return bool(np.all(a[1:] >= a[:-1]))
+
+
+MAX_FUSED_CATS = 16
+
+
+def _cat_args(cats):
+    """cats: list of (codes tensor, n_cols, drop_first) -> host arrays for the C ABI."""
+    n = len(cats)
+    codes = (C.c_void_p * n)(*[c[0].data_ptr() for c in cats])
+    ncols = (C.c_int64 * n)(*[int(c[1]) for c in cats])
+    drop = (C.c_int32 * n)(*[int(bool(c[2])) for c in cats])
+    return codes, ncols, drop, n
+
+
+def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev):
+    """All categorical x dense cross blocks in one pass over the dense block:
+    returns the stacked [sum(n_cols) x mat_j.m] result (ext/split.pyx:32-80, fused over cats)."""
+    total = sum(int(c[1]) for c in cats)
+    res = D.zeros((total, mat_j.m), mat_j.dtype)
+    if total == 0 or mat_j.m == 0 or mat_j.n == 0:
+        return res
+    codes, ncols, drop, n = _cat_args(cats)
+    call(f"tm_multi_cat_dense_sandwich_{D.fsuf(mat_j.buf)}", codes, ncols, drop, n, mat_j.n,
+         D.p(d), D.p(mat_j.buf), mat_j.m, mat_j.order_f, D.p(res), D.stream_ptr())
+    return res
+
+
+def multi_cat_sparse_sandwich(cats, d, S: SlabCsc):
+    """All categorical x sparse cross blocks in one pass over the slab-form sparse block:
+    stacked [sum(n_cols) x S.m] (the scipy product of categorical_matrix.py:825-838, fused)."""
+    total = sum(int(c[1]) for c in cats)
+    res = D.zeros((total, S.m), S.vals.dtype)
+    if total == 0 or S.m == 0 or S.n == 0:
+        return res
+    codes, ncols, drop, n = _cat_args(cats)
+    call(f"tm_multi_cat_sparse_sandwich_slab_{D.fsuf(S.vals)}", codes, ncols, drop, n, S.n, D.p(d),
+         D.p(S.vals), D.p(S.koff), D.p(S.ecol), D.p(S.gptr), S.m, D.p(res), D.stream_ptr())
+    return res

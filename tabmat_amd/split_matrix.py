@@ -226,8 +226,41 @@ class SplitMatrix(MatrixBase):
         pos_d = self._full_dev_indices() if cols_host is None else self._dev_idx(pos)
         sub_d = [None if sc is None else D.idx_dev(sc) for sc in sub_cols]
         out = D.zeros((n_cols, n_cols), torch.float64)
-        for i, mi in enumerate(self.matrices):
-            if sub_d[i] is not None and D.nlen(sub_d[i]) == 0:
+        mats = self.matrices
+        empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
+        done = set()
+        # ---- fused categorical cross terms: one pass over the dense / sparse block serves
+        #      every categorical block (tm_multi_cat_*), instead of one pass per pair
+        cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
+                   and m.shape[1] > 0]
+        budget = (128 * 1024) // np.dtype(self.dtype).itemsize
+        if len(cat_ids) >= 2 and len(cat_ids) <= xsplit.MAX_FUSED_CATS:
+            d_eff = d
+            if rows is not None:   # row restriction = masked d (excluded rows contribute 0)
+                d_eff = torch.zeros_like(d)
+                r64 = rows.to(torch.int64)
+                d_eff[r64] = d[r64]
+            cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in cat_ids]
+            total = sum(c[1] for c in cats)
+            offs = np.concatenate([[0], np.cumsum([c[1] for c in cats])])
+            for w, mw in enumerate(mats):
+                if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
+                    continue
+                stacked = None
+                if isinstance(mw, DenseMatrix) and total <= budget:
+                    stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev())
+                elif (isinstance(mw, SparseMatrix) and total * 32 <= budget
+                      and mw._dev().data.numel() > 0):
+                    stacked = xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
+                if stacked is None:
+                    continue
+                for ci, i in enumerate(cat_ids):
+                    res = stacked[int(offs[ci]):int(offs[ci + 1])]
+                    res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
+                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
+                    done.add((min(i, w), max(i, w)))
+        for i, mi in enumerate(mats):
+            if empty[i]:
                 continue
             if isinstance(mi, CategoricalMatrix):
                 diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
@@ -235,10 +268,10 @@ class SplitMatrix(MatrixBase):
             else:
                 res = mi._sandwich_dev(d, rows, sub_d[i])
                 xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
-            for j in range(i + 1, len(self.matrices)):
-                if sub_d[j] is not None and D.nlen(sub_d[j]) == 0:
+            for j in range(i + 1, len(mats)):
+                if empty[j] or (i, j) in done:
                     continue
-                res = mi._cross_sandwich_dev(self.matrices[j], d, rows, sub_d[i], sub_d[j])
+                res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
                 xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
         return out
 
