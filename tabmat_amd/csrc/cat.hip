@@ -491,7 +491,9 @@ struct CatSet {
 };
 
 // C-ordered dense: TJ lanes per row (64 / TJ rows per wave step), lane <-> dense column.
-template <typename F, int TJ>
+// NC = number of categoricals when <= 4 (codes of UNR rows x NC categoricals are loaded up
+// front so that ~UNR * (2 + NC) independent loads are in flight per lane), 0 = generic loop.
+template <typename F, int TJ, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
     int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
@@ -501,6 +503,8 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
     __syncthreads();
     constexpr int RPW = 64 / TJ;
+    constexpr int UNR = 4;
+    constexpr int NCC = NC > 0 ? NC : 1;
     const int lane = threadIdx.x & 63;
     const int sub = lane / TJ, jl = lane % TJ;
     const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -509,21 +513,36 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
     const int64_t step = (int64_t)nwave * RPW;
-    for (int64_t k = t0 + (int64_t)wave * RPW + sub; k < t1; k += 2 * step) {
-        // two independent rows per iteration: more loads in flight
-        const int64_t k2 = k + step;
-        const bool ok2 = k2 < t1;
-        F x1 = F(0), x2 = F(0);
-        if (jok) {
-            x1 = d[k] * M[k * m + j];
-            if (ok2) x2 = d[k2] * M[k2 * m + j];
+    for (int64_t k0 = t0 + (int64_t)wave * RPW + sub; k0 < t1; k0 += UNR * step) {
+        F x[UNR];
+        int cc[UNR][NCC];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t k = k0 + u * step;
+            const bool ok = k < t1;
+            x[u] = (ok && jok) ? d[k] * M[k * m + j] : F(0);
+            if (NC > 0) {
+#pragma unroll
+                for (int c = 0; c < NCC; ++c) cc[u][c] = ok ? cs.codes[c][k] - cs.drop[c] : -1;
+            }
         }
+        if (NC > 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int c = 0; c < NCC; ++c)
+                    if (jok && cc[u][c] >= 0)
+                        atomic_add(&tile[(cs.off[c] + cc[u][c]) * TJ + jl], x[u]);
+        } else {
 #pragma unroll 1
-        for (int c = 0; c < cs.n_cats; ++c) {
-            const int c1 = cs.codes[c][k] - cs.drop[c];
-            const int c2 = ok2 ? cs.codes[c][k2] - cs.drop[c] : -1;
-            if (jok && c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * TJ + jl], x1);
-            if (jok && c2 >= 0) atomic_add(&tile[(cs.off[c] + c2) * TJ + jl], x2);
+            for (int c = 0; c < cs.n_cats; ++c) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int64_t k = k0 + u * step;
+                    const int c1 = k < t1 ? cs.codes[c][k] - cs.drop[c] : -1;
+                    if (jok && c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * TJ + jl], x[u]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -586,20 +605,43 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
     for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
     __syncthreads();
     const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
     const unsigned rowb = 64u * (unsigned)sizeof(F);
-    for (int64_t s = s0; s < s1; ++s) {
-        const int64_t base = gptr[s * n_groups + g];
-        const int64_t end = gptr[s * n_groups + g + 1];
-        for (int64_t e = base + threadIdx.x; e < end; e += blockDim.x) {
-            const int64_t k = s * slab_rows + (int64_t)(koff[e] / rowb);
-            const F x = d[k] * vals[e];
-            const int ec = ecol[e];
+    // every wave walks its own slabs (s0 + wave, + nwave, ...): 16 independent streams per
+    // workgroup; the pointers of the next slab are requested before the current one is used
+    int64_t nb = 0, ne = 0;
+    if (s0 + wave < s1) {
+        nb = gptr[(s0 + wave) * n_groups + g];
+        ne = gptr[(s0 + wave) * n_groups + g + 1];
+    }
+    for (int64_t s = s0 + wave; s < s1; s += nwave) {
+        const int64_t base = nb, end = ne;
+        if (s + nwave < s1) {
+            nb = gptr[(s + nwave) * n_groups + g];
+            ne = gptr[(s + nwave) * n_groups + g + 1];
+        }
+        for (int64_t e0 = base + lane; e0 < end; e0 += 128) {
+            const int64_t e1 = e0 + 64;
+            const bool ok1 = e1 < end;
+            const unsigned ko0 = koff[e0];
+            const unsigned ko1 = ok1 ? koff[e1] : 0u;
+            const F v0 = vals[e0];
+            const F v1 = ok1 ? vals[e1] : F(0);
+            const int ec0 = ecol[e0];
+            const int ec1 = ok1 ? ecol[e1] : 0;
+            const int64_t k0 = s * slab_rows + (int64_t)(ko0 / rowb);
+            const int64_t k1 = s * slab_rows + (int64_t)(ko1 / rowb);
+            const F x0 = d[k0] * v0;
+            const F x1 = ok1 ? d[k1] * v1 : F(0);
 #pragma unroll 1
             for (int c = 0; c < cs.n_cats; ++c) {
-                const int cc = cs.codes[c][k] - cs.drop[c];
-                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * group_cols + ec], x);
+                const int c0 = cs.codes[c][k0] - cs.drop[c];
+                const int c1 = ok1 ? cs.codes[c][k1] - cs.drop[c] : -1;
+                if (c0 >= 0) atomic_add(&tile[(cs.off[c] + c0) * group_cols + ec0], x0);
+                if (c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * group_cols + ec1], x1);
             }
         }
     }
@@ -669,9 +711,14 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
         TM_LAUNCH_CHECK();
         return TM_OK;
     };
-#define TM_MCD_CASE(V)                                                                          \
-    case V:                                                                                     \
-        rc = order_f ? go(&multi_cat_dense_f_kernel<F, V>) : go(&multi_cat_dense_c_kernel<F, V>); \
+#define TM_MCD_CASE(V)                                                                       \
+    case V:                                                                                  \
+        if (order_f) rc = go(&multi_cat_dense_f_kernel<F, V>);                               \
+        else if (n_cats == 1) rc = go(&multi_cat_dense_c_kernel<F, V, 1>);                   \
+        else if (n_cats == 2) rc = go(&multi_cat_dense_c_kernel<F, V, 2>);                   \
+        else if (n_cats == 3) rc = go(&multi_cat_dense_c_kernel<F, V, 3>);                   \
+        else if (n_cats == 4) rc = go(&multi_cat_dense_c_kernel<F, V, 4>);                   \
+        else rc = go(&multi_cat_dense_c_kernel<F, V, 0>);                                    \
         break;
     switch (TJ) {
         TM_MCD_CASE(64)

@@ -143,16 +143,24 @@ __global__ __launch_bounds__(256) void csr_dense_kernel(
 // For I == J only pairs with colB <= colA are taken (lower triangle incl. diagonal), exactly
 // the `i > j: break` of ext/sparse.pyx:64-67; the mirror happens after the reduction.
 // ---------------------------------------------------------------------------------------
+constexpr int K2_WAVES = 16;
+
+template <typename F>
+struct __attribute__((aligned(16))) K2Entry {
+    F val;
+    int col;
+};
+
 template <typename F, int TS>
-__global__ __launch_bounds__(256) void sparse_sandwich_kernel(
+__global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
     const F *__restrict__ d, const int32_t *__restrict__ rows, int64_t n_iter,
     int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out,
     F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);                      // [TS][TS]
-    F *sval = tile + TS * TS;                                       // [4 waves][2][64]
-    int *scol = reinterpret_cast<int *>(sval + 4 * 2 * 64);         // [4 waves][2][64]
+    F *tile = reinterpret_cast<F *>(smem_raw);                                   // [TS][TS]
+    typedef K2Entry<F> Ent;
+    Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(F) * TS * TS);      // [waves][2][64]
     // part -> (I, J), J <= I:  part = I (I + 1) / 2 + J
     int I = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) - 1.0f) * 0.5f);
     while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.y) ++I;
@@ -164,66 +172,127 @@ __global__ __launch_bounds__(256) void sparse_sandwich_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    F *va = sval + (wave * 2 + 0) * 64, *vb = sval + (wave * 2 + 1) * 64;
-    int *ca = scol + (wave * 2 + 0) * 64, *cb = scol + (wave * 2 + 1) * 64;
+    Ent *sa = scratch + (wave * 2 + 0) * 64;
+    Ent *sb = scratch + (wave * 2 + 1) * 64;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int la = lane >> 3, lb = lane & 7;          // 8 x 8 pair block per wave step
     const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n_iter);
 
-    for (int64_t t = t0 + wave; t < t1; t += 4) {
-        const int64_t k = rows ? (int64_t)rows[t] : t;
-        const int64_t p0 = ptr[k], p1 = ptr[k + 1];
-        const F dk = d[k];
+    // Software pipeline over the rows of this wave (t, t + 16, ...): while row t is processed the
+    // first 64 entries of row t + 16 and the row pointers of row t + 32 are already in flight,
+    // so the three dependent memory round trips (row pointers -> entries -> LDS) overlap.
+    auto row_of = [&](int64_t t) -> int64_t { return rows ? (int64_t)rows[t] : t; };
+    int64_t p0_2 = 0, p1_2 = 0;   // stage 2: pointers of row t + 2*W
+    F d_2 = F(0);
+    int64_t p0_1 = 0, p1_1 = 0;   // stage 1: pointers + first chunk of row t + W
+    F d_1 = F(0), val_1 = F(0);
+    int col_1 = -1;
+    auto load_ptrs = [&](int64_t t) {
+        p0_2 = p1_2 = 0;
+        d_2 = F(0);
+        if (t < t1) {
+            const int64_t k = row_of(t);
+            p0_2 = ptr[k];
+            p1_2 = ptr[k + 1];
+            d_2 = d[k];
+        }
+    };
+    auto load_chunk = [&]() {   // stage 2 -> stage 1, issue the entry loads
+        p0_1 = p0_2; p1_1 = p1_2; d_1 = d_2;
+        col_1 = -1;
+        val_1 = F(0);
+        if (p0_1 + lane < p1_1) {
+            col_1 = ind[p0_1 + lane];
+            val_1 = data[p0_1 + lane];
+        }
+    };
+    const int64_t tw = t0 + wave;
+    load_ptrs(tw);
+    load_chunk();
+    load_ptrs(tw + K2_WAVES);
+
+    for (int64_t t = tw; t < t1; t += K2_WAVES) {
+        const int64_t p0 = p0_1, p1 = p1_1;
+        const F dk = d_1;
+        const int col_first = col_1;
+        const F val_first = val_1;
+        load_chunk();                       // row t + W: entries
+        load_ptrs(t + 2 * K2_WAVES);        // row t + 2W: pointers
+        if (p0 == p1) continue;
         for (int64_t qa = p0; qa < p1; qa += 64) {
-            // compact the A chunk
             int col = -1;
             F val = F(0);
-            if (qa + lane < p1) {
+            if (qa == p0) {
+                col = col_first;
+                val = val_first;
+                if (col >= 0 && col_map) col = col_map[col];
+            } else if (qa + lane < p1) {
                 const int j = ind[qa + lane];
                 col = col_map ? col_map[j] : j;
                 val = data[qa + lane];
             }
             const bool inA = col >= i0 && col < i0 + TS;
             const unsigned long long mA = __ballot(inA);
+            if (mA == 0) continue;
             const int na = __popcll(mA);
-            if (na == 0) continue;
             if (inA) {
-                const int pos = __popcll(mA & lt_mask);
-                ca[pos] = col - i0;
-                va[pos] = val * dk;
+                Ent e;
+                e.val = val * dk;
+                e.col = col - i0;
+                sa[__popcll(mA & lt_mask)] = e;
             }
             for (int64_t qb = p0; qb < p1; qb += 64) {
-                int colb = -1;
-                F valb = F(0);
-                if (qb + lane < p1) {
-                    const int j = ind[qb + lane];
-                    colb = col_map ? col_map[j] : j;
-                    valb = data[qb + lane];
+                int colb = col;
+                F valb = val;
+                if (qb != qa) {
+                    colb = -1;
+                    valb = F(0);
+                    if (qb + lane < p1) {
+                        const int j = ind[qb + lane];
+                        colb = col_map ? col_map[j] : j;
+                        valb = data[qb + lane];
+                    }
                 }
                 const bool inB = colb >= j0 && colb < j0 + TS;
                 const unsigned long long mB = __ballot(inB);
+                if (mB == 0) continue;
                 const int nb = __popcll(mB);
-                if (nb == 0) continue;
                 if (inB) {
-                    const int pos = __popcll(mB & lt_mask);
-                    cb[pos] = colb - j0;
-                    vb[pos] = valb;
+                    Ent e;
+                    e.val = valb;
+                    e.col = colb - j0;
+                    sb[__popcll(mB & lt_mask)] = e;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const int npair = na * nb;
-                for (int e = lane; e < npair; e += 64) {
-                    const int a = e / nb;
-                    const int b = e - a * nb;
-                    const int ra = ca[a], rb = cb[b];
-                    if (I != J || rb <= ra) atomic_add(&tile[ra * TS + rb], va[a] * vb[b]);
+                for (int a0 = 0; a0 < na; a0 += 8) {
+                    const int a = a0 + la;
+                    Ent ea;
+                    ea.val = F(0);
+                    ea.col = 0;
+                    if (a < na) ea = sa[a];
+                    for (int b0 = 0; b0 < nb; b0 += 8) {
+                        const int b = b0 + lb;
+                        if (a < na && b < nb) {
+                            const Ent eb = sb[b];
+                            if (I != J || eb.col <= ea.col)
+                                atomic_add(&tile[ea.col * TS + (eb.col ^ ((ea.col & 15) << 3))],
+                                           ea.val * eb.val);
+                        }
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
     }
     __syncthreads();
+    // un-swizzle on the way out (tile column = col ^ ((row & 15) << 3): the 8 lanes that share
+    // a B entry hit 8 different LDS banks instead of one)
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
-    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
+        const int r = b / TS, c = b % TS;
+        dst[b] = tile[r * TS + (c ^ ((r & 15) << 3))];
+    }
 }
 
 // out[i][j] (n_out x n_out) from the reduced tile buffer [part][TS*TS]; mirror included.
@@ -418,11 +487,11 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(n_out * n_out), st));
         return TM_OK;
     }
-    constexpr int TS = (sizeof(F) == 8) ? 120 : 176;   // TS*TS*sizeof(F) + scratch <= 128 KB
+    constexpr int TS = 128;   // 128 KB (f64) / 64 KB (f32) tile + 32 KB pair scratch
     const int nchunk = (int)ceil_div(n_out, TS);
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
-    const size_t lds = sizeof(F) * (size_t)(TS * TS + 4 * 2 * 64) + sizeof(int) * 4 * 2 * 64;
+    const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
     int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
     nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, 256)));
     const int64_t rpb = ceil_div(n_iter, nblk);
@@ -448,8 +517,8 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data, ind,
-                       ptr, d, rows, n_iter, rpb, col_map, (int)n_out, ws);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(K2_WAVES * 64), lds, st,
+                       data, ind, ptr, d, rows, n_iter, rpb, col_map, (int)n_out, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,

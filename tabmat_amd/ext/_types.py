@@ -126,3 +126,28 @@ class SlabCsc:
             torch.cumsum(cnt64.view(S * G, C).sum(dim=1), dim=0, out=gptr[1:])
         cnt = cnt64.to(torch.int16).contiguous()   # <= R = 128, bit pattern == uint16
         return SlabCsc(vals, koff, cnt, gptr, ecol, n, m)
+
+
+def onehot_slab(cats, n: int, dtype: torch.dtype) -> "SlabCsc":
+    """Slab form of the STACKED one-hot encodings of several categorical blocks: a sparse
+    matrix with (at most) one unit entry per row and categorical, columns = the categoricals'
+    columns side by side.  Lets categorical x dense cross terms run on the atomic-free gather
+    kernel (csr_dense_gather_kernel) instead of LDS atomics.
+    cats: list of (codes int32 device tensor, n_cols, drop_first)."""
+    dev = cats[0][0].device
+    cols, valid = [], []
+    off = 0
+    for codes, ncol, drop in cats:
+        c = codes.to(torch.int64) - int(bool(drop))
+        ok = (c >= 0) & (c < ncol)
+        cols.append(torch.where(ok, c + off, torch.zeros_like(c)))
+        valid.append(ok)
+        off += int(ncol)
+    colm = torch.stack(cols, dim=1)            # [n, n_cats], increasing along dim 1
+    okm = torch.stack(valid, dim=1)
+    counts = okm.sum(dim=1)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, dim=0, out=indptr[1:])
+    indices = colm[okm].to(torch.int32).contiguous()   # row-major => (row, col)-sorted
+    data = torch.ones(indices.numel(), dtype=dtype, device=dev)
+    return SlabCsc.from_csr(CsrDev(data, indices, indptr, n, off))

@@ -144,6 +144,17 @@ class SplitMatrix(MatrixBase):
             return self.indices, [None] * len(self.indices), self.shape[1]
         return xsplit.split_col_subsets(self, set_up_rows_or_cols(cols, self.shape[1]))
 
+    def _onehot_slab(self, cat_ids):
+        key = tuple(cat_ids)
+        cache = getattr(self, "_onehot_cache", None)
+        if cache is None or cache[0] != key:
+            from .ext._types import onehot_slab
+
+            mats = self.matrices
+            cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in cat_ids]
+            self._onehot_cache = (key, onehot_slab(cats, self.shape[0], D.torch_dtype(self.dtype)))
+        return self._onehot_cache[1]
+
     def _dev_idx(self, arrs):
         return [D.idx_dev(a, torch.int64) for a in arrs]
 
@@ -156,6 +167,10 @@ class SplitMatrix(MatrixBase):
         for m in self.matrices:
             m.to_device()
         self._full_dev_indices()
+        cat_ids = [i for i, m in enumerate(self.matrices)
+                   if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
+        if len(cat_ids) >= 2 and any(isinstance(m, DenseMatrix) for m in self.matrices):
+            self._onehot_slab(cat_ids)
         return self
 
     def astype(self, dtype, order="K", casting="unsafe", copy=True):
@@ -247,7 +262,14 @@ class SplitMatrix(MatrixBase):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
                 stacked = None
-                if isinstance(mw, DenseMatrix) and total <= budget:
+                if isinstance(mw, DenseMatrix) and mw._dev().order_f == 0:
+                    # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
+                    # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
+                    from .ext import sparse as xs
+
+                    stacked = xs.csr_dense_sandwich_slab(self._onehot_slab(cat_ids), mw._dev(),
+                                                         d_eff)
+                elif isinstance(mw, DenseMatrix) and total <= budget:
                     stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev())
                 elif (isinstance(mw, SparseMatrix) and total * 32 <= budget
                       and mw._dev().data.numel() > 0):
