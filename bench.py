@@ -93,7 +93,7 @@ def kernel_breakdown(mat, d, reps=3):
                     from tabmat_amd.ext import sparse as xs
 
                     cat_ids = [k for k, m in enumerate(mats) if isinstance(m, tm.CategoricalMatrix)]
-                    oh = mat._onehot_slab(cat_ids)
+                    oh, _ = mat._onehot_slab(cat_ids)
                     fused.append((f"allcats_x_dense{i}", lambda mw=mw, oh=oh: xs.csr_dense_sandwich_slab(
                         oh, mw._dev(), d)))
                 elif isinstance(mw, tm.SparseMatrix):

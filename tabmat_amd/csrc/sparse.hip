@@ -6,6 +6,8 @@
 //   K2  sparse self sandwich   (reference: ext/sparse.pyx:17-77)
 //   K3  sparse x dense cross   (reference: ext/sparse_helpers-tmpl.cpp:23-146)
 //   K6  CSR matvec / transpose-matvec (reference: ext/sparse.pyx:79-199)
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff,
     const unsigned short *__restrict__ cnt, const int64_t *__restrict__ gptr, int n_groups,
     int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
-    int nB, const F *__restrict__ d, F *__restrict__ ws) {
+    int nB, const F *__restrict__ d, F *__restrict__ ws, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int VEC = 16 / (int)sizeof(F);
     constexpr int ROWB = 64 * (int)sizeof(F);            // bytes per LDS slab row
@@ -741,21 +743,28 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         }
     };
 
-    // stream head of a (slab, group): run lengths, base, total and the first two 64-entry
-    // chunks.  The head of slab s + 1 is requested BEFORE slab s is processed, so neither its
-    // HBM latency nor the staging loads of the next dB slab sit in front of the hot loop in
-    // the in-order vmcnt queue.
-    int h_cnt = 0, h_total = 0;
+    // Two-deep software pipeline over the slabs so that no load of an iteration depends on
+    // another load issued in the same iteration (each would cost a full HBM round trip):
+    //   iteration s issues   meta(s + 2)  = run lengths + stream base/total      (stage M)
+    //                        head(s + 1)  = first two 64-entry chunks, from meta(s + 1) (stage H)
+    //                        slab(s + 1)  = dB rows into registers                (stage S)
+    //   then computes slab s out of LDS, writes slab(s + 1) to the other LDS buffer, barrier.
+    int m_cnt = 0, m_total = 0;          // meta of slab s + 2 (after stage M)
+    int64_t m_base = 0;
+    int h_cnt = 0, h_total = 0;          // head of slab s + 1 (after stage H)
     int64_t h_base = 0;
     F h_va = F(0), h_na = F(0);
     unsigned h_vk = 0, h_nk = 0;
-    auto load_head = [&](int64_t s) {
-        h_cnt = 0; h_total = 0; h_base = 0;
+    auto load_meta = [&](int64_t s) {
+        m_cnt = 0; m_total = 0; m_base = 0;
+        if (!active || s >= s1) return;
+        m_cnt = lane < GATHER_CPW ? (int)cnt[(s * n_groups + group) * GATHER_CPW + lane] : 0;
+        m_base = gptr[s * n_groups + group];
+        m_total = (int)(gptr[s * n_groups + group + 1] - m_base);
+    };
+    auto load_head = [&]() {             // consumes meta, issues the chunk loads
+        h_cnt = m_cnt; h_total = m_total; h_base = m_base;
         h_va = F(0); h_na = F(0); h_vk = 0; h_nk = 0;
-        if (!active) return;
-        h_cnt = lane < GATHER_CPW ? (int)cnt[(s * n_groups + group) * GATHER_CPW + lane] : 0;
-        h_base = gptr[s * n_groups + group];
-        h_total = (int)(gptr[s * n_groups + group + 1] - h_base);
         if (lane < h_total) {
             h_va = vals[h_base + lane];
             h_vk = koff[h_base + lane];
@@ -767,28 +776,31 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     };
 
     if (s0 < s1) {
-        load_head(s0);
+        load_meta(s0);
+        load_head();                      // head(s0)
+        load_meta(s0 + 1);                // meta(s0 + 1)
         load_slab(s0);
         store_slab(0);
     }
     __syncthreads();
     for (int64_t s = s0; s < s1; ++s) {
         const int buf = (int)((s - s0) & 1);
-        // take over the prefetched head of this slab, then request the next one
+        // take over the prefetched head of this slab
         const int cntv = h_cnt, total = h_total;
         const int64_t base = h_base;
         F va = h_va, na = h_na;
         unsigned vk = h_vk, nk = h_nk;
         if (s + 1 < s1) {
-            load_head(s + 1);
-            load_slab(s + 1);
+            load_head();                  // head(s + 1) from meta(s + 1), loaded last iteration
+            if (!(dbg & 2)) load_slab(s + 1);
         }
-        if (active && total > 0) {
+        load_meta(s + 2);
+        if (active && total > 0 && !(dbg & 1)) {
             int pos = 0;
             ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, cntv, pos, va, vk, na, nk, vals, koff,
                                base, total, lane, lane_off);
         }
-        if (s + 1 < s1) store_slab(buf ^ 1);
+        if (s + 1 < s1 && !(dbg & 4)) store_slab(buf ^ 1);
         __syncthreads();
     }
     if (active) {
@@ -844,7 +856,8 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS), lds,
-                       st, vals, koff, cnt, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
+                       st, vals, koff, cnt, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws,
+                       getenv("TM_GATHER_DBG") ? atoi(getenv("TM_GATHER_DBG")) : 0);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false,

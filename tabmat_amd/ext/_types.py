@@ -128,26 +128,43 @@ class SlabCsc:
         return SlabCsc(vals, koff, cnt, gptr, ecol, n, m)
 
 
-def onehot_slab(cats, n: int, dtype: torch.dtype) -> "SlabCsc":
+def onehot_slab(cats, n: int, dtype: torch.dtype):
     """Slab form of the STACKED one-hot encodings of several categorical blocks: a sparse
     matrix with (at most) one unit entry per row and categorical, columns = the categoricals'
     columns side by side.  Lets categorical x dense cross terms run on the atomic-free gather
     kernel (csr_dense_gather_kernel) instead of LDS atomics.
+
+    The stacked columns are PERMUTED round-robin over the kernel's column groups (32 columns per
+    wave): a categorical with few levels would otherwise put all of its n nonzeros into a single
+    wave.  Returns (SlabCsc over the permuted columns, inv) where row `c` of the stacked result
+    is row inv[c] of the kernel output.
     cats: list of (codes int32 device tensor, n_cols, drop_first)."""
+    from .._lib import lib
+
+    C = int(lib().tm_slab_group_cols())
     dev = cats[0][0].device
+    total = sum(int(c[1]) for c in cats)
+    G = max(1, (total + C - 1) // C)
+    # stacked column c -> permuted position: deal columns to groups like cards
+    c_all = torch.arange(total, device=dev, dtype=torch.int64)
+    perm_pos = (c_all % G) * C + torch.div(c_all, G, rounding_mode="floor")   # < G * C
     cols, valid = [], []
     off = 0
     for codes, ncol, drop in cats:
         c = codes.to(torch.int64) - int(bool(drop))
         ok = (c >= 0) & (c < ncol)
-        cols.append(torch.where(ok, c + off, torch.zeros_like(c)))
+        cols.append(perm_pos[torch.where(ok, c + off, torch.zeros_like(c))])
         valid.append(ok)
         off += int(ncol)
-    colm = torch.stack(cols, dim=1)            # [n, n_cats], increasing along dim 1
+    colm = torch.stack(cols, dim=1)
     okm = torch.stack(valid, dim=1)
+    big = G * C
+    colm = torch.where(okm, colm, torch.full_like(colm, big))
+    colm, _ = torch.sort(colm, dim=1)          # CSR rows need ascending column indices
+    okm = colm < big
     counts = okm.sum(dim=1)
     indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, dim=0, out=indptr[1:])
-    indices = colm[okm].to(torch.int32).contiguous()   # row-major => (row, col)-sorted
+    indices = colm[okm].to(torch.int32).contiguous()
     data = torch.ones(indices.numel(), dtype=dtype, device=dev)
-    return SlabCsc.from_csr(CsrDev(data, indices, indptr, n, off))
+    return SlabCsc.from_csr(CsrDev(data, indices, indptr, n, big)), perm_pos

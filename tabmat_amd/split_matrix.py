@@ -267,8 +267,8 @@ class SplitMatrix(MatrixBase):
                     # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
                     from .ext import sparse as xs
 
-                    stacked = xs.csr_dense_sandwich_slab(self._onehot_slab(cat_ids), mw._dev(),
-                                                         d_eff)
+                    oh, inv = self._onehot_slab(cat_ids)
+                    stacked = xs.csr_dense_sandwich_slab(oh, mw._dev(), d_eff)[inv]
                 elif isinstance(mw, DenseMatrix) and total <= budget:
                     stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev())
                 elif (isinstance(mw, SparseMatrix) and total * 32 <= budget
