@@ -145,6 +145,22 @@ __global__ __launch_bounds__(256) void csr_dense_kernel(
 // For I == J only pairs with colB <= colA are taken (lower triangle incl. diagonal), exactly
 // the `i > j: break` of ext/sparse.pyx:64-67; the mirror happens after the reduction.
 // ---------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ F readlane_f(F v, int l);
+
+template <>
+__device__ __forceinline__ double readlane_f<double>(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <>
+__device__ __forceinline__ float readlane_f<float>(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 constexpr int K2_WAVES = 16;
 
 template <typename F>
@@ -290,6 +306,139 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
     __syncthreads();
     // un-swizzle on the way out (tile column = col ^ ((row & 15) << 3): the 8 lanes that share
     // a B entry hit 8 different LDS banks instead of one)
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
+        const int r = b / TS, c = b % TS;
+        dst[b] = tile[r * TS + (c ^ ((r & 15) << 3))];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 (v3)  unrestricted sparse self sandwich on precomputed per-row CHUNK POINTERS:
+// cptr[k][c] = index of the first entry of row k whose column is >= 128 c (c = 0..NCH), so the
+// entries of row k that fall into tile chunk I are data[cptr[k][I] .. cptr[k][I+1]) -- no
+// ballots, no compaction, no scratch.  One wave per (row, tile) unit; lane (a, b) = (lane>>3,
+// lane&7) loads entry a of the I-list and entry b of the J-list straight from the CSR arrays
+// (L1 hits: a row is ~300 contiguous bytes) and issues one ds_add_f64 into the LDS tile.
+// ---------------------------------------------------------------------------------------
+template <typename F, int TS>
+__global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind,
+    const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
+    int64_t rows_per_block, F *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
+    typedef K2Entry<F> Ent;
+    Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(F) * TS * TS);   // [waves][2][64]
+    int I = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) - 1.0f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.y) ++I;
+    while (I * (I + 1) / 2 > (int)blockIdx.y) --I;
+    const int J = (int)blockIdx.y - I * (I + 1) / 2;
+    const int i0 = I * TS, j0 = J * TS;
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = F(0);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane >> 3, lt = lane & 7;       // load phase: row-in-group, entry slot
+    Ent *sa = scratch + (wave * 2 + 0) * 64;
+    Ent *sb = scratch + (wave * 2 + 1) * 64;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    const int stride = nch + 1;
+
+    // A wave owns GROUPS of 8 consecutive rows (8 lanes per row).  Two-stage pipeline: while
+    // group g is processed, the entries of group g + W and the chunk pointers of group g + 2W
+    // are in flight -> one memory round trip per 8 rows instead of one per row.
+    int q_pA = 0, q_nA = 0, q_pB = 0, q_nB = 0;      // stage 2
+    F q_d = F(0);
+    int p_pA = 0, p_nA = 0, p_pB = 0, p_nB = 0;      // stage 1
+    F p_d = F(0), p_va = F(0), p_vb = F(0);
+    int p_ca = 0, p_cb = 0;
+    auto load_ptrs = [&](int64_t g0) {
+        q_pA = q_nA = q_pB = q_nB = 0;
+        q_d = F(0);
+        const int64_t k = g0 + lr;
+        if (g0 < t1 && k < t1) {
+            const int32_t *cp = cptr + k * stride;
+            q_d = d[k];
+            q_pA = cp[I];
+            q_pB = cp[J];
+            if (q_d != F(0)) {
+                q_nA = cp[I + 1] - q_pA;
+                q_nB = cp[J + 1] - q_pB;
+            }
+        }
+    };
+    auto load_entries = [&]() {
+        p_pA = q_pA; p_nA = q_nA; p_pB = q_pB; p_nB = q_nB; p_d = q_d;
+        p_ca = p_cb = 0;
+        p_va = p_vb = F(0);
+        if (lt < p_nA) {
+            p_ca = ind[p_pA + lt];
+            p_va = data[p_pA + lt];
+        }
+        if (lt < p_nB) {
+            p_cb = ind[p_pB + lt];
+            p_vb = data[p_pB + lt];
+        }
+    };
+    const int64_t gstep = (int64_t)K2_WAVES * 8;
+    const int64_t gw = t0 + (int64_t)wave * 8;
+    load_ptrs(gw);
+    load_entries();
+    load_ptrs(gw + gstep);
+    const int pa = lane >> 3, pb = lane & 7;       // pair phase: (a, b) of the 8 x 8 block
+    for (int64_t g0 = gw; g0 < t1; g0 += gstep) {
+        const int nA = p_nA, nB = p_nB, pA0 = p_pA, pB0 = p_pB;
+        const F dk = p_d;
+        Ent ea, eb;
+        ea.val = p_va * dk;
+        ea.col = p_ca - i0;
+        eb.val = p_vb;
+        eb.col = p_cb - j0;
+        load_entries();                    // group g + W
+        load_ptrs(g0 + 2 * gstep);         // group g + 2W
+        sa[lane] = ea;
+        sb[lane] = eb;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
+            const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
+            if (nAr == 0 || nBr == 0) continue;
+            const Ent xa = sa[r * 8 + pa];
+            const Ent xb = sb[r * 8 + pb];
+            if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))], xa.val * xb.val);
+            if (nAr > 8 || nBr > 8) {
+                // long lists: remaining 8 x 8 blocks straight from the CSR arrays
+                const int pAr = __builtin_amdgcn_readlane(pA0, r * 8);
+                const int pBr = __builtin_amdgcn_readlane(pB0, r * 8);
+                const F dr = readlane_f<F>(dk, r * 8);
+                for (int a0 = 0; a0 < nAr; a0 += 8) {
+                    const int a = a0 + pa;
+                    int ca = 0;
+                    F va = F(0);
+                    if (a < nAr) {
+                        ca = ind[pAr + a] - i0;
+                        va = data[pAr + a] * dr;
+                    }
+                    for (int b0 = (a0 == 0 ? 8 : 0); b0 < nBr; b0 += 8) {
+                        const int b = b0 + pb;
+                        if (a < nAr && b < nBr) {
+                            const int cb = ind[pBr + b] - j0;
+                            const F vb = data[pBr + b];
+                            if (I != J || cb <= ca)
+                                atomic_add(&tile[ca * TS + (cb ^ ((ca & 15) << 3))], va * vb);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
         const int r = b / TS, c = b % TS;
@@ -533,6 +682,48 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
     return TM_OK;
 }
 
+template <typename F>
+static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const int32_t *cptr,
+                                       int64_t n, int64_t m, const F *d, F *out, hipStream_t st) {
+    if (m == 0) return TM_OK;
+    if (n == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(m * m), st));
+        return TM_OK;
+    }
+    constexpr int TS = 128;
+    const int nchunk = (int)ceil_div(m, TS);
+    const int n_parts = nchunk * (nchunk + 1) / 2;
+    TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
+    const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 1024)));
+    const int64_t rpb = ceil_div(n, nblk);
+    nblk = ceil_div(n, rpb);
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)n_parts * TS * TS);
+    void *wsv = nullptr;
+    int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS + 256,
+                           &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    auto kern = &sparse_sandwich_chunked_kernel<F, TS>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(K2_WAVES * 64), lds, st,
+                       data, ind, cptr, nchunk, d, n, rpb, ws);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,
+                                   (int64_t)n_parts * TS * TS, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sparse_sandwich_assemble_kernel<F, TS>),
+                       dim3((unsigned)ceil_div(m, 64), (unsigned)m), dim3(64), 0, st, tmp, (int)m,
+                       nchunk, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -599,22 +790,6 @@ namespace tmh {
 // inner loop; partial results are reduced by reduce_partials_kernel.
 // =======================================================================================
 constexpr int SLAB_R = 128;
-
-template <typename F>
-__device__ __forceinline__ F readlane_f(F v, int l);
-
-template <>
-__device__ __forceinline__ double readlane_f<double>(double v, int l) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-template <>
-__device__ __forceinline__ float readlane_f<float>(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
 
 constexpr int GATHER_CPW = 32;                      // sparse columns (static accumulators) per wave
 constexpr int GATHER_NW = 16;                       // waves per workgroup -> 512 sparse columns
@@ -872,6 +1047,20 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
 }  // namespace tmh
 
 extern "C" {
+
+int tm_sparse_chunk_cols(void) { return 128; }
+int tm_sparse_sandwich_chunked_f32(const float *csr_data, const int32_t *csr_indices,
+                                   const int32_t *cptr, int64_t n, int64_t m, const float *d,
+                                   float *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<float>(csr_data, csr_indices, cptr, n, m, d, out,
+                                                   tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_indices,
+                                   const int32_t *cptr, int64_t n, int64_t m, const double *d,
+                                   double *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<double>(csr_data, csr_indices, cptr, n, m, d, out,
+                                                    tmh::as_stream(stream));
+}
 
 int tm_slab_rows(void) { return tmh::SLAB_R; }
 int tm_slab_group_cols(void) { return tmh::GATHER_CPW; }

@@ -62,6 +62,30 @@ class CsrDev:
     def dtype(self):
         return self.data.dtype
 
+    def chunk_ptr(self) -> torch.Tensor:
+        """int32 [n, NCH + 1]: first entry of each row at or after column c * chunk (see
+        tm_sparse_sandwich_chunked_*).  Built once per block (ingest), cached."""
+        cp = getattr(self, "_cptr", None)
+        if cp is None:
+            from .._lib import lib
+
+            ch = int(lib().tm_sparse_chunk_cols())
+            nch = (self.m + ch - 1) // ch
+            if self.data.numel() >= 2**31:
+                raise ValueError("chunk pointers need nnz < 2^31")
+            counts = self.indptr[1:] - self.indptr[:-1]
+            rows = torch.repeat_interleave(
+                torch.arange(self.n, device=self.data.device, dtype=torch.int64), counts)
+            key = rows * nch + torch.div(self.indices.to(torch.int64), ch, rounding_mode="floor")
+            per = torch.bincount(key, minlength=self.n * nch).view(self.n, nch)
+            cp = torch.empty((self.n, nch + 1), dtype=torch.int64, device=self.data.device)
+            cp[:, 0] = self.indptr[:-1]
+            torch.cumsum(per, dim=1, out=cp[:, 1:])
+            cp[:, 1:] += self.indptr[:-1, None]
+            cp = cp.to(torch.int32).contiguous()
+            self._cptr = cp
+        return cp
+
     @staticmethod
     def from_scipy(csr) -> "CsrDev":
         n, m = csr.shape

@@ -71,3 +71,14 @@ def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
     call(f"tm_csr_dense_sandwich_slab_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.cnt),
          D.p(A.gptr), A.n, A.m, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
     return out
+
+
+def sparse_sandwich_chunked(A: CsrDev, d):
+    """Unrestricted fast path of ext/sparse.pyx:17-77 on per-row chunk pointers (K2 v3)."""
+    out = D.zeros((A.m, A.m), A.dtype)
+    if A.m == 0 or A.n == 0:
+        return out
+    cp = A.chunk_ptr()
+    call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(cp),
+         A.n, A.m, D.p(d), D.p(out), D.stream_ptr())
+    return out

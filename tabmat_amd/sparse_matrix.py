@@ -103,7 +103,7 @@ class SparseMatrix(MatrixBase):
         return self._slabblk
 
     def to_device(self):
-        self._dev()
+        self._dev().chunk_ptr()
         self._slab()
         return self
 
@@ -173,7 +173,21 @@ class SparseMatrix(MatrixBase):
 
     # ---- hot path -----------------------------------------------------------------------
     def _sandwich_dev(self, d, rows, cols):
-        return xs.sparse_sandwich(self._dev(), d, rows, cols)
+        A = self._dev()
+        if A.data.numel() > 0 and A.data.numel() < 2**31 and self.shape[1] <= 128 * 32:
+            # fast path: unrestricted chunk-pointer kernel; row restriction = masked d,
+            # column restriction = sub-selection of the small result
+            if rows is not None:
+                dm = torch.zeros_like(d)
+                r64 = rows.to(torch.int64)
+                dm[r64] = d[r64]
+                d = dm
+            res = xs.sparse_sandwich_chunked(A, d)
+            if cols is not None:
+                c64 = cols.to(torch.int64)
+                res = res[c64][:, c64].contiguous()
+            return res
+        return xs.sparse_sandwich(A, d, rows, cols)
 
     def sandwich(self, d, rows=None, cols=None):
         """sparse_matrix.py:175-185."""
