@@ -353,8 +353,8 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     int q_pA = 0, q_nA = 0, q_pB = 0, q_nB = 0;      // stage 2
     F q_d = F(0);
     int p_pA = 0, p_nA = 0, p_pB = 0, p_nB = 0;      // stage 1
-    F p_d = F(0), p_va = F(0), p_vb = F(0);
-    int p_ca = 0, p_cb = 0;
+    F p_d = F(0), p_va = F(0), p_vb = F(0), p_va2 = F(0), p_vb2 = F(0);
+    int p_ca = 0, p_cb = 0, p_ca2 = 0, p_cb2 = 0;
     auto load_ptrs = [&](int64_t g0) {
         q_pA = q_nA = q_pB = q_nB = 0;
         q_d = F(0);
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             }
         }
     };
-    auto load_entries = [&]() {
+    auto load_entries = [&]() {   // slots lt and lt + 8 of both lists: 16 entries per list
         p_pA = q_pA; p_nA = q_nA; p_pB = q_pB; p_nB = q_nB; p_d = q_d;
-        p_ca = p_cb = 0;
-        p_va = p_vb = F(0);
+        p_ca = p_cb = p_ca2 = p_cb2 = 0;
+        p_va = p_vb = p_va2 = p_vb2 = F(0);
         if (lt < p_nA) {
             p_ca = ind[p_pA + lt];
             p_va = data[p_pA + lt];
@@ -382,37 +382,65 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             p_cb = ind[p_pB + lt];
             p_vb = data[p_pB + lt];
         }
+        if (lt + 8 < p_nA) {
+            p_ca2 = ind[p_pA + lt + 8];
+            p_va2 = data[p_pA + lt + 8];
+        }
+        if (lt + 8 < p_nB) {
+            p_cb2 = ind[p_pB + lt + 8];
+            p_vb2 = data[p_pB + lt + 8];
+        }
     };
     const int64_t gstep = (int64_t)K2_WAVES * 8;
     const int64_t gw = t0 + (int64_t)wave * 8;
     load_ptrs(gw);
     load_entries();
     load_ptrs(gw + gstep);
-    const int pa = lane >> 3, pb = lane & 7;       // pair phase: (a, b) of the 8 x 8 block
+    const int pa = lane >> 3, pb = lane & 7;       // pair phase: (a, b) of an 8 x 8 block
     for (int64_t g0 = gw; g0 < t1; g0 += gstep) {
         const int nA = p_nA, nB = p_nB, pA0 = p_pA, pB0 = p_pB;
         const F dk = p_d;
-        Ent ea, eb;
-        ea.val = p_va * dk;
-        ea.col = p_ca - i0;
-        eb.val = p_vb;
-        eb.col = p_cb - j0;
+        Ent ea, eb, ea2, eb2;
+        ea.val = p_va * dk;   ea.col = p_ca - i0;
+        eb.val = p_vb;        eb.col = p_cb - j0;
+        ea2.val = p_va2 * dk; ea2.col = p_ca2 - i0;
+        eb2.val = p_vb2;      eb2.col = p_cb2 - j0;
         load_entries();                    // group g + W
         load_ptrs(g0 + 2 * gstep);         // group g + 2W
-        sa[lane] = ea;
-        sb[lane] = eb;
-        __builtin_amdgcn_wave_barrier();
+        const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
+        // four phases over the (A half, B half) blocks; the per-wave scratch holds one half of
+        // each list at a time.  ha/hb = which half (0: entries 0..7, 1: entries 8..15).
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
-            const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
-            if (nAr == 0 || nBr == 0) continue;
-            const Ent xa = sa[r * 8 + pa];
-            const Ent xb = sb[r * 8 + pb];
-            if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
-                atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))], xa.val * xb.val);
-            if (nAr > 8 || nBr > 8) {
-                // long lists: remaining 8 x 8 blocks straight from the CSR arrays
+        for (int phase = 0; phase < 4; ++phase) {
+            const int ha = (phase == 1 || phase == 2) ? 1 : 0;
+            const int hb = (phase >= 2) ? 1 : 0;
+            if (ha && !anyA2) continue;
+            if (hb && !anyB2) continue;
+            if (phase == 0) { sa[lane] = ea; sb[lane] = eb; }
+            else if (phase == 1) { sa[lane] = ea2; }
+            else if (phase == 2) { sb[lane] = eb2; }
+            else { sa[lane] = ea; sb[lane] = eb2; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int nAr = __builtin_amdgcn_readlane(nA, r * 8) - 8 * ha;
+                const int nBr = __builtin_amdgcn_readlane(nB, r * 8) - 8 * hb;
+                if (nAr <= 0 || nBr <= 0) continue;
+                const Ent xa = sa[r * 8 + pa];
+                const Ent xb = sb[r * 8 + pb];
+                if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                    atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
+                               xa.val * xb.val);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__any(nA > 16) || __any(nB > 16)) {
+            // very long lists (> 16 entries of one row in one 128-column chunk): remaining
+            // 8 x 8 blocks straight from the CSR arrays
+            for (int r = 0; r < 8; ++r) {
+                const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
+                const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
+                if ((nAr <= 16 && nBr <= 16) || nAr == 0 || nBr == 0) continue;
                 const int pAr = __builtin_amdgcn_readlane(pA0, r * 8);
                 const int pBr = __builtin_amdgcn_readlane(pB0, r * 8);
                 const F dr = readlane_f<F>(dk, r * 8);
@@ -424,7 +452,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                         ca = ind[pAr + a] - i0;
                         va = data[pAr + a] * dr;
                     }
-                    for (int b0 = (a0 == 0 ? 8 : 0); b0 < nBr; b0 += 8) {
+                    for (int b0 = (a0 < 16 ? 16 : 0); b0 < nBr; b0 += 8) {
                         const int b = b0 + pb;
                         if (a < nAr && b < nBr) {
                             const int cb = ind[pBr + b] - j0;
@@ -436,7 +464,6 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
