@@ -822,19 +822,27 @@ constexpr int GATHER_CPW = 32;                      // sparse columns (static ac
 constexpr int GATHER_NW = 16;                       // waves per workgroup -> 512 sparse columns
 constexpr int GATHER_THREADS = GATHER_NW * 64;
 
-// One entry step: broadcast (value, row offset) of stream position p from the 64-entry
-// register chunk, read the LDS slab row, fused multiply-add into the STATIC accumulator.
-#define TM_GATHER_LOAD(A, X, LIDX)                                                        \
-    const F A = readlane_f<F>(va, (LIDX));                                                \
-    const F X = *reinterpret_cast<const F *>(                                             \
-        slab + (unsigned)__builtin_amdgcn_readlane((int)vk, (LIDX)) + lane_off);
+// Stream entries are broadcast to the 64 lanes through a small per-wave LDS ring (two halves
+// of 64 entries): a uniform-address ds_read_b128 delivers {value, row offset} to every lane
+// (v_readlane costs ~9 cycles each on this kernel's critical path, 3 per nonzero).
+template <typename F>
+struct __attribute__((aligned(16))) GEntry {
+    F a;
+    unsigned ko;
+    unsigned pad;
+};
+
+#define TM_GATHER_STEP(E, X, LIDX)                                                        \
+    const GEntry<F> E = ring[(LIDX)];                                                     \
+    const F X = *reinterpret_cast<const F *>(slab + E.ko + lane_off);
 
 template <typename F, int C>
 struct ColLoop {
     // processes static column C of the wave's group, then recurses to C + 1
     static __device__ __forceinline__ void run(F (&acc)[GATHER_CPW],
-                                               const unsigned char *__restrict__ slab, int cntv,
-                                               int &pos, F &va, unsigned &vk, F &na, unsigned &nk,
+                                               const unsigned char *__restrict__ slab,
+                                               GEntry<F> *__restrict__ ring0, int &half, int cntv,
+                                               int &pos, F &na, unsigned &nk,
                                                const F *__restrict__ vals,
                                                const unsigned *__restrict__ koff, int64_t base,
                                                int total, int lane, int lane_off) {
@@ -843,27 +851,34 @@ struct ColLoop {
             // stay inside the current 64-entry chunk: no rotation test in the hot loop
             const int l0 = pos & 63;
             const int m = min(nc, 64 - l0);
+            const GEntry<F> *ring = ring0 + half * 64 + l0;
             int t = 0;
             for (; t + 4 <= m; t += 4) {   // 4 independent LDS reads in flight
-                TM_GATHER_LOAD(a0, x0, l0 + t)
-                TM_GATHER_LOAD(a1, x1, l0 + t + 1)
-                TM_GATHER_LOAD(a2, x2, l0 + t + 2)
-                TM_GATHER_LOAD(a3, x3, l0 + t + 3)
-                acc[C] = fma(a0, x0, acc[C]);
-                acc[C] = fma(a1, x1, acc[C]);
-                acc[C] = fma(a2, x2, acc[C]);
-                acc[C] = fma(a3, x3, acc[C]);
+                TM_GATHER_STEP(e0, x0, t)
+                TM_GATHER_STEP(e1, x1, t + 1)
+                TM_GATHER_STEP(e2, x2, t + 2)
+                TM_GATHER_STEP(e3, x3, t + 3)
+                acc[C] = fma(e0.a, x0, acc[C]);
+                acc[C] = fma(e1.a, x1, acc[C]);
+                acc[C] = fma(e2.a, x2, acc[C]);
+                acc[C] = fma(e3.a, x3, acc[C]);
             }
             for (; t < m; ++t) {
-                TM_GATHER_LOAD(a0, x0, l0 + t)
-                acc[C] = fma(a0, x0, acc[C]);
+                TM_GATHER_STEP(e0, x0, t)
+                acc[C] = fma(e0.a, x0, acc[C]);
             }
             pos += m;
             nc -= m;
             if ((pos & 63) == 0) {
-                // chunk exhausted: rotate in the prefetched chunk, issue the next prefetch
-                va = na;
-                vk = nk;
+                // chunk exhausted: publish the prefetched chunk in the other ring half and
+                // issue the next prefetch
+                half ^= 1;
+                GEntry<F> e;
+                e.a = na;
+                e.ko = nk;
+                e.pad = 0;
+                ring0[half * 64 + lane] = e;
+                __builtin_amdgcn_wave_barrier();
                 const int nxt = pos + 64 + lane;
                 if (nxt < total) {
                     na = vals[base + nxt];
@@ -872,8 +887,8 @@ struct ColLoop {
             }
         }
         if constexpr (C + 1 < GATHER_CPW)
-            ColLoop<F, C + 1>::run(acc, slab, cntv, pos, va, vk, na, nk, vals, koff, base, total,
-                                   lane, lane_off);
+            ColLoop<F, C + 1>::run(acc, slab, ring0, half, cntv, pos, na, nk, vals, koff, base,
+                                   total, lane, lane_off);
     }
 };
 
@@ -893,7 +908,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPRs / s_load
     const int group = blockIdx.z * GATHER_NW + wave;
     const bool active = group < n_groups;
     const int j0 = blockIdx.y * 64;
@@ -998,9 +1013,16 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         }
         load_meta(s + 2);
         if (active && total > 0 && !(dbg & 1)) {
-            int pos = 0;
-            ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, cntv, pos, va, vk, na, nk, vals, koff,
-                               base, total, lane, lane_off);
+            int pos = 0, half = 0;
+            GEntry<F> *ring0 = reinterpret_cast<GEntry<F> *>(smem_raw + 2 * SLABB) + wave * 128;
+            GEntry<F> e;
+            e.a = va;
+            e.ko = vk;
+            e.pad = 0;
+            ring0[lane] = e;
+            __builtin_amdgcn_wave_barrier();
+            ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, ring0, half, cntv, pos, na, nk, vals,
+                               koff, base, total, lane, lane_off);
         }
         if (s + 1 < s1 && !(dbg & 4)) store_slab(buf ^ 1);
         __syncthreads();
@@ -1052,7 +1074,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F);
+    const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F) + (size_t)GATHER_NW * 128 * sizeof(GEntry<F>);
     auto kern = &csr_dense_gather_kernel<F>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
