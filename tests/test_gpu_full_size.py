@@ -1,0 +1,146 @@
+"""-m gpu parity tests, part 3: BASELINE.json's FULL sizes, through size-independent properties
+(the oracle cannot run 10M rows in seconds): exact categorical counts, linearity in d, a
+checksum of checksums that ties sandwich to matvec, symmetry, and a true oracle comparison on a
+random row subset (rows=...) whose data is pulled back from HBM."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse as sps
+
+import _cases as cs
+from _gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _orc():
+    from oracle import oracle as orc
+
+    return orc
+
+
+def _subset_specs(X, rows_t):
+    """Pull the selected rows of a device SplitMatrix back as oracle blocks."""
+    import tabmat_amd as tm
+
+    blocks = []
+    for m in X.matrices:
+        if isinstance(m, tm.DenseMatrix):
+            blocks.append(("dense", m._dev().as_2d()[rows_t].cpu().numpy()))
+        elif isinstance(m, tm.SparseMatrix):
+            c = m._dev()
+            lo, hi = c.indptr[rows_t], c.indptr[rows_t + 1]
+            cnt = (hi - lo)
+            starts = torch.repeat_interleave(lo, cnt)
+            offs = torch.arange(int(cnt.sum()), device=lo.device) - torch.repeat_interleave(
+                torch.cumsum(cnt, 0) - cnt, cnt)
+            sel = starts + offs
+            indptr = np.concatenate([[0], np.cumsum(cnt.cpu().numpy())])
+            S = sps.csr_matrix((c.data[sel].cpu().numpy(), c.indices[sel].cpu().numpy(), indptr),
+                               shape=(len(rows_t), c.m))
+            blocks.append(("sparse", S.tocsc()))
+        else:
+            blocks.append(("cat", m._dev()[rows_t].cpu().numpy(), m.shape[1] + int(m.drop_first),
+                           m.drop_first))
+    return blocks
+
+
+def test_cfg4_split_sandwich_10M():
+    """BASELINE configs[3]: dense 128 + sparse 512 @5% + cats (256, 96, 32), 10M rows, float64."""
+    import tabmat_amd as tm
+    from tabmat_amd import synth
+
+    n = 10_000_000
+    X = synth.mixed_split(n, 128, 512, (256, 96, 32), 0.05, torch.float64, 3)
+    p = X.shape[1]
+    assert p == 1024
+    g = torch.Generator(device="cuda").manual_seed(1)
+    d1 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    d2 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    S1 = X.sandwich(d1)
+    S2 = X.sandwich(d2)
+    S12 = X.sandwich(d1 + d2)
+    assert S1.dtype == torch.float64 and tuple(S1.shape) == (p, p)
+    # symmetry: exact (mirrored tiles)
+    assert torch.equal(S1, S1.T)
+    # linearity in d
+    assert float((S12 - (S1 + S2)).abs().max() / S12.abs().max()) < 1e-12
+    # checksum of checksums: 1' (X' D X) 1 == sum_k d_k (X 1)_k^2, X 1 from the matvec kernels
+    ones = torch.ones(p, dtype=torch.float64, device="cuda")
+    rs = X.matvec(ones)
+    lhs = float(S1.sum())
+    rhs = float((d1 * rs * rs).sum())
+    assert abs(lhs - rhs) / abs(rhs) < 1e-11
+    # X' d from transpose_matvec == first-moment identity through a second sandwich-free path
+    tmv = X.transpose_matvec(d1)
+    assert abs(float(tmv.sum()) - float((d1 * rs).sum())) / abs(float(tmv.sum())) < 1e-11
+    # categorical diagonal blocks with d == 1 are exact counts
+    Sones = X.sandwich(torch.ones(n, dtype=torch.float64, device="cuda"))
+    for m, idx in zip(X.matrices, X.indices):
+        if isinstance(m, tm.CategoricalMatrix):
+            counts = torch.bincount(m._dev().to(torch.int64), minlength=m.shape[1]).to(torch.float64)
+            ii = torch.as_tensor(idx, device="cuda")
+            assert torch.equal(Sones[ii, ii], counts)
+    # true oracle comparison on a random row subset via rows=
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(n, size=20_000, replace=False)).astype(np.int32)
+    rows_t = torch.as_tensor(rows.astype(np.int64), device="cuda")
+    sub = X.sandwich(d1, rows=rows)
+    blocks = [cs.to_oracle_block(s) for s in _subset_specs(X, rows_t)]
+    ref = _orc().split_sandwich(blocks, [np.asarray(i) for i in X.indices], d1[rows_t].cpu().numpy())
+    assert rel_err(sub.cpu().numpy(), ref) < 1e-10
+
+
+def test_cfg2_dense_f32_10M_x_256():
+    """BASELINE configs[1]: DenseMatrix.sandwich float32, 10M x 256 (MFMA row-weighted syrk)."""
+    from tabmat_amd import synth
+
+    n, k = 10_000_000, 256
+    X = synth.dense_block(n, k, torch.float32, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    d1 = torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+    d2 = torch.rand(n, dtype=torch.float32, device="cuda", generator=g)
+    S1, S2, S12 = X.sandwich(d1), X.sandwich(d2), X.sandwich(d1 + d2)
+    assert S1.dtype == torch.float32 and tuple(S1.shape) == (k, k)
+    assert torch.equal(S1, S1.T)
+    scale = float(S12.abs().max())
+    # fp32 accumulation over ~2e4 rows per workgroup, partials combined in double: 1e-4 relative
+    assert float((S12 - (S1 + S2)).abs().max()) / scale < 1e-4
+    # trace identity against an independent fp64 torch reduction
+    A = X._dev().as_2d()
+    tr = 0.0
+    for lo in range(0, n, 2_000_000):
+        blk = A[lo:lo + 2_000_000].to(torch.float64)
+        tr += float(((blk * blk).sum(dim=1) * d1[lo:lo + 2_000_000].to(torch.float64)).sum())
+    assert abs(float(S1.to(torch.float64).diagonal().sum()) - tr) / tr < 1e-5
+    # oracle on a row subset
+    rng = np.random.default_rng(1)
+    rows = np.sort(rng.choice(n, size=30_000, replace=False)).astype(np.int32)
+    rt = torch.as_tensor(rows.astype(np.int64), device="cuda")
+    ref = _orc().dense_sandwich(A[rt].cpu().numpy().astype(np.float64),
+                                d1[rt].cpu().numpy().astype(np.float64), None, None)
+    assert rel_err(X.sandwich(d1, rows=rows).cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("zipf", [0.0, 1.1])
+def test_cfg3_categorical_50M_x_10k(zipf):
+    """BASELINE configs[2]: CategoricalMatrix.sandwich + transpose_matvec, 50M rows x 10k
+    categories (uniform and Zipf-skewed codes).  Counts are bit-exact."""
+    from tabmat_amd import synth
+
+    n, c = 50_000_000, 10_000
+    X = synth.cat_block(n, c, seed=2, zipf=zipf)
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    counts = torch.bincount(X._dev().to(torch.int64), minlength=c).to(torch.float64)
+    diag = X._sandwich_diag_dev(ones, None, None)
+    assert torch.equal(diag, counts)
+    assert torch.equal(X.transpose_matvec(ones), counts)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    dd = X._sandwich_diag_dev(d, None, None)
+    ref = torch.zeros(c, dtype=torch.float64, device="cuda").index_add_(0, X._dev().to(torch.int64), d)
+    assert float((dd - ref).abs().max() / ref.abs().max()) < 1e-12
+    assert abs(float(dd.sum()) - float(d.sum())) / float(d.sum()) < 1e-12
+    # matvec (gather) is exact
+    v = torch.rand(c, dtype=torch.float64, device="cuda", generator=g)
+    assert torch.equal(X.matvec(v), v[X._dev().to(torch.int64)])
