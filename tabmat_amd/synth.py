@@ -53,8 +53,11 @@ def cat_block(n: int, n_categories: int, seed: int = 0, dtype=np.float64, drop_f
               zipf: float = 0.0) -> CategoricalMatrix:
     g = _gen(seed)
     if zipf > 0:
+        # inverse-CDF sampling (torch.multinomial is far too slow for 5e7 draws)
         w = 1.0 / torch.arange(1, n_categories + 1, dtype=torch.float64, device=g.device) ** zipf
-        codes = torch.multinomial(w / w.sum(), n, replacement=True, generator=g).to(torch.int32)
+        cdf = torch.cumsum(w / w.sum(), dim=0)
+        u = torch.rand(n, dtype=torch.float64, device=g.device, generator=g)
+        codes = torch.searchsorted(cdf, u).clamp_(max=n_categories - 1).to(torch.int32)
     else:
         codes = torch.randint(0, n_categories, (n,), dtype=torch.int32, device=g.device, generator=g)
     return CategoricalMatrix(codes, categories=np.arange(n_categories), drop_first=drop_first,

@@ -138,8 +138,9 @@ def test_cfg3_categorical_50M_x_10k(zipf):
     g = torch.Generator(device="cuda").manual_seed(3)
     d = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     dd = X._sandwich_diag_dev(d, None, None)
-    ref = torch.zeros(c, dtype=torch.float64, device="cuda").index_add_(0, X._dev().to(torch.int64), d)
-    assert float((dd - ref).abs().max() / ref.abs().max()) < 1e-12
+    # independent reference on the host (torch.index_add_ degenerates under skewed indices)
+    ref = np.bincount(X._dev().cpu().numpy(), weights=d.cpu().numpy(), minlength=c)
+    assert rel_err(dd.cpu().numpy(), ref) < 1e-12
     assert abs(float(dd.sum()) - float(d.sum())) / float(d.sum()) < 1e-12
     # matvec (gather) is exact
     v = torch.rand(c, dtype=torch.float64, device="cuda", generator=g)
