@@ -154,7 +154,7 @@ int tm_csr_dense_sandwich_f64(const double *csr_data, const int32_t *csr_indices
                               int64_t n_rows, const int32_t *A_cols, int64_t nA,
                               const int32_t *B_cols, int64_t nB, double *out, void *stream);
 
-/* Same product as tm_csr_dense_sandwich_* with rows = A_cols = B_cols = NULL and a C-ordered B,
+/* Same product as tm_csr_dense_sandwich_* with rows = A_cols = B_cols = NULL (B C- or F-ordered),
  * on the slab-blocked column-major twin of the sparse block (the fast path; restrictions are
  * applied by the host side through a masked d and sub-selection of the small result).
  * Layout: rows cut into slabs of tm_slab_rows() rows; within a slab nonzeros ordered by
@@ -166,10 +166,10 @@ int tm_slab_rows(void);
 int tm_slab_group_cols(void);
 int tm_csr_dense_sandwich_slab_f32(const float *vals, const uint32_t *koff, const uint16_t *cnt,
                                    const int64_t *gptr, int64_t n, int64_t m, const float *B,
-                                   int64_t r, const float *d, float *out, void *stream);
+                                   int64_t r, int order_f, const float *d, float *out, void *stream);
 int tm_csr_dense_sandwich_slab_f64(const double *vals, const uint32_t *koff, const uint16_t *cnt,
                                    const int64_t *gptr, int64_t n, int64_t m, const double *B,
-                                   int64_t r, const double *d, double *out, void *stream);
+                                   int64_t r, int order_f, const double *d, double *out, void *stream);
 
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */

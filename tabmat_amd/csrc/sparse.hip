@@ -892,7 +892,7 @@ struct ColLoop {
     }
 };
 
-template <typename F>
+template <typename F, bool ORDER_F>
 __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff,
     const unsigned short *__restrict__ cnt, const int64_t *__restrict__ gptr, int n_groups,
@@ -921,42 +921,87 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     for (int c = 0; c < GATHER_CPW; ++c) acc[c] = F(0);
 
     vec_t stage[NV];
+    // C-ordered B: thread -> (row, 16-byte vector of columns).  F-ordered B (what the
+    // reference's from_csc / from_df produce, constructor_util.py:39-43): thread -> (column,
+    // pair of consecutive rows), coalesced down the column; transposed on the way into LDS.
     auto load_slab = [&](int64_t s) {
-        constexpr int VPR = 64 / VEC;  // vectors per slab row
+        if (!ORDER_F) {
+            constexpr int VPR = 64 / VEC;  // vectors per slab row
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int q = tid + i * GATHER_THREADS;
-            const int row = q / VPR;
-            const int c = (q % VPR) * VEC;
-            const int64_t k = s * SLAB_R + row;
-            vec_t v;
+            for (int i = 0; i < NV; ++i) {
+                const int q = tid + i * GATHER_THREADS;
+                const int row = q / VPR;
+                const int c = (q % VPR) * VEC;
+                const int64_t k = s * SLAB_R + row;
+                vec_t v;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[e] = F(0);
-            if (k < n) {
-                const F dk = d[k];
-                const F *src = B + k * r + j0 + c;
-                if (j0 + c + VEC <= nB && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                    v = *reinterpret_cast<const vec_t *>(src);
+                for (int e = 0; e < VEC; ++e) v[e] = F(0);
+                if (k < n) {
+                    const F dk = d[k];
+                    const F *src = B + k * r + j0 + c;
+                    if (j0 + c + VEC <= nB && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                        v = *reinterpret_cast<const vec_t *>(src);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] *= dk;
-                } else {
+                        for (int e = 0; e < VEC; ++e) v[e] *= dk;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        if (j0 + c + e < nB) v[e] = dk * src[e];
+                        for (int e = 0; e < VEC; ++e)
+                            if (j0 + c + e < nB) v[e] = dk * src[e];
+                    }
                 }
+                stage[i] = v;
             }
-            stage[i] = v;
+        } else {
+            constexpr int RPC = SLAB_R / VEC;  // row-vectors per column
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = tid + i * GATHER_THREADS;
+                const int c = q / RPC;
+                const int row = (q % RPC) * VEC;
+                const int64_t k = s * SLAB_R + row;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = F(0);
+                if (j0 + c < nB) {
+                    const F *src = B + (int64_t)(j0 + c) * n + k;
+                    if (k + VEC <= n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(d + k) & 15) == 0)) {
+                        v = *reinterpret_cast<const vec_t *>(src);
+                        const vec_t dv = *reinterpret_cast<const vec_t *>(d + k);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v[e] *= dv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (k + e < n) v[e] = d[k + e] * src[e];
+                    }
+                }
+                stage[i] = v;
+            }
         }
     };
     auto store_slab = [&](int buf) {
-        constexpr int VPR = 64 / VEC;
         unsigned char *dst = smem_raw + buf * SLABB;
+        if (!ORDER_F) {
+            constexpr int VPR = 64 / VEC;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int q = tid + i * GATHER_THREADS;
-            const int row = q / VPR;
-            const int c = (q % VPR) * VEC;
-            *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = stage[i];
+            for (int i = 0; i < NV; ++i) {
+                const int q = tid + i * GATHER_THREADS;
+                const int row = q / VPR;
+                const int c = (q % VPR) * VEC;
+                *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = stage[i];
+            }
+        } else {
+            constexpr int RPC = SLAB_R / VEC;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = tid + i * GATHER_THREADS;
+                const int c = q / RPC;
+                const int row = (q % RPC) * VEC;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) = stage[i][e];
+            }
         }
     };
 
@@ -1049,7 +1094,7 @@ __global__ void gather_untile_kernel(const F *__restrict__ tmp, int64_t m, int64
 template <typename F>
 static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsigned short *cnt,
                                 const int64_t *gptr, int64_t n, int64_t m, const F *B, int64_t r,
-                                const F *d, F *out, hipStream_t st) {
+                                int order_f, const F *d, F *out, hipStream_t st) {
     const int64_t nB = r;
     const int64_t total = m * nB;
     if (total == 0) return TM_OK;
@@ -1075,7 +1120,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F) + (size_t)GATHER_NW * 128 * sizeof(GEntry<F>);
-    auto kern = &csr_dense_gather_kernel<F>;
+    auto kern = order_f ? &csr_dense_gather_kernel<F, true> : &csr_dense_gather_kernel<F, false>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
@@ -1116,14 +1161,14 @@ int tm_slab_group_cols(void) { return tmh::GATHER_CPW; }
 
 int tm_csr_dense_sandwich_slab_f32(const float *vals, const uint32_t *koff, const uint16_t *cnt,
                                    const int64_t *gptr, int64_t n, int64_t m, const float *B,
-                                   int64_t r, const float *d, float *out, void *stream) {
-    return tmh::run_csr_dense_gather<float>(vals, koff, cnt, gptr, n, m, B, r, d, out,
+                                   int64_t r, int order_f, const float *d, float *out, void *stream) {
+    return tmh::run_csr_dense_gather<float>(vals, koff, cnt, gptr, n, m, B, r, order_f, d, out,
                                             tmh::as_stream(stream));
 }
 int tm_csr_dense_sandwich_slab_f64(const double *vals, const uint32_t *koff, const uint16_t *cnt,
                                    const int64_t *gptr, int64_t n, int64_t m, const double *B,
-                                   int64_t r, const double *d, double *out, void *stream) {
-    return tmh::run_csr_dense_gather<double>(vals, koff, cnt, gptr, n, m, B, r, d, out,
+                                   int64_t r, int order_f, const double *d, double *out, void *stream) {
+    return tmh::run_csr_dense_gather<double>(vals, koff, cnt, gptr, n, m, B, r, order_f, d, out,
                                              tmh::as_stream(stream));
 }
 

@@ -62,14 +62,14 @@ def csc_rmatvec(X: CsrDev, v, rows, cols, out=None):
 
 
 def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
-    """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B:
-    slab-blocked gather kernel with static register accumulators (csrc/sparse.hip, K3 v2)."""
-    assert B.order_f == 0 and B.n == A.n
+    """Fast path of ext/sparse.pyx:211-260 for an unrestricted product (B C- or F-ordered):
+    slab-blocked gather kernel with static register accumulators (csrc/sparse.hip, K3)."""
+    assert B.n == A.n
     out = D.zeros((A.m, B.m), A.vals.dtype)
     if A.m == 0 or B.m == 0 or A.n == 0:
         return out
     call(f"tm_csr_dense_sandwich_slab_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.cnt),
-         D.p(A.gptr), A.n, A.m, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
+         D.p(A.gptr), A.n, A.m, D.p(B.buf), B.m, B.order_f, D.p(d), D.p(out), D.stream_ptr())
     return out
 
 

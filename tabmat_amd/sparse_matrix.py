@@ -210,7 +210,7 @@ class SparseMatrix(MatrixBase):
                     f"np.float32. This matrix is of type {self.dtype}, B is of type "
                     f"{other.dtype}.")
             Bd = other._dev()
-            if Bd.order_f == 0 and self.shape[0] > 0 and self._dev().data.numel() > 0:
+            if self.shape[0] > 0 and self._dev().data.numel() > 0:
                 # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded
                 # rows contribute exactly 0), column restrictions select from the small result
                 if rows is not None:

@@ -262,7 +262,7 @@ class SplitMatrix(MatrixBase):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
                 stacked = None
-                if isinstance(mw, DenseMatrix) and mw._dev().order_f == 0:
+                if isinstance(mw, DenseMatrix):
                     # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
                     # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
                     from .ext import sparse as xs
