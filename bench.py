@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2", "cfg3"])
-    ap.add_argument("--cpu-rows", type=int, default=200_000)
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows of the bounded CPU-baseline sample (0 = per-workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-op kernel times to stderr")
     ap.add_argument("--out", default=None, help="also write the JSON (+breakdown) to this file")
@@ -324,7 +325,9 @@ def main():
             "sum_kernel_ms": round(sum(bd.values()), 4),
         }
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rows, 3)
+            cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,
+                                         "cfg3": 50_000_000}[args.workload]
+            result["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_rows, n_local), 3)
         if args.breakdown:
             for k, v in sorted(bd.items(), key=lambda kv: -kv[1]):
                 print(f"  {k:24s} {v:9.4f} ms", file=sys.stderr)

@@ -892,7 +892,7 @@ struct ColLoop {
     }
 };
 
-template <typename F, bool ORDER_F>
+template <typename F, bool ORDER_F, bool VEC_OK>
 __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff,
     const unsigned short *__restrict__ cnt, const int64_t *__restrict__ gptr, int n_groups,
@@ -921,9 +921,14 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     for (int c = 0; c < GATHER_CPW; ++c) acc[c] = F(0);
 
     vec_t stage[NV];
+    vec_t dstage[ORDER_F ? NV : 1];
+    F dsc[ORDER_F ? 1 : NV];
     // C-ordered B: thread -> (row, 16-byte vector of columns).  F-ordered B (what the
     // reference's from_csc / from_df produce, constructor_util.py:39-43): thread -> (column,
-    // pair of consecutive rows), coalesced down the column; transposed on the way into LDS.
+    // VEC consecutive rows), coalesced down the column; transposed on the way into LDS.
+    // load_slab ONLY ISSUES loads (branch-free: out-of-range lanes read a clamped in-range
+    // address and are zeroed later), so all of them are in flight together while the previous
+    // slab is processed; the scaling by d happens in store_slab.
     auto load_slab = [&](int64_t s) {
         if (!ORDER_F) {
             constexpr int VPR = 64 / VEC;  // vectors per slab row
@@ -932,55 +937,40 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const int q = tid + i * GATHER_THREADS;
                 const int row = q / VPR;
                 const int c = (q % VPR) * VEC;
-                const int64_t k = s * SLAB_R + row;
-                vec_t v;
+                const int64_t k = min(s * SLAB_R + row, n - 1);
+                dsc[i] = d[k];
+                if (VEC_OK) {
+                    const int cc = min(j0 + c, nB - VEC);
+                    stage[i] = *reinterpret_cast<const vec_t *>(B + k * r + cc);
+                } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = F(0);
-                if (k < n) {
-                    const F dk = d[k];
-                    const F *src = B + k * r + j0 + c;
-                    if (j0 + c + VEC <= nB && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                        v = *reinterpret_cast<const vec_t *>(src);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= dk;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e)
-                            if (j0 + c + e < nB) v[e] = dk * src[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) stage[i][e] = B[k * r + min(j0 + c + e, nB - 1)];
                 }
-                stage[i] = v;
             }
         } else {
             constexpr int RPC = SLAB_R / VEC;  // row-vectors per column
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int q = tid + i * GATHER_THREADS;
-                const int c = q / RPC;
+                const int c = min(j0 + q / RPC, nB - 1);
                 const int row = (q % RPC) * VEC;
                 const int64_t k = s * SLAB_R + row;
-                vec_t v;
+                if (VEC_OK) {
+                    const int64_t kk = min(k, n - VEC);
+                    stage[i] = *reinterpret_cast<const vec_t *>(B + (int64_t)c * n + kk);
+                    dstage[i] = *reinterpret_cast<const vec_t *>(d + kk);
+                } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[e] = F(0);
-                if (j0 + c < nB) {
-                    const F *src = B + (int64_t)(j0 + c) * n + k;
-                    if (k + VEC <= n && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(d + k) & 15) == 0)) {
-                        v = *reinterpret_cast<const vec_t *>(src);
-                        const vec_t dv = *reinterpret_cast<const vec_t *>(d + k);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v[e] *= dv[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e)
-                            if (k + e < n) v[e] = d[k + e] * src[e];
+                    for (int e = 0; e < VEC; ++e) {
+                        const int64_t kk = min(k + e, n - 1);
+                        stage[i][e] = B[(int64_t)c * n + kk];
+                        dstage[i][e] = d[kk];
                     }
                 }
-                stage[i] = v;
             }
         }
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int64_t s, int buf) {
         unsigned char *dst = smem_raw + buf * SLABB;
         if (!ORDER_F) {
             constexpr int VPR = 64 / VEC;
@@ -989,7 +979,12 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const int q = tid + i * GATHER_THREADS;
                 const int row = q / VPR;
                 const int c = (q % VPR) * VEC;
-                *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = stage[i];
+                const bool rok = s * SLAB_R + row < n;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    v[e] = (rok && j0 + c + e < nB) ? dsc[i] * stage[i][e] : F(0);
+                *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = v;
             }
         } else {
             constexpr int RPC = SLAB_R / VEC;
@@ -998,9 +993,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const int q = tid + i * GATHER_THREADS;
                 const int c = q / RPC;
                 const int row = (q % RPC) * VEC;
+                const bool cok = j0 + c < nB;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) = stage[i][e];
+                for (int e = 0; e < VEC; ++e) {
+                    const bool ok = cok && (s * SLAB_R + row + e < n);
+                    *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) =
+                        ok ? dstage[i][e] * stage[i][e] : F(0);
+                }
             }
         }
     };
@@ -1042,7 +1041,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         load_head();                      // head(s0)
         load_meta(s0 + 1);                // meta(s0 + 1)
         load_slab(s0);
-        store_slab(0);
+        store_slab(s0, 0);
     }
     __syncthreads();
     for (int64_t s = s0; s < s1; ++s) {
@@ -1069,7 +1068,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
             ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, ring0, half, cntv, pos, na, nk, vals,
                                koff, base, total, lane, lane_off);
         }
-        if (s + 1 < s1 && !(dbg & 4)) store_slab(buf ^ 1);
+        if (s + 1 < s1 && !(dbg & 4)) store_slab(s + 1, buf ^ 1);
         __syncthreads();
     }
     if (active) {
@@ -1120,7 +1119,16 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F) + (size_t)GATHER_NW * 128 * sizeof(GEntry<F>);
-    auto kern = order_f ? &csr_dense_gather_kernel<F, true> : &csr_dense_gather_kernel<F, false>;
+    // 16-byte vector loads need aligned bases and row/column strides that keep every vector
+    // 16-byte aligned and entirely inside the matrix
+    constexpr int VEC = 16 / (int)sizeof(F);
+    const bool base_ok = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && n >= VEC && nB >= VEC;
+    const bool vec_ok = order_f ? (base_ok && n % VEC == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0)
+                                : (base_ok && r % VEC == 0);
+    auto kern = order_f ? (vec_ok ? &csr_dense_gather_kernel<F, true, true>
+                                  : &csr_dense_gather_kernel<F, true, false>)
+                        : (vec_ok ? &csr_dense_gather_kernel<F, false, true>
+                                  : &csr_dense_gather_kernel<F, false, false>);
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);

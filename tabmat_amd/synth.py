@@ -89,7 +89,12 @@ def algorithmic_bytes(mat) -> int:
         else:
             total += n * 4
     total += n * isz                       # d
-    total += mat.shape[1] ** 2 * 8         # float64 p x p result
+    if isinstance(mat, SplitMatrix):
+        total += mat.shape[1] ** 2 * 8     # float64 p x p result
+    elif isinstance(mat, CategoricalMatrix):
+        total += mat.shape[1] * isz        # diagonal only
+    else:
+        total += mat.shape[1] ** 2 * isz
     return int(total)
 
 
