@@ -127,6 +127,17 @@ class CategoricalMatrix(MatrixBase):
         self._dev()
         return self
 
+    def _onehot(self):
+        """(slab form of the one-hot encoding, row permutation) for the gather kernel; cached."""
+        tdt = D.torch_dtype(self.dtype)
+        cache = getattr(self, "_onehot_cache", None)
+        if cache is None or cache[0] != tdt:   # astype() changes the nominal dtype in place
+            from .ext._types import onehot_slab
+
+            self._onehot_cache = (tdt, onehot_slab([(self._dev(), self.shape[1], self.drop_first)],
+                                                   self.shape[0], tdt))
+        return self._onehot_cache[1]
+
     def recover_orig(self):
         orig = self.categories[self.indices]
         if self._has_missings:
@@ -296,6 +307,19 @@ class CategoricalMatrix(MatrixBase):
     def _cross_sandwich_dev(self, other, d, rows, L_cols, R_cols):
         """X' diag(d) Y, device in / device out (categorical_matrix.py:655-671)."""
         if isinstance(other, DenseMatrix):
+            if self.shape[0] >= 4096 and self.shape[1] > 0:
+                # large n: atomic-free gather kernel on the one-hot slab (masked d for a row
+                # restriction, sub-selection of the small result for column restrictions)
+                from .ext import sparse as xs
+
+                if rows is not None:
+                    dm = torch.zeros_like(d)
+                    r64 = rows.to(torch.int64)
+                    dm[r64] = d[r64]
+                    d = dm
+                oh, inv = self._onehot()
+                res = xs.csr_dense_sandwich_slab(oh, other._dev(), d)[inv]
+                return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_dense(self._dev(), self.shape[1], d, other._dev(), rows,
                                             R_cols, self.drop_first)
             return self._restrict(res, L_cols, None)

@@ -325,15 +325,38 @@ template <typename F, int TS>
 __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
-    int64_t rows_per_block, F *__restrict__ ws) {
+    int nb_diag, int nb_off, int max_nb, F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
     typedef K2Entry<F> Ent;
     Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(F) * TS * TS);   // [waves][2][64]
-    int I = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) - 1.0f) * 0.5f);
-    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.y) ++I;
-    while (I * (I + 1) / 2 > (int)blockIdx.y) --I;
-    const int J = (int)blockIdx.y - I * (I + 1) / 2;
+    // 1-D grid: the nch diagonal tiles come first with nb_diag workgroups each, then the
+    // off-diagonal tiles with nb_off each (a diagonal tile has ~40 % fewer pairs per row).
+    int part, blk, nblk_part;
+    {
+        const int b = blockIdx.x;
+        const int ndiag_blocks = nch * nb_diag;
+        if (b < ndiag_blocks) {
+            const int Id = b / nb_diag;
+            blk = b % nb_diag;
+            nblk_part = nb_diag;
+            part = Id * (Id + 1) / 2 + Id;
+        } else {
+            const int o = (b - ndiag_blocks) / nb_off;       // o-th off-diagonal tile
+            blk = (b - ndiag_blocks) % nb_off;
+            nblk_part = nb_off;
+            int Io = (int)((sqrtf(8.0f * (float)o + 1.0f) - 1.0f) * 0.5f);   // (Io+1, Jo), Jo <= Io
+            while ((Io + 1) * (Io + 2) / 2 <= o) ++Io;
+            while (Io * (Io + 1) / 2 > o) --Io;
+            const int Jo = o - Io * (Io + 1) / 2;
+            part = (Io + 1) * (Io + 2) / 2 + Jo;
+        }
+    }
+    const int64_t rows_per_block = (n + nblk_part - 1) / nblk_part;
+    int I = (int)((sqrtf(8.0f * (float)part + 1.0f) - 1.0f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= part) ++I;
+    while (I * (I + 1) / 2 > part) --I;
+    const int J = part - I * (I + 1) / 2;
     const int i0 = I * TS, j0 = J * TS;
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = F(0);
     __syncthreads();
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const int lr = lane >> 3, lt = lane & 7;       // load phase: row-in-group, entry slot
     Ent *sa = scratch + (wave * 2 + 0) * 64;
     Ent *sb = scratch + (wave * 2 + 1) * 64;
-    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t0 = (int64_t)blk * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
     const int stride = nch + 1;
 
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         }
     }
     __syncthreads();
-    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
+    F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
         const int r = b / TS, c = b % TS;
         dst[b] = tile[r * TS + (c ^ ((r & 15) << 3))];
@@ -722,10 +745,15 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
     const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
-    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
-    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 1024)));
-    const int64_t rpb = ceil_div(n, nblk);
-    nblk = ceil_div(n, rpb);
+    // workgroups per tile.  Measured: diagonal and off-diagonal tiles cost the same per row
+    // (the per-row overhead dominates the pair count), so the split is even.
+    const int n_off = n_parts - nchunk;
+    int nb_diag = std::max(1, NUM_CU / n_parts);
+    int nb_off = nb_diag;
+    const int cap = (int)std::max<int64_t>(1, ceil_div(n, 1024));
+    nb_diag = std::min(nb_diag, cap);
+    nb_off = std::min(nb_off, cap);
+    const int64_t nblk = std::max(nb_diag, nb_off);   // stride of the partial-tile buffer
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)n_parts * TS * TS);
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS + 256,
@@ -737,8 +765,9 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(K2_WAVES * 64), lds, st,
-                       data, ind, cptr, nchunk, d, n, rpb, ws);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nchunk * nb_diag + n_off * nb_off)),
+                       dim3(K2_WAVES * 64), lds, st, data, ind, cptr, nchunk, d, n, nb_diag, nb_off,
+                       (int)nblk, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,

@@ -169,7 +169,7 @@ class SplitMatrix(MatrixBase):
         self._full_dev_indices()
         cat_ids = [i for i, m in enumerate(self.matrices)
                    if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
-        if len(cat_ids) >= 2 and any(isinstance(m, DenseMatrix) for m in self.matrices):
+        if len(cat_ids) >= 1 and any(isinstance(m, DenseMatrix) for m in self.matrices):
             self._onehot_slab(cat_ids)
         return self
 
@@ -249,7 +249,7 @@ class SplitMatrix(MatrixBase):
         cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
                    and m.shape[1] > 0]
         budget = (128 * 1024) // np.dtype(self.dtype).itemsize
-        if len(cat_ids) >= 2 and len(cat_ids) <= xsplit.MAX_FUSED_CATS:
+        if len(cat_ids) >= 1 and len(cat_ids) <= xsplit.MAX_FUSED_CATS:
             d_eff = d
             if rows is not None:   # row restriction = masked d (excluded rows contribute 0)
                 d_eff = torch.zeros_like(d)
