@@ -111,6 +111,13 @@ int tm_dense_rmatvec_f64(const double *X, int64_t n, int64_t m, int order_f, con
                          const int32_t *rows, int64_t n_rows, const int32_t *cols,
                          int64_t n_cols, double *out, void *stream);
 
+/* out[j] += sum_i w[i] * (X[i,j] - shift[j])^2, all rows / columns (standardize()'s column
+ * variances).  Replaces transpose_square_dot_weights (ext/dense.pyx:103-122). */
+int tm_dense_col_sq_dev_f32(const float *X, int64_t n, int64_t m, int order_f, const float *w,
+                            const float *shift, float *out, void *stream);
+int tm_dense_col_sq_dev_f64(const double *X, int64_t n, int64_t m, int order_f, const double *w,
+                            const double *shift, double *out, void *stream);
+
 /* =====================================================================================
  * Sparse block  (reference: ext/sparse.pyx + ext/sparse_helpers-tmpl.cpp)
  * Only the CSR twin (sparse_matrix.py:133-143) lives on the device:
@@ -194,6 +201,14 @@ int tm_csr_rmatvec_f64(const double *csr_data, const int32_t *csr_indices,
                        const int64_t *csr_indptr, int64_t n, int64_t m, const double *v,
                        const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
                        double *out, void *stream);
+
+/* out[j] += sum_i w[i] * X[i,j]^2 on the CSR twin.  Replaces transpose_square_dot_weights
+ * (ext/sparse.pyx:262-282). */
+int tm_csr_col_sq_f32(const float *csr_data, const int32_t *csr_indices, const int64_t *csr_indptr,
+                      int64_t n, int64_t m, const float *w, float *out, void *stream);
+int tm_csr_col_sq_f64(const double *csr_data, const int32_t *csr_indices,
+                      const int64_t *csr_indptr, int64_t n, int64_t m, const double *w,
+                      double *out, void *stream);
 
 /* =====================================================================================
  * Categorical block  (reference: ext/categorical.pyx, ext/split.pyx,

@@ -561,6 +561,69 @@ __global__ __launch_bounds__(256) void dense_rmatvec_f_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// K7  out[j] += sum_i w[i] * (X[i, j] - shift[j])^2      (ext/dense.pyx:103-122,
+// transpose_square_dot_weights; used once per standardize()).  Same decomposition as rmatvec.
+// -------------------------------------------------------------------------------------------
+template <typename F, bool ORDER_F>
+__global__ __launch_bounds__(256) void dense_col_sq_dev_kernel(
+    const F *__restrict__ X, int64_t n, int64_t m, const F *__restrict__ w,
+    const F *__restrict__ shift, int64_t rows_per_block, F *__restrict__ out) {
+    __shared__ F red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    if (ORDER_F) {
+        for (int64_t c = wave; c < m; c += 4) {
+            const F sh = shift[c];
+            const F *xc = X + c * n;
+            F acc = F(0);
+            for (int64_t t = t0 + lane; t < t1; t += 64) {
+                const F x = xc[t] - sh;
+                acc += w[t] * x * x;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) atomic_add(&out[c], acc);
+        }
+        return;
+    }
+    for (int64_t c0 = 0; c0 < m; c0 += 64) {
+        const int64_t c = c0 + lane;
+        F acc = F(0);
+        if (c < m) {
+            const F sh = shift[c];
+#pragma unroll 4
+            for (int64_t t = t0 + wave; t < t1; t += 4) {
+                const F x = X[t * m + c] - sh;
+                acc += w[t] * x * x;
+            }
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c < m)
+            atomic_add(&out[c], (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+        __syncthreads();
+    }
+}
+
+template <typename F>
+static int run_dense_col_sq_dev(const F *X, int64_t n, int64_t m, int order_f, const F *w,
+                                const F *shift, F *out, hipStream_t st) {
+    if (n == 0 || m == 0) return TM_OK;
+    int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n, 512)), NUM_CU * 4);
+    const int64_t rpb = ceil_div(n, nblk);
+    nblk = ceil_div(n, rpb);
+    if (order_f)
+        hipLaunchKernelGGL((dense_col_sq_dev_kernel<F, true>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           X, n, m, w, shift, rpb, out);
+    else
+        hipLaunchKernelGGL((dense_col_sq_dev_kernel<F, false>), dim3((unsigned)nblk), dim3(256), 0,
+                           st, X, n, m, w, shift, rpb, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 template <typename F>
 static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const F *v,
                             const int32_t *rows, int64_t n_rows, const int32_t *cols,
@@ -657,6 +720,15 @@ TM_DENSE_ENTRY(tm_dense_matvec_f32, float, run_dense_matvec)
 TM_DENSE_ENTRY(tm_dense_matvec_f64, double, run_dense_matvec)
 TM_DENSE_ENTRY(tm_dense_rmatvec_f32, float, run_dense_rmatvec)
 TM_DENSE_ENTRY(tm_dense_rmatvec_f64, double, run_dense_rmatvec)
+
+int tm_dense_col_sq_dev_f32(const float *X, int64_t n, int64_t m, int order_f, const float *w,
+                            const float *shift, float *out, void *stream) {
+    return run_dense_col_sq_dev<float>(X, n, m, order_f, w, shift, out, as_stream(stream));
+}
+int tm_dense_col_sq_dev_f64(const double *X, int64_t n, int64_t m, int order_f, const double *w,
+                            const double *shift, double *out, void *stream) {
+    return run_dense_col_sq_dev<double>(X, n, m, order_f, w, shift, out, as_stream(stream));
+}
 
 int tm_scatter_block_f32(const float *src, int64_t nr, int64_t nc, const int64_t *ri,
                          const int64_t *ci, double *out, int64_t p, int mirror, int diag,

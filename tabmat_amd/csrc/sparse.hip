@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
     const F *__restrict__ v, const int32_t *__restrict__ rows, int64_t n_iter,
     int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out, F *__restrict__ ws,
-    F *__restrict__ out) {
+    F *__restrict__ out, int square) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *bins = reinterpret_cast<F *>(smem_raw);
     if (USE_LDS) {
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
             const int j = ind[p];
             const int oc = col_map ? col_map[j] : j;
             if (oc >= 0) {
-                if (USE_LDS) atomic_add(&bins[oc], data[p] * vi);
-                else atomic_add(&out[oc], data[p] * vi);
+                const F x = square ? data[p] * data[p] : data[p];
+                if (USE_LDS) atomic_add(&bins[oc], x * vi);
+                else atomic_add(&out[oc], x * vi);
             }
         }
     }
@@ -553,7 +554,8 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
 template <typename F>
 static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
                            int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
-                           const int32_t *cols, int64_t n_cols, F *out, hipStream_t st) {
+                           const int32_t *cols, int64_t n_cols, F *out, hipStream_t st,
+                           int square = 0) {
     const int64_t n_iter = rows ? n_rows : n;
     const int64_t n_out = cols ? n_cols : m;
     if (n_iter == 0 || n_out == 0) return TM_OK;
@@ -582,13 +584,13 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
-                           n_iter, rpb, col_map, (int)n_out, ws, out);
+                           n_iter, rpb, col_map, (int)n_out, ws, out, square);
     prof_end(st);
         TM_LAUNCH_CHECK();
         return launch_reduce_partials<F>(ws, n_out, (int)nblk, 1, out, n_out, true, st);
     }
     hipLaunchKernelGGL((csr_rmatvec_kernel<F, G, false>), dim3((unsigned)nblk), dim3(256), 0, st,
-                       data, ind, ptr, v, rows, n_iter, rpb, col_map, (int)n_out, ws, out);
+                       data, ind, ptr, v, rows, n_iter, rpb, col_map, (int)n_out, ws, out, square);
     TM_LAUNCH_CHECK();
     return TM_OK;
 }
@@ -801,6 +803,19 @@ TM_CSR_MV_ENTRY(tm_csr_rmatvec_f32, float, run_csr_rmatvec)
 TM_CSR_MV_ENTRY(tm_csr_rmatvec_f64, double, run_csr_rmatvec)
 TM_CSR_MV_ENTRY(tm_sparse_sandwich_f32, float, run_sparse_sandwich)
 TM_CSR_MV_ENTRY(tm_sparse_sandwich_f64, double, run_sparse_sandwich)
+
+/* K7: out[j] += sum_i w[i] * X[i,j]^2 (ext/sparse.pyx:262-282) */
+int tm_csr_col_sq_f32(const float *csr_data, const int32_t *csr_indices, const int64_t *csr_indptr,
+                      int64_t n, int64_t m, const float *w, float *out, void *stream) {
+    return run_csr_rmatvec<float>(csr_data, csr_indices, csr_indptr, n, m, w, nullptr, 0, nullptr,
+                                  0, out, as_stream(stream), 1);
+}
+int tm_csr_col_sq_f64(const double *csr_data, const int32_t *csr_indices,
+                      const int64_t *csr_indptr, int64_t n, int64_t m, const double *w,
+                      double *out, void *stream) {
+    return run_csr_rmatvec<double>(csr_data, csr_indices, csr_indptr, n, m, w, nullptr, 0, nullptr,
+                                   0, out, as_stream(stream), 1);
+}
 
 int tm_csr_dense_sandwich_f32(const float *csr_data, const int32_t *csr_indices,
                               const int64_t *csr_indptr, int64_t n, int64_t m, const float *B,

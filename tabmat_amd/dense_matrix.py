@@ -158,13 +158,11 @@ class DenseMatrix(MatrixBase):
         return res if on_dev else D.to_host(res)
 
     def _get_col_stds(self, weights, col_means):
-        """sqrt(sum_i w_i (x_ij - mean_j)^2) (dense_matrix.py:180-187; the reference's
-        transpose_square_dot_weights, ext/dense.pyx:103-122).  Evaluated from device products:
-        sum w x^2 = diag(X' W X), sum w x = X' w."""
-        w = np.asarray(weights, dtype=self.dtype)
-        ex2 = np.diag(self.sandwich(w))
-        ex = self.transpose_matvec(w)
-        arg = ex2 - 2 * col_means * ex + col_means**2 * w.sum()
+        """sqrt(sum_i w_i (x_ij - mean_j)^2) (dense_matrix.py:180-187) with the K7 kernel
+        (transpose_square_dot_weights, ext/dense.pyx:103-122)."""
+        tdt = D.torch_dtype(self.dtype)
+        arg = D.to_host(xd.transpose_square_dot_weights(
+            self._dev(), D.to_dev(np.asarray(weights), tdt), D.to_dev(np.asarray(col_means), tdt)))
         arg[arg < 0] = 0
         return np.sqrt(arg)
 

@@ -42,3 +42,13 @@ def dense_matvec(X: DenseDev, v, rows, cols, out=None):
     call(f"tm_dense_matvec_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(v), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
+
+
+def transpose_square_dot_weights(X: DenseDev, weights, shift):
+    """ext/dense.pyx:103-122: out[j] = sum_i w[i] * (X[i, j] - shift[j])**2."""
+    out = D.zeros((X.m,), X.dtype)
+    if X.n == 0 or X.m == 0:
+        return out
+    call(f"tm_dense_col_sq_dev_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(weights),
+         D.p(shift), D.p(out), D.stream_ptr())
+    return out

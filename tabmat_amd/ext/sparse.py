@@ -82,3 +82,13 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(cp),
          A.n, A.m, D.p(d), D.p(out), D.stream_ptr())
     return out
+
+
+def transpose_square_dot_weights(A: CsrDev, weights):
+    """ext/sparse.pyx:262-282: out[j] = sum_i w[i] * A[i, j]**2."""
+    out = D.zeros((A.m,), A.dtype)
+    if A.n == 0 or A.m == 0 or A.data.numel() == 0:
+        return out
+    call(f"tm_csr_col_sq_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n, A.m,
+         D.p(weights), D.p(out), D.stream_ptr())
+    return out

@@ -294,8 +294,10 @@ class SparseMatrix(MatrixBase):
         return self._matvec_helper(vec, rows, cols, out, True)
 
     def _get_col_stds(self, weights, col_means):
-        """sparse_matrix.py:295-311 (ext/sparse.pyx:262-282): sum_i w_i x_ij^2 = diag(X' W X)."""
-        w = np.asarray(weights, dtype=self.dtype)
-        arg = np.diag(self.sandwich(w)) - col_means**2
+        """sparse_matrix.py:295-311 with the K7 kernel (ext/sparse.pyx:262-282)."""
+        tdt = D.torch_dtype(self.dtype)
+        ex2 = D.to_host(xs.transpose_square_dot_weights(self._dev(),
+                                                        D.to_dev(np.asarray(weights), tdt)))
+        arg = ex2 - np.asarray(col_means) ** 2
         arg[arg < 0] = 0
         return np.sqrt(arg)

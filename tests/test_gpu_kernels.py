@@ -388,3 +388,27 @@ def test_standardized_split():
     v = rng.random(p)
     np.testing.assert_allclose(std.matvec(v), S @ v, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(std.transpose_matvec(d), S.T @ d, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_column_second_moments_k7(order, dtype):
+    """transpose_square_dot_weights (ext/dense.pyx:103-122, ext/sparse.pyx:262-282) vs oracle."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(17)
+    n, k = 20_011, 37
+    X = rng.standard_normal((n, k)).astype(dtype)
+    X = np.asfortranarray(X) if order == "F" else X
+    S = sps.random(n, 90, density=0.05, format="csc", random_state=rng).astype(dtype)
+    w = rng.random(n).astype(dtype)
+    w /= w.sum()
+    orc = _orc()
+    dm, sm = tm.DenseMatrix(X), tm.SparseMatrix(S)
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    means = dm.transpose_matvec(w)
+    ref = np.sqrt(np.maximum(orc.dense_col_sq_dev(X, w, means.astype(dtype)), 0))
+    assert rel_err(dm._get_col_stds(w, means), ref) < tol
+    smeans = sm.transpose_matvec(w)
+    ref = np.sqrt(np.maximum(orc.csc_col_sq(S, w) - smeans.astype(np.float64) ** 2, 0))
+    assert rel_err(sm._get_col_stds(w, smeans), ref) < tol * 10
