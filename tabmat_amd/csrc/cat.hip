@@ -634,8 +634,10 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
             const int ec1 = ok1 ? ecol[e1] : 0;
             const int64_t k0 = s * slab_rows + (int64_t)(ko0 / rowb);
             const int64_t k1 = s * slab_rows + (int64_t)(ko1 / rowb);
-            const F x0 = d[k0] * v0;
-            const F x1 = ok1 ? d[k1] * v1 : F(0);
+            const F d0 = d[k0];
+            const F d1 = ok1 ? d[k1] : F(0);
+            const F x0 = d0 != F(0) ? d0 * v0 : F(0);   // rows masked out by d == 0 contribute
+            const F x1 = d1 != F(0) ? d1 * v1 : F(0);   // exactly nothing, whatever they hold
 #pragma unroll 1
             for (int c = 0; c < cs.n_cats; ++c) {
                 const int c0 = cs.codes[c][k0] - cs.drop[c];

@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 vec_t v;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    v[e] = (rok && j0 + c + e < nB) ? dsc[i] * stage[i][e] : F(0);
+                    v[e] = (rok && j0 + c + e < nB && dsc[i] != F(0)) ? dsc[i] * stage[i][e] : F(0);
                 *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = v;
             }
         } else {
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const bool cok = j0 + c < nB;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const bool ok = cok && (s * SLAB_R + row + e < n);
+                    const bool ok = cok && (s * SLAB_R + row + e < n) && dstage[i][e] != F(0);
                     *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) =
                         ok ? dstage[i][e] * stage[i][e] : F(0);
                 }

@@ -95,6 +95,14 @@ class SparseMatrix(MatrixBase):
             self._devblk = CsrDev.from_scipy(self.array_csr)
         return self._devblk
 
+    def _values_finite(self) -> bool:
+        """True when no stored value is inf / nan (checked once).  The gather kernel implements a
+        row restriction as d = 0 on the excluded rows, and inf * 0 would leak a NaN from an
+        excluded row; such blocks take the generic row-list kernel instead."""
+        if getattr(self, "_finite", None) is None:
+            self._finite = bool(torch.isfinite(self._dev().data).all().item())
+        return self._finite
+
     def _slab(self) -> SlabCsc:
         """Slab-blocked column-major twin used by the sparse x dense gather kernel (built on
         first use; the reference likewise materialises its CSR twin lazily)."""
@@ -210,7 +218,8 @@ class SparseMatrix(MatrixBase):
                     f"np.float32. This matrix is of type {self.dtype}, B is of type "
                     f"{other.dtype}.")
             Bd = other._dev()
-            if self.shape[0] > 0 and self._dev().data.numel() > 0:
+            if self.shape[0] > 0 and self._dev().data.numel() > 0 and (
+                    rows is None or self._values_finite()):
                 # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded
                 # rows contribute exactly 0), column restrictions select from the small result
                 if rows is not None:

@@ -412,3 +412,28 @@ def test_column_second_moments_k7(order, dtype):
     smeans = sm.transpose_matvec(w)
     ref = np.sqrt(np.maximum(orc.csc_col_sq(S, w) - smeans.astype(np.float64) ** 2, 0))
     assert rel_err(sm._get_col_stds(w, smeans), ref) < tol * 10
+
+
+def test_row_restriction_ignores_non_finite_excluded_rows():
+    """The fast paths implement `rows` as a masked d.  Rows that are NOT selected must not
+    contribute even if they hold inf / nan (the reference never reads them)."""
+    specs, idx = cs.mixed_specs(6000, 8, 40, (7, 5), seed=11)
+    X = specs[0][1].copy()
+    S = specs[1][1].copy().tolil()
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(6000, 4000, replace=False)).astype(np.int32)
+    excluded = np.setdiff1d(np.arange(6000), rows)
+    X[excluded[:50], 2] = np.inf
+    X[excluded[50:100], 5] = np.nan
+    S[int(excluded[7]), 3] = np.inf
+    specs = [("dense", X), ("sparse", sps.csc_matrix(S))] + list(specs[2:])
+    mat = to_tm_split(specs, idx)
+    d = rng.random(6000)
+    res = mat.sandwich(d, rows=rows)
+    assert np.isfinite(res).all()
+    Xc, Sc = X.copy(), sps.lil_matrix(S)
+    Xc[excluded] = 0.0
+    Sc[int(excluded[7]), 3] = 0.0
+    clean = [("dense", Xc), ("sparse", sps.csc_matrix(Sc))] + list(specs[2:])
+    ref = _orc().split_sandwich([cs.to_oracle_block(s) for s in clean], idx, d, rows)
+    assert rel_err(res, ref) < F64_TOL
