@@ -866,9 +866,10 @@ constexpr int GATHER_CPW = 32;                      // sparse columns (static ac
 constexpr int GATHER_NW = 16;                       // waves per workgroup -> 512 sparse columns
 constexpr int GATHER_THREADS = GATHER_NW * 64;
 
-// Stream entries are broadcast to the 64 lanes through a small per-wave LDS ring (two halves
-// of 64 entries): a uniform-address ds_read_b128 delivers {value, row offset} to every lane
-// (v_readlane costs ~9 cycles each on this kernel's critical path, 3 per nonzero).
+// Stream entries are broadcast to the 64 lanes through a small per-wave LDS ring of 64 entries:
+// a uniform-address ds_read_b128 delivers {value, row offset} to every lane (v_readlane costs
+// ~9 cycles each on this kernel's critical path, 3 per nonzero).  The ring is rewritten in place
+// when its 64 entries are consumed (LDS operations of one wave execute in order).
 template <typename F>
 struct __attribute__((aligned(16))) GEntry {
     F a;
@@ -880,13 +881,33 @@ struct __attribute__((aligned(16))) GEntry {
     const GEntry<F> E = ring[(LIDX)];                                                     \
     const F X = *reinterpret_cast<const F *>(slab + E.ko + lane_off);
 
-template <typename F, int C>
+// SCALE: the dense slab in LDS holds B unscaled (async global->LDS copy); d is folded into the
+// stream value when an entry enters the ring, and entries of rows with d == 0 are redirected to
+// an all-zero LDS row so that excluded rows contribute exactly nothing.
+template <typename F, bool SCALE>
+__device__ __forceinline__ GEntry<F> make_entry(F a, unsigned ko, const F *__restrict__ dl,
+                                                unsigned zero_off) {
+    GEntry<F> e;
+    e.pad = 0;
+    if (SCALE) {
+        const F dk = dl[ko / (64u * (unsigned)sizeof(F))];
+        e.a = a * dk;
+        e.ko = dk != F(0) ? ko : zero_off;
+    } else {
+        e.a = a;
+        e.ko = ko;
+    }
+    return e;
+}
+
+template <typename F, bool SCALE, int C>
 struct ColLoop {
     // processes static column C of the wave's group, then recurses to C + 1
     static __device__ __forceinline__ void run(F (&acc)[GATHER_CPW],
                                                const unsigned char *__restrict__ slab,
-                                               GEntry<F> *__restrict__ ring0, int &half, int cntv,
-                                               int &pos, F &na, unsigned &nk,
+                                               GEntry<F> *__restrict__ ring,
+                                               const F *__restrict__ dl, unsigned zero_off,
+                                               int cntv, int &pos, F &na, unsigned &nk,
                                                const F *__restrict__ vals,
                                                const unsigned *__restrict__ koff, int64_t base,
                                                int total, int lane, int lane_off) {
@@ -895,9 +916,9 @@ struct ColLoop {
             // stay inside the current 64-entry chunk: no rotation test in the hot loop
             const int l0 = pos & 63;
             const int m = min(nc, 64 - l0);
-            const GEntry<F> *ring = ring0 + half * 64 + l0;
-            int t = 0;
-            for (; t + 4 <= m; t += 4) {   // 4 independent LDS reads in flight
+            int t = l0;
+            const int tend = l0 + m;
+            for (; t + 4 <= tend; t += 4) {   // 4 independent LDS reads in flight
                 TM_GATHER_STEP(e0, x0, t)
                 TM_GATHER_STEP(e1, x1, t + 1)
                 TM_GATHER_STEP(e2, x2, t + 2)
@@ -907,21 +928,16 @@ struct ColLoop {
                 acc[C] = fma(e2.a, x2, acc[C]);
                 acc[C] = fma(e3.a, x3, acc[C]);
             }
-            for (; t < m; ++t) {
+            for (; t < tend; ++t) {
                 TM_GATHER_STEP(e0, x0, t)
                 acc[C] = fma(e0.a, x0, acc[C]);
             }
             pos += m;
             nc -= m;
             if ((pos & 63) == 0) {
-                // chunk exhausted: publish the prefetched chunk in the other ring half and
-                // issue the next prefetch
-                half ^= 1;
-                GEntry<F> e;
-                e.a = na;
-                e.ko = nk;
-                e.pad = 0;
-                ring0[half * 64 + lane] = e;
+                // chunk exhausted: the prefetched chunk replaces it, next prefetch is issued
+                __builtin_amdgcn_wave_barrier();
+                ring[lane] = make_entry<F, SCALE>(na, nk, dl, zero_off);
                 __builtin_amdgcn_wave_barrier();
                 const int nxt = pos + 64 + lane;
                 if (nxt < total) {
@@ -931,9 +947,19 @@ struct ColLoop {
             }
         }
         if constexpr (C + 1 < GATHER_CPW)
-            ColLoop<F, C + 1>::run(acc, slab, ring0, half, cntv, pos, na, nk, vals, koff, base,
-                                   total, lane, lane_off);
+            ColLoop<F, SCALE, C + 1>::run(acc, slab, ring, dl, zero_off, cntv, pos, na, nk, vals,
+                                          koff, base, total, lane, lane_off);
     }
+};
+
+template <typename F>
+struct GatherLds {
+    static constexpr int ROWB = 64 * (int)sizeof(F);             // bytes per LDS slab row
+    static constexpr int SLABB = SLAB_R * ROWB;                  // bytes per slab buffer
+    static constexpr int ZERO_OFF = 2 * SLABB;                   // all-zero row
+    static constexpr int DL_OFF = ZERO_OFF + ROWB;               // d of the slab rows, 2 buffers
+    static constexpr int RING_OFF = DL_OFF + 2 * SLAB_R * (int)sizeof(F);
+    static constexpr int TOTAL = RING_OFF + GATHER_NW * 64 * (int)sizeof(GEntry<F>);
 };
 
 template <typename F, bool ORDER_F, bool VEC_OK>
@@ -943,11 +969,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
     int nB, const F *__restrict__ d, F *__restrict__ ws, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using L = GatherLds<F>;
+    constexpr bool ASYNC = !ORDER_F && VEC_OK;   // global_load_lds staging, d folded into the stream
     constexpr int VEC = 16 / (int)sizeof(F);
-    constexpr int ROWB = 64 * (int)sizeof(F);            // bytes per LDS slab row
-    constexpr int SLABB = SLAB_R * ROWB;                 // bytes per LDS buffer
+    constexpr int ROWB = L::ROWB;
+    constexpr int SLABB = L::SLABB;
     constexpr int NV = SLAB_R * 64 / VEC / GATHER_THREADS;  // 16-byte vectors staged per thread
-    static_assert(NV >= 1, "staging needs at least one vector per thread");
+    static_assert(NV >= 1 && (64 / VEC) % NV == 0, "staging: NV vectors of one row per thread");
     typedef F vec_t __attribute__((ext_vector_type(VEC)));
 
     const int tid = threadIdx.x;
@@ -959,37 +987,50 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
     const int lane_off = lane * (int)sizeof(F);
+    F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
+    GEntry<F> *ring = reinterpret_cast<GEntry<F> *>(smem_raw + L::RING_OFF) + wave * 64;
 
     F acc[GATHER_CPW];
 #pragma unroll
     for (int c = 0; c < GATHER_CPW; ++c) acc[c] = F(0);
+    for (int i = tid; i < ROWB / (int)sizeof(F); i += GATHER_THREADS)
+        reinterpret_cast<F *>(smem_raw + L::ZERO_OFF)[i] = F(0);
 
-    vec_t stage[NV];
+    // ---------------- staging of the dense slab ----------------
+    vec_t stage[ASYNC ? 1 : NV];
     vec_t dstage[ORDER_F ? NV : 1];
-    F dsc[ORDER_F ? 1 : NV];
-    // C-ordered B: thread -> (row, 16-byte vector of columns).  F-ordered B (what the
-    // reference's from_csc / from_df produce, constructor_util.py:39-43): thread -> (column,
-    // VEC consecutive rows), coalesced down the column; transposed on the way into LDS.
-    // load_slab ONLY ISSUES loads (branch-free: out-of-range lanes read a clamped in-range
-    // address and are zeroed later), so all of them are in flight together while the previous
-    // slab is processed; the scaling by d happens in store_slab.
-    auto load_slab = [&](int64_t s) {
-        if (!ORDER_F) {
-            constexpr int VPR = 64 / VEC;  // vectors per slab row
+    F dsc = F(0);
+    // ASYNC: every wave copies NV KiB-sized pieces (64 lanes x 16 B) of the slab straight into
+    // LDS with global_load_lds (no VGPRs, no ds_write pass); d of the slab rows goes to LDS (dl).
+    // Otherwise (F-ordered or unaligned B): loads into registers, scaled by d when written to LDS.
+    auto issue_slab = [&](int64_t s, int buf) {
+        if (ASYNC) {
+            constexpr int RPP = 1024 / ROWB;             // slab rows per 1 KiB piece
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int q = tid + i * GATHER_THREADS;
-                const int row = q / VPR;
-                const int c = (q % VPR) * VEC;
+                const int piece = wave * NV + i;
+                const int row = piece * RPP + (lane * 16) / ROWB;
+                const int c = ((lane * 16) % ROWB) / (int)sizeof(F);
                 const int64_t k = min(s * SLAB_R + row, n - 1);
-                dsc[i] = d[k];
-                if (VEC_OK) {
-                    const int cc = min(j0 + c, nB - VEC);
-                    stage[i] = *reinterpret_cast<const vec_t *>(B + k * r + cc);
-                } else {
+                const int cc = min(j0 + c, nB - VEC);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(B + k * r + cc),
+                    (__attribute__((address_space(3))) void *)(smem_raw + buf * SLABB + piece * 1024),
+                    16, 0, 0);
+            }
+            if (tid < SLAB_R) dsc = d[min(s * SLAB_R + tid, n - 1)];
+        } else if (!ORDER_F) {
+            constexpr int VPR = 64 / VEC;        // vectors per slab row
+            constexpr int TPR = VPR / NV;        // threads per slab row (NV consecutive vectors each)
+            const int row = tid / TPR;
+            const int c0 = (tid % TPR) * NV * VEC;
+            const int64_t k = min(s * SLAB_R + row, n - 1);
+            dsc = d[k];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) stage[i][e] = B[k * r + min(j0 + c + e, nB - 1)];
-                }
+            for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    stage[ASYNC ? 0 : i][e] = B[k * r + min(j0 + c0 + i * VEC + e, nB - 1)];
             }
         } else {
             constexpr int RPC = SLAB_R / VEC;  // row-vectors per column
@@ -1001,33 +1042,36 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const int64_t k = s * SLAB_R + row;
                 if (VEC_OK) {
                     const int64_t kk = min(k, n - VEC);
-                    stage[i] = *reinterpret_cast<const vec_t *>(B + (int64_t)c * n + kk);
-                    dstage[i] = *reinterpret_cast<const vec_t *>(d + kk);
+                    stage[ASYNC ? 0 : i] = *reinterpret_cast<const vec_t *>(B + (int64_t)c * n + kk);
+                    dstage[ORDER_F ? i : 0] = *reinterpret_cast<const vec_t *>(d + kk);
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const int64_t kk = min(k + e, n - 1);
-                        stage[i][e] = B[(int64_t)c * n + kk];
-                        dstage[i][e] = d[kk];
+                        stage[ASYNC ? 0 : i][e] = B[(int64_t)c * n + kk];
+                        dstage[ORDER_F ? i : 0][e] = d[kk];
                     }
                 }
             }
         }
     };
-    auto store_slab = [&](int64_t s, int buf) {
+    auto finish_slab = [&](int64_t s, int buf) {
         unsigned char *dst = smem_raw + buf * SLABB;
-        if (!ORDER_F) {
+        if (ASYNC) {
+            if (tid < SLAB_R) dl_all[buf * SLAB_R + tid] = (s * SLAB_R + tid < n) ? dsc : F(0);
+        } else if (!ORDER_F) {
             constexpr int VPR = 64 / VEC;
+            constexpr int TPR = VPR / NV;
+            const int row = tid / TPR;
+            const int c0 = (tid % TPR) * NV * VEC;
+            const bool rok = (s * SLAB_R + row < n) && dsc != F(0);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int q = tid + i * GATHER_THREADS;
-                const int row = q / VPR;
-                const int c = (q % VPR) * VEC;
-                const bool rok = s * SLAB_R + row < n;
+                const int c = c0 + i * VEC;
                 vec_t v;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e)
-                    v[e] = (rok && j0 + c + e < nB && dsc[i] != F(0)) ? dsc[i] * stage[i][e] : F(0);
+                    v[e] = (rok && j0 + c + e < nB) ? dsc * stage[ASYNC ? 0 : i][e] : F(0);
                 *reinterpret_cast<vec_t *>(dst + row * ROWB + c * (int)sizeof(F)) = v;
             }
         } else {
@@ -1040,9 +1084,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const bool cok = j0 + c < nB;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const bool ok = cok && (s * SLAB_R + row + e < n) && dstage[i][e] != F(0);
+                    const F dv = dstage[ORDER_F ? i : 0][e];
+                    const bool ok = cok && (s * SLAB_R + row + e < n) && dv != F(0);
                     *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) =
-                        ok ? dstage[i][e] * stage[i][e] : F(0);
+                        ok ? dv * stage[ASYNC ? 0 : i][e] : F(0);
                 }
             }
         }
@@ -1052,8 +1097,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     // another load issued in the same iteration (each would cost a full HBM round trip):
     //   iteration s issues   meta(s + 2)  = run lengths + stream base/total      (stage M)
     //                        head(s + 1)  = first two 64-entry chunks, from meta(s + 1) (stage H)
-    //                        slab(s + 1)  = dB rows into registers                (stage S)
-    //   then computes slab s out of LDS, writes slab(s + 1) to the other LDS buffer, barrier.
+    //                        slab(s + 1)  = dense rows of the next slab           (stage S)
+    //   then computes slab s out of LDS, completes slab(s + 1) in the other LDS buffer, barrier.
     int m_cnt = 0, m_total = 0;          // meta of slab s + 2 (after stage M)
     int64_t m_base = 0;
     int h_cnt = 0, h_total = 0;          // head of slab s + 1 (after stage H)
@@ -1084,8 +1129,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         load_meta(s0);
         load_head();                      // head(s0)
         load_meta(s0 + 1);                // meta(s0 + 1)
-        load_slab(s0);
-        store_slab(s0, 0);
+        issue_slab(s0, 0);
+        finish_slab(s0, 0);
     }
     __syncthreads();
     for (int64_t s = s0; s < s1; ++s) {
@@ -1097,22 +1142,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         unsigned vk = h_vk, nk = h_nk;
         if (s + 1 < s1) {
             load_head();                  // head(s + 1) from meta(s + 1), loaded last iteration
-            if (!(dbg & 2)) load_slab(s + 1);
+            if (!(dbg & 2)) issue_slab(s + 1, buf ^ 1);
         }
         load_meta(s + 2);
         if (active && total > 0 && !(dbg & 1)) {
-            int pos = 0, half = 0;
-            GEntry<F> *ring0 = reinterpret_cast<GEntry<F> *>(smem_raw + 2 * SLABB) + wave * 128;
-            GEntry<F> e;
-            e.a = va;
-            e.ko = vk;
-            e.pad = 0;
-            ring0[lane] = e;
+            int pos = 0;
+            const F *dl = dl_all + buf * SLAB_R;
+            const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
+            ring[lane] = make_entry<F, ASYNC>(va, vk, dl, zero_off);
             __builtin_amdgcn_wave_barrier();
-            ColLoop<F, 0>::run(acc, smem_raw + buf * SLABB, ring0, half, cntv, pos, na, nk, vals,
-                               koff, base, total, lane, lane_off);
+            ColLoop<F, ASYNC, 0>::run(acc, smem_raw + buf * SLABB, ring, dl, zero_off, cntv, pos, na,
+                                      nk, vals, koff, base, total, lane, lane_off);
         }
-        if (s + 1 < s1 && !(dbg & 4)) store_slab(s + 1, buf ^ 1);
+        if (s + 1 < s1 && !(dbg & 4)) finish_slab(s + 1, buf ^ 1);
         __syncthreads();
     }
     if (active) {
@@ -1162,7 +1204,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    const size_t lds = 2 * (size_t)SLAB_R * 64 * sizeof(F) + (size_t)GATHER_NW * 128 * sizeof(GEntry<F>);
+    const size_t lds = (size_t)GatherLds<F>::TOTAL;
     // 16-byte vector loads need aligned bases and row/column strides that keep every vector
     // 16-byte aligned and entirely inside the matrix
     constexpr int VEC = 16 / (int)sizeof(F);
