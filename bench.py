@@ -294,7 +294,15 @@ def main():
             roof = {"bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        roof["traffic"] = None  # PMC passes: see profiles/ (FETCH_SIZE x2 correction, gfx950)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (a profiler cannot be
+        # attached from inside this process); null when no measurement exists for this kernel
+        roof["traffic"] = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if n_local == 10_000_000:
+                roof["traffic"] = tr.get(args.workload, {}).get(dom)
+        except Exception:
+            pass
         roof["kernel"] = dom
         roof["kernel_ms"] = round(dom_ms, 4)
         roof["algorithmic_bytes_per_launch"] = int(dom_bytes)

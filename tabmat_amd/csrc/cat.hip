@@ -70,7 +70,28 @@ __global__ __launch_bounds__(1024) void hist_lds_kernel(
 
     const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n_iter);
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+    int64_t tbeg = t0;
+    if (!TWO && rows == nullptr && (t0 & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(ci) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        // streaming fast path (BASELINE configs[2]): 4 consecutive rows per thread and step,
+        // one 16-byte load of codes + 4 weights in flight per lane
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        const int64_t nvec = (t1 - t0) / 4;
+        for (int64_t q = threadIdx.x; q < nvec; q += blockDim.x) {
+            const int64_t k = t0 + q * 4;
+            const i4 cc = *reinterpret_cast<const i4 *>(ci + k);
+            F ww[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ww[e] = w[k + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = cc[e] - drop_i;
+                if (c >= i0 && c < i1 && !(col_map && col_map[c] < 0)) atomic_add(&bins[c - i0], ww[e]);
+            }
+        }
+        tbeg = t0 + nvec * 4;
+    }
+    for (int64_t t = tbeg + threadIdx.x; t < t1; t += blockDim.x) {
         const int64_t k = rows ? (int64_t)rows[t] : t;
         const int c = ci[k] - drop_i;
         if (c < i0 || c >= i1) continue;
@@ -145,7 +166,7 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     const int blocks_per_cu = lds > 64 * 1024 ? 1 : 2;
     int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / n_parts);
     nblk = std::min<int64_t>(nblk, ceil_div(n_iter, threads * 4));
-    const int64_t rows_per_block = ceil_div(n_iter, nblk);
+    const int64_t rows_per_block = ceil_div(ceil_div(n_iter, nblk), 4) * 4;   // keeps t0 % 4 == 0
     nblk = ceil_div(n_iter, rows_per_block);
     void *wsv = nullptr;
     int rc = get_workspace(sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);

@@ -121,19 +121,46 @@ __device__ __forceinline__ void syrk_wave_main(
     const F *__restrict__ lbuf, const F *__restrict__ dbuf,
     typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], int lane) {
     using C = SyrkCfg<F, NBLK, RECT>;
-#pragma unroll 2
-    for (int g = 0; g < C::RS / 4; ++g) {
-        const int rl = 4 * g + (lane >> 4);
-        const F dv = dbuf[rl];
-        const F *lrow = lbuf + rl * C::LDW + (lane & 15);
-        F xa[NBLK], xb[NBLK];
+    constexpr int NG = C::RS / 4;
+    // Wide panels (NBLK = 16) already run one wave per SIMD (accumulators fill the register
+    // file): software-pipeline inside the wave -- the fragments of row group g + 1 are read from
+    // LDS before the MFMAs of group g issue, so LDS latency hides behind the matrix pipe.
+    // Narrower panels keep two waves per SIMD instead (the extra fragment set would cost that).
+    constexpr bool PIPE = NBLK >= 16;
+    if constexpr (PIPE) {
+        F xa[2][NBLK], xb[2][NBLK];
+        auto load_frag = [&](int g, int slot) {
+            const int rl = 4 * g + (lane >> 4);
+            const F dv = dbuf[rl];
+            const F *lrow = lbuf + rl * C::LDW + (lane & 15);
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            xb[b] = lrow[16 * b];
-            xa[b] = dv * xb[b];
+            for (int b = 0; b < NBLK; ++b) {
+                xb[slot][b] = lrow[16 * b];
+                xa[slot][b] = dv * xb[slot][b];
+            }
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_frag(g + 1, (g + 1) & 1);
+            syrk_wave_step<F, NBLK, RECT, WID>(xa[g & 1], xb[g & 1], acc,
+                                               std::make_integer_sequence<int, C::MAXT>{});
         }
-        syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc,
-                                           std::make_integer_sequence<int, C::MAXT>{});
+    } else {
+#pragma unroll 2
+        for (int g = 0; g < NG; ++g) {
+            const int rl = 4 * g + (lane >> 4);
+            const F dv = dbuf[rl];
+            const F *lrow = lbuf + rl * C::LDW + (lane & 15);
+            F xa[NBLK], xb[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                xb[b] = lrow[16 * b];
+                xa[b] = dv * xb[b];
+            }
+            syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc,
+                                               std::make_integer_sequence<int, C::MAXT>{});
+        }
     }
 }
 
