@@ -517,6 +517,92 @@ __global__ __launch_bounds__(256) void dense_matvec_c_kernel(
     }
 }
 
+// C-order fast path (all rows, all columns, 16-byte aligned rows): a wave streams MV_R rows per
+// step with one 16-byte load per lane and row segment, so MV_R KiB-sized loads are in flight per
+// wave; the MV_R row sums are then reduced across the lanes with a halving butterfly (the number
+// of live values halves with every exchange: 7 + 3 shuffles for 8 rows instead of 6 per row).
+// LPR = lanes per row (m / VEC when that is a power of two <= 64; 64 with NL loads per row else).
+constexpr int MV_R = 8;
+
+template <typename F, int LPR, int NL>
+__global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__restrict__ X,
+                                                                   int64_t n, int64_t m,
+                                                                   const F *__restrict__ v,
+                                                                   F *__restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(F);
+    constexpr int RPL = 64 / LPR;                      // rows covered by one wave-wide load
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / LPR;                        // row within a load
+    const int sl = lane % LPR;
+    vec_t vv[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) vv[q] = *reinterpret_cast<const vec_t *>(v + ((int64_t)q * 64 + sl) * VEC);
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int ROWS = MV_R * RPL;                   // rows per wave step
+    const int64_t nstep = (n + ROWS - 1) / ROWS;
+    for (int64_t t = wave0; t < nstep; t += nw) {
+        const int64_t r0 = t * ROWS;
+        F acc[MV_R];
+        vec_t x[MV_R][NL];
+#pragma unroll
+        for (int r = 0; r < MV_R; ++r) {
+            const int64_t row = min(r0 + r * RPL + seg, n - 1);
+#pragma unroll
+            for (int q = 0; q < NL; ++q)
+                x[r][q] = *reinterpret_cast<const vec_t *>(X + row * m + ((int64_t)q * 64 + sl) * VEC);
+        }
+#pragma unroll
+        for (int r = 0; r < MV_R; ++r) {
+            F a = F(0);
+#pragma unroll
+            for (int q = 0; q < NL; ++q)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a = fma(x[r][q][e], vv[q][e], a);
+            acc[r] = a;
+        }
+        // halving butterfly inside each LPR-lane segment: after the step with mask s the lanes
+        // with bit s set own the upper half of the remaining row values
+        int sel = 0;
+        int live = MV_R;
+#pragma unroll
+        for (int s = LPR / 2; s >= 1; s >>= 1) {
+            if (live > 1) {
+                const int half = live / 2;
+                const bool up = (lane & s) != 0;
+#pragma unroll
+                for (int i = 0; i < MV_R / 2; ++i) {
+                    if (i < half) {
+                        const F keep = up ? acc[i + half] : acc[i];
+                        const F send = up ? acc[i] : acc[i + half];
+                        acc[i] = keep + __shfl_xor(send, s, 64);
+                    }
+                }
+                sel += up ? half : 0;
+                live = half;
+            } else {
+                acc[0] += __shfl_xor(acc[0], s, 64);
+            }
+        }
+        if (live == 1) {
+            // one value per lane group: the lane whose low bits are zero writes row `sel`
+            constexpr int GRP = (LPR >= MV_R) ? LPR / MV_R : 1;
+            const int64_t row = r0 + (int64_t)sel * RPL + seg;
+            if ((sl % GRP) == 0 && row < n) out[row] += acc[0];
+        } else {
+            // LPR < MV_R: `live` values remain per lane after the segment is exhausted
+#pragma unroll
+            for (int i = 0; i < MV_R; ++i) {
+                if (i < live) {
+                    const int64_t row = r0 + (int64_t)(sel + i) * RPL + seg;
+                    if (row < n) out[row] += acc[i];
+                }
+            }
+        }
+    }
+}
+
 // F-order matvec: one thread per output row.
 template <typename F>
 __global__ __launch_bounds__(256) void dense_matvec_f_kernel(
@@ -665,6 +751,27 @@ static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const
                            v, rows, n_iter, cols, (int)n_cols, out);
     prof_end(st);
     } else {
+        constexpr int VEC = 16 / (int)sizeof(F);
+        const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+        const int64_t lpr = m / VEC;
+        if (!rows && !cols && aligned && m % VEC == 0 &&
+            (lpr == 64 || lpr == 128 || lpr == 32 || lpr == 16 || lpr == 8)) {
+            const int64_t rows_per_step = MV_R * (lpr >= 64 ? 1 : 64 / lpr);
+            const int64_t nblk = std::min<int64_t>(ceil_div(ceil_div(n, rows_per_step), 4), NUM_CU * 8);
+            prof_begin(st);
+#define TM_MV_LAUNCH(LPR_, NL_)                                                               \
+    hipLaunchKernelGGL((dense_matvec_c_stream_kernel<F, LPR_, NL_>), dim3((unsigned)nblk),     \
+                       dim3(256), 0, st, X, n, m, v, out)
+            if (lpr == 128) TM_MV_LAUNCH(64, 2);
+            else if (lpr == 64) TM_MV_LAUNCH(64, 1);
+            else if (lpr == 32) TM_MV_LAUNCH(32, 1);
+            else if (lpr == 16) TM_MV_LAUNCH(16, 1);
+            else TM_MV_LAUNCH(8, 1);
+#undef TM_MV_LAUNCH
+            prof_end(st);
+            TM_LAUNCH_CHECK();
+            return TM_OK;
+        }
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 4), NUM_CU * 8);
         prof_begin(st);
     hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,

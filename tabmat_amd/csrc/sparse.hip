@@ -18,6 +18,8 @@ namespace tmh {
 
 constexpr size_t SP_LDS_MAX = 128 * 1024;
 
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 // ---------------------------------------------------------------------------------------
 // K6a  out[Ci] += sum_j X[rows[Ci], j] v[j]   -- G lanes per row
 // ---------------------------------------------------------------------------------------
@@ -82,6 +84,96 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
         F *dst = ws + (int64_t)blockIdx.x * n_out;
         for (int b = threadIdx.x; b < n_out; b += blockDim.x) dst[b] = bins[b];
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// K6 fast paths (all rows, all columns): the CSR arrays are STREAMED with coalesced loads --
+// lane <-> nonzero, independent of the row structure -- instead of being walked row by row.
+// A wave owns CSR_RPW consecutive rows; their nonzeros [p0, p1) pass through a per-wave LDS
+// buffer in chunks of CSR_CAP entries:
+//   matvec :  stage  prod[e] = data[e] * v[ind[e]]  (v gathered from an LDS copy), then lane <->
+//             row sums its own segment of the buffer and adds it to out[row];
+//   rmatvec:  lane <-> row first fills  vrow[e] = v[row]  over its segment, then lane <-> nonzero
+//             adds  data[e] * vrow[e]  to the workgroup's LDS bins[ind[e]]  (ds_add), partials
+//             are combined by reduce_partials_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int CSR_RPW = 64;          // rows per wave
+constexpr int CSR_CAP = 1024;        // staged entries per wave and chunk
+constexpr int CSR_WAVES = 4;
+
+template <typename F>
+__global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ v, int64_t n, int m, F *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *vl = reinterpret_cast<F *>(smem_raw);                       // [m]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    F *prod = vl + m + wave * CSR_CAP;                             // [CSR_CAP] per wave
+    for (int j = threadIdx.x; j < m; j += blockDim.x) vl[j] = v[j];
+    __syncthreads();
+    const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
+    for (int64_t c = (int64_t)blockIdx.x * CSR_WAVES + wave; c < nchunk;
+         c += (int64_t)gridDim.x * CSR_WAVES) {
+        const int64_t row = c * CSR_RPW + lane;
+        const int64_t rlo = ptr[min(row, n)];
+        const int64_t rhi = ptr[min(row + 1, n)];
+        const int64_t p0 = __shfl(rlo, 0, 64);
+        const int64_t p1 = ptr[min(c * CSR_RPW + CSR_RPW, n)];
+        F acc = F(0);
+        for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
+            const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
+#pragma unroll 4
+            for (int e = lane; e < cnt; e += 64) prod[e] = data[c0 + e] * vl[ind[c0 + e]];
+            __builtin_amdgcn_wave_barrier();
+            const int lo = (int)(max(rlo, c0) - c0);
+            const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
+            for (int e = lo; e < hi; ++e) acc += prod[e];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (row < n) out[row] += acc;
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_block, F *__restrict__ ws,
+    int square) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *bins = reinterpret_cast<F *>(smem_raw);                     // [m]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    F *vrow = bins + m + wave * CSR_CAP;                           // [CSR_CAP] per wave
+    for (int j = threadIdx.x; j < m; j += blockDim.x) bins[j] = F(0);
+    __syncthreads();
+    const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
+    const int64_t cb0 = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t cb1 = min(cb0 + chunks_per_block, nchunk);
+    for (int64_t c = cb0 + wave; c < cb1; c += CSR_WAVES) {
+        const int64_t row = c * CSR_RPW + lane;
+        const int64_t rlo = ptr[min(row, n)];
+        const int64_t rhi = ptr[min(row + 1, n)];
+        const F vr = row < n ? v[row] : F(0);
+        const int64_t p0 = __shfl(rlo, 0, 64);
+        const int64_t p1 = ptr[min(c * CSR_RPW + CSR_RPW, n)];
+        for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
+            const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
+            const int lo = (int)(max(rlo, c0) - c0);
+            const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
+            for (int e = lo; e < hi; ++e) vrow[e] = vr;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int e = lane; e < cnt; e += 64) {
+                const F x = data[c0 + e];
+                atomic_add(&bins[ind[c0 + e]], (square ? x * x : x) * vrow[e]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    F *dst = ws + (int64_t)blockIdx.x * m;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) dst[j] = bins[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -532,6 +624,21 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     const int64_t n_iter = rows ? n_rows : n;
     if (n_iter == 0 || m == 0) return TM_OK;
     if (cols && n_cols == 0) return TM_OK;
+    if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
+        const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
+        auto kern = &csr_matvec_stream_kernel<F>;
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t nchunk = ceil_div(n, CSR_RPW);
+        const int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
+        prof_begin(st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind, ptr,
+                           v, n, (int)m, out);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
     int32_t *col_map = nullptr;
     if (cols) {
         void *wsv = nullptr;
@@ -559,6 +666,27 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     const int64_t n_iter = rows ? n_rows : n;
     const int64_t n_out = cols ? n_cols : m;
     if (n_iter == 0 || n_out == 0) return TM_OK;
+    if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
+        const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
+        auto kern = &csr_rmatvec_stream_kernel<F>;
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t nchunk = ceil_div(n, CSR_RPW);
+        int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
+        const int64_t cpb = ceil_div(nchunk, nblk);
+        nblk = ceil_div(nchunk, cpb);
+        void *wsv = nullptr;
+        int rc = get_workspace(sizeof(F) * (size_t)(nblk * m) + 256, &wsv);
+        if (rc) return rc;
+        F *ws = reinterpret_cast<F *>(wsv);
+        prof_begin(st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind, ptr,
+                           v, n, (int)m, cpb, ws, square);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+        return launch_reduce_partials<F>(ws, m, (int)nblk, 1, out, m, true, st);
+    }
     const size_t map_bytes = cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
     const bool use_lds = sizeof(F) * (size_t)n_out <= SP_LDS_MAX;
     int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 2048)), NUM_CU * 2);

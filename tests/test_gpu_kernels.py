@@ -100,6 +100,28 @@ def test_dense_matvec_rmatvec(order, dtype):
     assert rel_err(mat.transpose_matvec(w, rows, cols), orc.dense_rmatvec(X, w, rows, cols)) < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k", [16, 32, 64, 128, 256, 512])
+def test_dense_matvec_stream_path(dtype, k):
+    """Unrestricted C-order matvec takes the 16-byte streaming kernel when a row is 8..128
+    16-byte vectors long (dense.hip dense_matvec_c_stream_kernel); every lanes-per-row
+    instantiation, row counts that do not fill the last wave step, and accumulation into out."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(100 + k)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    for n in (1, 7, 63, 1000, 4099):
+        X = rng.standard_normal((n, k)).astype(dtype)
+        v = rng.standard_normal(k).astype(dtype)
+        mat = tm.DenseMatrix(X)
+        ref = X.astype(np.float64) @ v.astype(np.float64)
+        assert rel_err(mat.matvec(v), ref) < tol
+        assert rel_err(mat.matvec(v), _orc().dense_matvec(X, v, None, None)) < tol
+        out = np.full(n, 2.5, dtype=dtype)
+        res = mat.matvec(v, out=out)
+        assert res is out and rel_err(out, ref + 2.5) < tol
+
+
 # ------------------------------------------------------------------ K2 sparse sandwich
 @pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("n,m,dens", [(200, 50, 0.05), (5000, 130, 0.05), (20000, 512, 0.05),
@@ -183,6 +205,32 @@ def test_sparse_matvec_rmatvec(dtype):
                    S64[rows][:, cols].T @ w[rows].astype(np.float64)) < tol
     orc = _orc()
     assert rel_err(mat.transpose_matvec(w, rows, cols), orc.csc_rmatvec(S, w, rows, cols)) < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,dens", [(1, 5, 1.0), (63, 40, 0.3), (64, 40, 0.3), (65, 40, 0.3),
+                                      (300, 3000, 0.5), (20011, 512, 0.05), (5000, 64, 0.0)])
+def test_sparse_matvec_stream_path(dtype, n, m, dens):
+    """Unrestricted CSR matvec / transpose_matvec take the streaming kernels (sparse.hip K6 fast
+    paths): row counts around the 64-row wave chunk, rows longer than the 1024-entry staging
+    buffer (300 x 3000 at 50 %), an empty matrix, accumulation into out."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n * 7 + m)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng).astype(dtype)
+    mat = tm.SparseMatrix(S)
+    v, w = rng.standard_normal(m).astype(dtype), rng.standard_normal(n).astype(dtype)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    S64 = S.astype(np.float64)
+    ref_mv, ref_tmv = S64 @ v.astype(np.float64), S64.T @ w.astype(np.float64)
+    scale_mv, scale_tmv = max(1.0, np.abs(ref_mv).max()), max(1.0, np.abs(ref_tmv).max())
+    assert np.abs(mat.matvec(v) - ref_mv).max() / scale_mv < tol
+    assert np.abs(mat.transpose_matvec(w) - ref_tmv).max() / scale_tmv < tol
+    orc = _orc()
+    assert np.abs(mat.matvec(v) - orc.csr_matvec_unrestricted(S.tocsr(), v)).max() / scale_mv < tol
+    out = np.full(m, -1.25, dtype=dtype)
+    res = mat.transpose_matvec(w, out=out)
+    assert res is out and np.abs(out - (ref_tmv - 1.25)).max() / scale_tmv < tol
 
 
 # ------------------------------------------------------------------ K4 categorical family
