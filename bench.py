@@ -332,7 +332,7 @@ def main():
             "hbm_frac_whole_job": round(alg_bytes / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "sum_kernel_ms": round(sum(bd.values()), 4),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,
                                          "cfg3": 50_000_000}[args.workload]
             result["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_rows, n_local), 3)
