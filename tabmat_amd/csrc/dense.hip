@@ -72,7 +72,7 @@ struct SyrkCfg {
     static constexpr int THREADS = NWAVES * 64;
     static constexpr int W = NBLK * 16;                 // padded number of columns
     static constexpr int LDW = W + 16;                  // LDS row stride (bank-conflict free)
-    static constexpr int RS = (W * (int)sizeof(F) >= 2048) ? 16 : 32;  // rows per chunk
+    static constexpr int RS = (W * (int)sizeof(F) >= 1024) ? 16 : 32;  // rows per chunk
     static constexpr int T = RECT ? (NBLK / 2) * (NBLK / 2) : NBLK * (NBLK + 1) / 2;  // tiles
     static constexpr int MAXT = (T + NWAVES - 1) / NWAVES;
     static constexpr int VEC = 16 / (int)sizeof(F);
@@ -116,57 +116,38 @@ __device__ __forceinline__ void syrk_wave_store(
      ...);
 }
 
-template <typename F, int NBLK, bool RECT, int WID>
+// HALF = 0 / 1: first / second half of the chunk's row groups (the staging of the next chunk is
+// issued between the two halves, see syrk_kernel).
+template <typename F, int NBLK, bool RECT, int WID, int HALF>
 __device__ __forceinline__ void syrk_wave_main(
     const F *__restrict__ lbuf, const F *__restrict__ dbuf,
     typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], int lane) {
     using C = SyrkCfg<F, NBLK, RECT>;
-    constexpr int NG = C::RS / 4;
-    // Wide panels (NBLK = 16) already run one wave per SIMD (accumulators fill the register
-    // file): software-pipeline inside the wave -- the fragments of row group g + 1 are read from
-    // LDS before the MFMAs of group g issue, so LDS latency hides behind the matrix pipe.
-    // Narrower panels keep two waves per SIMD instead (the extra fragment set would cost that).
-    constexpr bool PIPE = NBLK >= 16;
-    if constexpr (PIPE) {
-        F xa[2][NBLK], xb[2][NBLK];
-        auto load_frag = [&](int g, int slot) {
-            const int rl = 4 * g + (lane >> 4);
-            const F dv = dbuf[rl];
-            const F *lrow = lbuf + rl * C::LDW + (lane & 15);
-#pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                xb[slot][b] = lrow[16 * b];
-                xa[slot][b] = dv * xb[slot][b];
-            }
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) load_frag(g + 1, (g + 1) & 1);
-            syrk_wave_step<F, NBLK, RECT, WID>(xa[g & 1], xb[g & 1], acc,
-                                               std::make_integer_sequence<int, C::MAXT>{});
-        }
-    } else {
+    constexpr int NGH = C::RS / 8;          // row groups (of 4 rows) per half
+    constexpr int GB = HALF * NGH;
+    constexpr int NG = GB + NGH;
+    // No fragment prefetch across row groups: it would cost the second wave per SIMD (the kernel
+    // is tuned to <= 256 registers, amdgpu_waves_per_eu(2)), and two resident workgroups per CU
+    // hide the LDS latency better than a software pipeline inside one wave does
+    // (cfg2: 7.4 ms with one wave per SIMD and prefetch, 5.8 ms with two waves and none).
 #pragma unroll 2
-        for (int g = 0; g < NG; ++g) {
-            const int rl = 4 * g + (lane >> 4);
-            const F dv = dbuf[rl];
-            const F *lrow = lbuf + rl * C::LDW + (lane & 15);
-            F xa[NBLK], xb[NBLK];
+    for (int g = GB; g < NG; ++g) {
+        const int rl = 4 * g + (lane >> 4);
+        const F dv = dbuf[rl];
+        const F *lrow = lbuf + rl * C::LDW + (lane & 15);
+        F xa[NBLK], xb[NBLK];
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                xb[b] = lrow[16 * b];
-                xa[b] = dv * xb[b];
-            }
-            syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc,
-                                               std::make_integer_sequence<int, C::MAXT>{});
+        for (int b = 0; b < NBLK; ++b) {
+            xb[b] = lrow[16 * b];
+            xa[b] = dv * xb[b];
         }
+        syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc, std::make_integer_sequence<int, C::MAXT>{});
     }
 }
 
 // One workgroup: rows [blockIdx.x * rows_per_block, +rows_per_block) of the row list.
 template <typename F, int NBLK, int MODE, bool RECT>
-__global__ __launch_bounds__(256) void syrk_kernel(const F *__restrict__ X, int64_t n, int64_t m,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void syrk_kernel(const F *__restrict__ X, int64_t n, int64_t m,
                                                    const F *__restrict__ d,
                                                    const int32_t *__restrict__ rows,
                                                    int64_t n_iter, int64_t rows_per_block,
@@ -283,27 +264,38 @@ __global__ __launch_bounds__(256) void syrk_kernel(const F *__restrict__ X, int6
         }
     };
 
-    if (nchunk > 0) load_chunk(0);
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1;
-        store_chunk(buf);
-        __syncthreads();
-        if (ch + 1 < nchunk) load_chunk(ch + 1);
-        const F *lb = lds + buf * C::RS * C::LDW;
-        const F *db = dl + buf * C::RS;
-        // wave-uniform dispatch to the statically scheduled tile set of this wave
-        if (wave == 0) syrk_wave_main<F, NBLK, RECT, 0>(lb, db, acc, lane);
-        else if (wave == 1) syrk_wave_main<F, NBLK, RECT, 1>(lb, db, acc, lane);
-        else if (wave == 2) syrk_wave_main<F, NBLK, RECT, 2>(lb, db, acc, lane);
-        else syrk_wave_main<F, NBLK, RECT, 3>(lb, db, acc, lane);
-    }
-
+    // One barrier per chunk.  The staging of chunk ch + 1 (registers -> LDS, other buffer) and the
+    // global loads of chunk ch + 2 are issued BETWEEN the two halves of chunk ch's MFMA work, so
+    // the LDS writes overlap with the matrix pipe instead of sitting in front of the barrier, and
+    // every global load has a whole chunk of compute to land.
+    // The whole chunk loop is instantiated once per wave id (wave-uniform dispatch to the
+    // statically scheduled tile set of the wave, taken ONCE): the accumulators then stay in place
+    // for the whole kernel; every wave executes the same number of barriers.
     F *dst = ws + (int64_t)blockIdx.x * (C::T * 256);  // [tile][16][16]
-    constexpr auto seq = std::make_integer_sequence<int, C::MAXT>{};
-    if (wave == 0) syrk_wave_store<F, NBLK, RECT, 0>(acc, dst, lane, seq);
-    else if (wave == 1) syrk_wave_store<F, NBLK, RECT, 1>(acc, dst, lane, seq);
-    else if (wave == 2) syrk_wave_store<F, NBLK, RECT, 2>(acc, dst, lane, seq);
-    else syrk_wave_store<F, NBLK, RECT, 3>(acc, dst, lane, seq);
+    auto run = [&](auto wid) {
+        constexpr int WID = decltype(wid)::value;
+        if (nchunk > 0) {
+            load_chunk(0);
+            store_chunk(0);
+            if (nchunk > 1) load_chunk(1);
+        }
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int buf = ch & 1;
+            const F *lb = lds + buf * C::RS * C::LDW;
+            const F *db = dl + buf * C::RS;
+            syrk_wave_main<F, NBLK, RECT, WID, 0>(lb, db, acc, lane);
+            if (ch + 1 < nchunk) store_chunk(buf ^ 1);
+            if (ch + 2 < nchunk) load_chunk(ch + 2);
+            syrk_wave_main<F, NBLK, RECT, WID, 1>(lb, db, acc, lane);
+            __syncthreads();
+        }
+        syrk_wave_store<F, NBLK, RECT, WID>(acc, dst, lane, std::make_integer_sequence<int, C::MAXT>{});
+    };
+    if (wave == 0) run(std::integral_constant<int, 0>{});
+    else if (wave == 1) run(std::integral_constant<int, 1>{});
+    else if (wave == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
 }
 
 // Sum the per-workgroup partial tiles in fixed order (double accumulation): one block per
