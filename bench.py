@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2", "cfg3"])
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (SplitMatrix.sandwich_graph) "
+                         "instead of launching every kernel eagerly; single-GPU only")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the bounded CPU-baseline sample (0 = per-workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,13 +243,26 @@ def main():
 
     import tabmat_amd as tm
 
-    def step():
+    def product(dd):
         if isinstance(mat, tm.CategoricalMatrix):
-            out = mat._sandwich_diag_dev(d, None, None)
-        elif isinstance(mat, tm.SplitMatrix):
-            out = mat._sandwich_dev(d, None, None)
-        else:
-            out = mat._sandwich_dev(d, None, None)
+            return mat._sandwich_diag_dev(dd, None, None)
+        return mat._sandwich_dev(dd, None, None)
+
+    # One step = one pass of the hot path over the shard, launched eagerly.  --graph replays the
+    # same launch sequence (same kernels, order, arguments) from a HIP graph, the form a GLM solver
+    # would use for its per-iteration sandwich (SplitMatrix.sandwich_graph); at 10M rows the two
+    # are within 0.3 % (the step is ~45 launches of 0.02-11 ms each), it pays for small matrices.
+    use_graph = args.graph and world == 1
+    if not use_graph:
+        run = product
+    else:
+        from tabmat_amd.graph import CapturedProduct
+
+        run = CapturedProduct(product, d)
+        d = run._static_in
+
+    def step():
+        out = run(d)
         if world > 1:
             dist.all_reduce(out)  # RCCL over xGMI: p x p float64 (8 MB at p = 1024)
         return out
@@ -326,6 +342,7 @@ def main():
             "dtype": "f64" if tdt == torch.float64 else "f32",
             "data": "synthetic",
             "config": {"workload": wl_names[args.workload], "rows_per_gpu": n_local, "p": p,
+                       "launch": "hipgraph replay" if use_graph else "eager",
                        "sharding": "rows" if world > 1 else "none",
                        "collective": "all_reduce(p*p f64)" if world > 1 else "none"},
             "roofline": roof,

@@ -66,6 +66,10 @@ int tm_stream_synchronize(void *stream);
 /* Give the library caller-owned scratch for the current device (ptr == NULL: go back
  * to the internal allocation). */
 int tm_set_workspace(void *ptr, size_t bytes);
+/* Counter that changes whenever the library's workspace pointer of any device changes (growth or
+ * tm_set_workspace).  A caller that captured kernel launches into a HIP graph must re-capture
+ * when the value differs from the one read at capture time: the graph holds the old pointer. */
+int tm_workspace_generation(int64_t *generation);
 /* ---- event helpers so a ctypes host can time kernels on the launch stream ---- */
 int tm_event_create(void **event);
 int tm_event_destroy(void *event);

@@ -31,6 +31,7 @@ struct Workspace {
 };
 static Workspace g_ws[64];
 static std::mutex g_ws_mu;
+static int64_t g_ws_generation = 0;   // bumped whenever a workspace pointer changes
 
 int get_workspace(size_t bytes, void **ptr) {
     int dev = 0;
@@ -56,6 +57,7 @@ int get_workspace(size_t bytes, void **ptr) {
         size_t want = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes + bytes / 4;
         TM_HIP(hipMalloc(&w.ptr, want));
         w.bytes = want;
+        ++g_ws_generation;
     }
     *ptr = w.ptr;
     return TM_OK;
@@ -156,6 +158,7 @@ int tm_set_workspace(void *ptr, size_t bytes) {
         TM_HIP(hipDeviceSynchronize());
         TM_HIP(hipFree(w.ptr));
     }
+    ++g_ws_generation;
     if (ptr) {
         w.ptr = ptr;
         w.bytes = bytes;
@@ -165,6 +168,13 @@ int tm_set_workspace(void *ptr, size_t bytes) {
         w.bytes = 0;
         w.external = false;
     }
+    return TM_OK;
+}
+
+int tm_workspace_generation(int64_t *generation) {
+    TM_REQUIRE(generation != nullptr, "generation is NULL");
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    *generation = g_ws_generation;
     return TM_OK;
 }
 

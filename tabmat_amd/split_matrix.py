@@ -234,12 +234,18 @@ class SplitMatrix(MatrixBase):
         return stds
 
     # ---- hot path -------------------------------------------------------------------------
-    def _sandwich_dev(self, d, rows, cols_host):
-        """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
-        Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356)."""
+    def _sandwich_plan(self, cols_host):
+        """Column bookkeeping of one sandwich call, staged on the device once: output positions
+        and per-block column subsets (split_matrix.py:341-349)."""
         pos, sub_cols, n_cols = self._split_col_subsets(cols_host)
         pos_d = self._full_dev_indices() if cols_host is None else self._dev_idx(pos)
         sub_d = [None if sc is None else D.idx_dev(sc) for sc in sub_cols]
+        return pos_d, sub_d, n_cols
+
+    def _sandwich_dev(self, d, rows, cols_host, plan=None):
+        """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
+        Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356)."""
+        pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
         out = D.zeros((n_cols, n_cols), torch.float64)
         mats = self.matrices
         empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
@@ -296,6 +302,19 @@ class SplitMatrix(MatrixBase):
                 res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
                 xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
         return out
+
+    def sandwich_graph(self, d, rows=None, cols=None):
+        """HIP-graph form of `sandwich` for solvers that call it with the same `rows` / `cols`
+        every iteration: returns f(d) -> float64 (n_cols, n_cols) device tensor (a static buffer,
+        overwritten by the next call) that replays the captured launch sequence of
+        `_sandwich_dev` (tabmat_amd/graph.py).  d: a device tensor of the matrix dtype."""
+        from .graph import CapturedProduct
+
+        check_sandwich_compatible(self, d)
+        rows_d = D.idx_dev(normalize_index(rows, self.shape[0]))
+        cols_n = normalize_index(cols, self.shape[1])
+        plan = self._sandwich_plan(cols_n)      # index uploads happen here, outside the capture
+        return CapturedProduct(lambda dd: self._sandwich_dev(dd, rows_d, cols_n, plan), d)
 
     def sandwich(self, d, rows=None, cols=None):
         """X[rows, cols].T @ diag(d[rows]) @ X[rows, cols]; always float64 like the reference

@@ -485,3 +485,32 @@ def test_row_restriction_ignores_non_finite_excluded_rows():
     clean = [("dense", Xc), ("sparse", sps.csc_matrix(Sc))] + list(specs[2:])
     ref = _orc().split_sandwich([cs.to_oracle_block(s) for s in clean], idx, d, rows)
     assert rel_err(res, ref) < F64_TOL
+
+
+def test_sandwich_graph_replay_matches_eager():
+    """SplitMatrix.sandwich_graph replays the captured launch sequence (tabmat_amd/graph.py):
+    same result as the eager call for new d, with and without rows/cols, and after the library's
+    workspace moved (re-capture on tm_workspace_generation change)."""
+    import torch
+
+    import tabmat_amd as tm
+
+    specs, idx = cs.mixed_specs(20_000, 32, 48, (16, 9, 5), seed=5)
+    X = to_tm_split(specs, idx)
+    rng = np.random.default_rng(6)
+    d0 = torch.from_numpy(rng.random(20_000)).cuda()
+    f = X.sandwich_graph(d0)
+    for seed in (1, 2):
+        d = torch.from_numpy(np.random.default_rng(seed).random(20_000)).cuda()
+        got = f(d).clone()
+        ref = X.sandwich(d)
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < F64_TOL
+    rows = _rows_subset(rng, 20_000)
+    cols = np.sort(rng.choice(X.shape[1], 40, replace=False))
+    fr = X.sandwich_graph(d0, rows, cols)
+    assert rel_err(fr(d0).cpu().numpy(), X.sandwich(d0, rows, cols).cpu().numpy()) < F64_TOL
+    # a larger product moves the workspace: the captured graphs must notice and re-capture
+    big = tm.DenseMatrix(rng.standard_normal((300_000, 700)))
+    big.sandwich(rng.random(300_000))
+    d = torch.from_numpy(np.random.default_rng(9).random(20_000)).cuda()
+    assert rel_err(f(d).cpu().numpy(), X.sandwich(d).cpu().numpy()) < F64_TOL
