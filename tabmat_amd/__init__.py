@@ -3,6 +3,7 @@ MatrixBase / SplitMatrix API.  Block storage lives in HBM; every product is a ha
 HIP kernel in libtabmat_hip.so reached through the C ABI of include/tabmat_hip.h.  There is
 no CPU fallback."""
 from .categorical_matrix import CategoricalMatrix
+from .constructor import from_csc, from_df, from_pandas
 from .dense_matrix import DenseMatrix
 from .matrix_base import MatrixBase
 from .sparse_matrix import SparseMatrix
@@ -10,4 +11,5 @@ from .split_matrix import SplitMatrix, as_tabmat, hstack
 from .standardized_mat import StandardizedMatrix
 
 __all__ = ["DenseMatrix", "SparseMatrix", "CategoricalMatrix", "SplitMatrix",
-           "StandardizedMatrix", "MatrixBase", "hstack", "as_tabmat"]
+           "StandardizedMatrix", "MatrixBase", "hstack", "as_tabmat", "from_csc", "from_df",
+           "from_pandas"]
