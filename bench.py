@@ -222,12 +222,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # one process per GPU; TABMAT_BENCH_BACKEND=gloo lets the N > 1 control flow be exercised on a
+    # box with fewer GPUs than ranks (ranks then share devices; not a performance configuration)
+    backend = os.environ.get("TABMAT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from tabmat_amd import synth
