@@ -613,21 +613,33 @@ __global__ void multi_cat_untile_kernel(const F *__restrict__ tmp, int64_t total
 }
 
 // Sparse operand in slab-blocked column-major form (sparse.hip): part = one 32-column group,
-// lane <-> nonzero of the (slab, group) stream.
-template <typename F>
+// lane <-> nonzero of the (slab, group) stream.  The LDS tile has a row stride of
+// group_cols + 1: consecutive stream entries belong to the same column (runs of ~6 rows), with an
+// unpadded stride they would all fall on one bank pair.  STAGE: every wave first copies the
+// codes and d of its 128-row slab into its own LDS scratch (coalesced loads), the per-nonzero
+// lookups are then LDS reads instead of 64-lane global gathers.
+template <typename F, bool STAGE>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ vals,
     const unsigned *__restrict__ koff, const unsigned char *__restrict__ ecol,
     const int64_t *__restrict__ gptr, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
-    int slab_rows, int group_cols, F *__restrict__ ws, int64_t stride) {
+    int slab_rows, int group_cols, int64_t n, F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols]
-    const int nel = cs.total * group_cols;
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols + 1]
+    const int tstr = group_cols + 1;
+    const int nel = cs.total * tstr;
     for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
-    __syncthreads();
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    // per-wave scratch (STAGE): d of the slab rows, then the codes of every categorical
+    F *sd = reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16) +
+            (size_t)wave * slab_rows;
+    int32_t *sc = reinterpret_cast<int32_t *>(
+                      reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16) +
+                      (size_t)nwave * slab_rows) +
+                  (size_t)wave * cs.n_cats * slab_rows;
+    __syncthreads();
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
     const unsigned rowb = 64u * (unsigned)sizeof(F);
@@ -644,6 +656,15 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
             nb = gptr[(s + nwave) * n_groups + g];
             ne = gptr[(s + nwave) * n_groups + g + 1];
         }
+        if (STAGE) {
+            __builtin_amdgcn_wave_barrier();
+            for (int r = lane; r < slab_rows; r += 64) {
+                const int64_t k = min(s * slab_rows + r, n - 1);
+                sd[r] = d[k];
+                for (int c = 0; c < cs.n_cats; ++c) sc[c * slab_rows + r] = cs.codes[c][k] - cs.drop[c];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         for (int64_t e0 = base + lane; e0 < end; e0 += 128) {
             const int64_t e1 = e0 + 64;
             const bool ok1 = e1 < end;
@@ -653,24 +674,138 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
             const F v1 = ok1 ? vals[e1] : F(0);
             const int ec0 = ecol[e0];
             const int ec1 = ok1 ? ecol[e1] : 0;
-            const int64_t k0 = s * slab_rows + (int64_t)(ko0 / rowb);
-            const int64_t k1 = s * slab_rows + (int64_t)(ko1 / rowb);
-            const F d0 = d[k0];
-            const F d1 = ok1 ? d[k1] : F(0);
+            const int r0 = (int)(ko0 / rowb), r1 = (int)(ko1 / rowb);
+            const int64_t k0 = s * slab_rows + r0;
+            const int64_t k1 = s * slab_rows + r1;
+            const F d0 = STAGE ? sd[r0] : d[k0];
+            const F d1 = ok1 ? (STAGE ? sd[r1] : d[k1]) : F(0);
             const F x0 = d0 != F(0) ? d0 * v0 : F(0);   // rows masked out by d == 0 contribute
             const F x1 = d1 != F(0) ? d1 * v1 : F(0);   // exactly nothing, whatever they hold
 #pragma unroll 1
             for (int c = 0; c < cs.n_cats; ++c) {
-                const int c0 = cs.codes[c][k0] - cs.drop[c];
-                const int c1 = ok1 ? cs.codes[c][k1] - cs.drop[c] : -1;
-                if (c0 >= 0) atomic_add(&tile[(cs.off[c] + c0) * group_cols + ec0], x0);
-                if (c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * group_cols + ec1], x1);
+                const int c0 = STAGE ? sc[c * slab_rows + r0] : cs.codes[c][k0] - cs.drop[c];
+                const int c1 = ok1 ? (STAGE ? sc[c * slab_rows + r1] : cs.codes[c][k1] - cs.drop[c])
+                                   : -1;
+                if (c0 >= 0) atomic_add(&tile[(cs.off[c] + c0) * tstr + ec0], x0);
+                if (c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * tstr + ec1], x1);
             }
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < cs.total * group_cols; b += blockDim.x)
+        dst[b] = tile[(b / group_cols) * tstr + (b % group_cols)];
+}
+
+// Fast variant for 1..4 categoricals: one (slab, group) block per wave step.  While a block is
+// processed, the first 256 stream entries of the wave's NEXT block and the d / codes of that
+// slab's 128 rows are already in flight into registers (one memory round trip per block, hidden
+// behind the previous block's atomics); d and codes are then parked in per-wave LDS scratch so the
+// per-nonzero lookups are LDS reads.
+template <typename F, int NC>
+__global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals,
+    const unsigned *__restrict__ koff, const unsigned char *__restrict__ ecol,
+    const int64_t *__restrict__ gptr, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
+    int group_cols, int64_t n, F *__restrict__ ws, int64_t stride) {
+    constexpr int SR = 128;              // slab rows (tm_slab_rows)
+    constexpr int NQ = 4;                // prefetched 64-entry chunks per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols + 1]
+    const int tstr = group_cols + 1;
+    const int nel = cs.total * tstr;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    unsigned char *scratch = smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16;
+    F *sd = reinterpret_cast<F *>(scratch) + (size_t)wave * SR;
+    int32_t *sc = reinterpret_cast<int32_t *>(reinterpret_cast<F *>(scratch) + (size_t)nwave * SR) +
+                  (size_t)wave * NC * SR;
+    __syncthreads();
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const unsigned rowb = 64u * (unsigned)sizeof(F);
+
+    // pointers two blocks ahead, stream + row data one block ahead
+    int64_t q_base = 0, q_end = 0;
+    int64_t p_base = 0, p_end = 0;
+    unsigned p_ko[NQ];
+    F p_v[NQ];
+    int p_ec[NQ];
+    F p_d[2];
+    int p_c[NC][2];
+    auto load_ptrs = [&](int64_t s) {
+        q_base = q_end = 0;
+        if (s < s1) {
+            q_base = gptr[s * n_groups + g];
+            q_end = gptr[s * n_groups + g + 1];
+        }
+    };
+    auto load_block = [&](int64_t s) {     // consumes the pointers, issues the loads of block s
+        p_base = q_base;
+        p_end = q_end;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t e = p_base + q * 64 + lane;
+            const int64_t ec = min(e, max(p_end - 1, p_base));     // clamped: branch-free issue
+            const bool ok = e < p_end;
+            p_ko[q] = ok ? koff[ec] : 0u;
+            p_v[q] = ok ? vals[ec] : F(0);
+            p_ec[q] = ok ? (int)ecol[ec] : 0;
+        }
+        if (s < s1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t k = min(s * SR + lane + 64 * h, n - 1);
+                p_d[h] = d[k];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) p_c[c][h] = cs.codes[c][k] - cs.drop[c];
+            }
+        }
+    };
+    const int64_t sw = s0 + wave;
+    load_ptrs(sw);
+    load_block(sw);
+    load_ptrs(sw + nwave);
+    for (int64_t s = sw; s < s1; s += nwave) {
+        // take over the prefetched block
+        const int64_t base = p_base, end = p_end;
+        unsigned ko[NQ];
+        F v[NQ];
+        int ec[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { ko[q] = p_ko[q]; v[q] = p_v[q]; ec[q] = p_ec[q]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sd[lane + 64 * h] = p_d[h];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sc[c * SR + lane + 64 * h] = p_c[c][h];
+        }
+        __builtin_amdgcn_wave_barrier();
+        load_block(s + nwave);
+        load_ptrs(s + 2 * nwave);
+        auto scatter = [&](unsigned kk, F vv, int ee) {
+            const int r = (int)(kk / rowb);
+            const F dk = sd[r];
+            const F x = dk != F(0) ? dk * vv : F(0);   // rows masked out by d == 0 contribute nothing
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int cc = sc[c * SR + r];
+                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * tstr + ee], x);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (base + q * 64 + lane < end) scatter(ko[q], v[q], ec[q]);
+        // blocks longer than the prefetch window (dense columns): the rest straight from memory
+        for (int64_t e = base + NQ * 64 + lane; e < end; e += 64) scatter(koff[e], vals[e], (int)ecol[e]);
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < cs.total * group_cols; b += blockDim.x)
+        dst[b] = tile[(b / group_cols) * tstr + (b % group_cols)];
 }
 
 static int make_catset(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
@@ -779,11 +914,15 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
     if (n == 0) return TM_OK;
     const int64_t stride = (int64_t)cs.total * group_cols;
-    const size_t lds = sizeof(F) * (size_t)stride;
-    if (lds > HIST_LDS_MAX) {
+    const size_t tile_bytes = ((sizeof(F) * (size_t)cs.total * (group_cols + 1) + 15) / 16) * 16;
+    if (tile_bytes > HIST_LDS_MAX) {
         set_error("multi_cat_sparse: %d stacked categories exceed the LDS tile", cs.total);
         return TM_EUNSUPPORTED;
     }
+    // per-wave staging of the slab's d and codes when it fits next to the tile
+    const size_t stage_bytes = (size_t)16 * slab_rows * (sizeof(F) + sizeof(int32_t) * (size_t)n_cats);
+    const bool stage = tile_bytes + stage_bytes <= 150 * 1024;
+    const size_t lds = tile_bytes + (stage ? stage_bytes : 0);
     const int n_groups = (int)ceil_div(m, group_cols);
     const int64_t n_slabs = ceil_div(n, slab_rows);
     int64_t nblk = std::max<int64_t>(1, NUM_CU / n_groups);
@@ -797,16 +936,31 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    auto kern = &multi_cat_sparse_kernel<F>;
-    if (lds > 48 * 1024)
-        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs, d,
-                       vals, koff, ecol, gptr, n_groups, n_slabs, spb, slab_rows, group_cols, ws,
-                       stride);
-    prof_end(st);
-    TM_LAUNCH_CHECK();
+    if (stage && n_cats <= 4 && slab_rows == 128) {
+        auto kpf = n_cats == 1   ? &multi_cat_sparse_pf_kernel<F, 1>
+                   : n_cats == 2 ? &multi_cat_sparse_pf_kernel<F, 2>
+                   : n_cats == 3 ? &multi_cat_sparse_pf_kernel<F, 3>
+                                 : &multi_cat_sparse_pf_kernel<F, 4>;
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kpf),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(st);
+        hipLaunchKernelGGL(kpf, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs, d,
+                           vals, koff, ecol, gptr, n_groups, n_slabs, spb, group_cols, n, ws, stride);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+    } else {
+        auto kern = stage ? &multi_cat_sparse_kernel<F, true> : &multi_cat_sparse_kernel<F, false>;
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs,
+                           d, vals, koff, ecol, gptr, n_groups, n_slabs, spb, slab_rows, group_cols,
+                           n, ws, stride);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+    }
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_groups, tmp,
                                    (int64_t)n_groups * stride, false, st);
     if (rc) return rc;

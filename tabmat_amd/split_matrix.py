@@ -277,7 +277,7 @@ class SplitMatrix(MatrixBase):
                     stacked = xs.csr_dense_sandwich_slab(oh, mw._dev(), d_eff)[inv]
                 elif isinstance(mw, DenseMatrix) and total <= budget:
                     stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev())
-                elif (isinstance(mw, SparseMatrix) and total * 32 <= budget
+                elif (isinstance(mw, SparseMatrix) and total * 33 <= budget
                       and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
                     stacked = xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
                 if stacked is None:
