@@ -101,7 +101,7 @@ def test_dense_matvec_rmatvec(order, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("k", [16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("k", [4, 16, 32, 64, 128, 256, 512, 520])
 def test_dense_matvec_stream_path(dtype, k):
     """Unrestricted C-order matvec takes the 16-byte streaming kernel when a row is 8..128
     16-byte vectors long (dense.hip dense_matvec_c_stream_kernel); every lanes-per-row
@@ -120,6 +120,18 @@ def test_dense_matvec_stream_path(dtype, k):
         out = np.full(n, 2.5, dtype=dtype)
         res = mat.matvec(v, out=out)
         assert res is out and rel_err(out, ref + 2.5) < tol
+        # transpose_matvec and the weighted column second moments (K7) share the 16-byte
+        # streaming kernel dense_rmatvec_c_stream_kernel
+        w = rng.standard_normal(n).astype(dtype)
+        ref_t = X.astype(np.float64).T @ w.astype(np.float64)
+        scale = max(1.0, np.abs(ref_t).max())
+        assert np.abs(mat.transpose_matvec(w) - ref_t).max() / scale < tol
+        wts = rng.random(n).astype(dtype)
+        wts /= wts.sum()
+        means = (X.astype(np.float64) * wts[:, None].astype(np.float64)).sum(axis=0)
+        ref_sd = np.sqrt((((X.astype(np.float64) - means) ** 2) * wts[:, None]).sum(axis=0))
+        got_sd = mat._get_col_stds(wts, means.astype(dtype))
+        assert np.abs(got_sd - ref_sd).max() < (1e-9 if dtype == np.float64 else 2e-3)
 
 
 # ------------------------------------------------------------------ K2 sparse sandwich
