@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__r
             const int64_t row = min(r0 + r * RPL + seg, n - 1);
 #pragma unroll
             for (int q = 0; q < NL; ++q)
-                x[r][q] = *reinterpret_cast<const vec_t *>(X + row * m + ((int64_t)q * 64 + sl) * VEC);
+                x[r][q] = __builtin_nontemporal_load(
+                    reinterpret_cast<const vec_t *>(X + row * m + ((int64_t)q * 64 + sl) * VEC));
         }
 #pragma unroll
         for (int r = 0; r < MV_R; ++r) {
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256) void dense_rmatvec_c_stream_kernel(
 #pragma unroll
                 for (int r = 0; r < MV_R; ++r) {
                     const int64_t row = min(r0 + r, t1 - 1);
-                    x[r] = *reinterpret_cast<const vec_t *>(X + row * m + c);
+                    x[r] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(X + row * m + c));
                     w[r] = r0 + r < t1 ? v[row] : F(0);
                 }
 #pragma unroll
