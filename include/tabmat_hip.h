@@ -142,14 +142,15 @@ int tm_sparse_sandwich_f64(const double *csr_data, const int32_t *csr_indices,
 /* Unrestricted fast path of the same product on precomputed per-row chunk pointers:
  * cptr[k * (NCH + 1) + c] = index (into csr_data / csr_indices, < 2^31) of the first entry of
  * row k whose column is >= c * tm_sparse_chunk_cols(), c = 0 .. NCH = ceil(m / chunk_cols).
+ * nnz = number of stored entries (rows must be sorted by column and duplicate-free).
  * Restrictions are applied by the host side (masked d, sub-selection of the result). */
 int tm_sparse_chunk_cols(void);
 int tm_sparse_sandwich_chunked_f32(const float *csr_data, const int32_t *csr_indices,
-                                   const int32_t *cptr, int64_t n, int64_t m, const float *d,
-                                   float *out, void *stream);
+                                   const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                   const float *d, float *out, void *stream);
 int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_indices,
-                                   const int32_t *cptr, int64_t n, int64_t m, const double *d,
-                                   double *out, void *stream);
+                                   const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                   const double *d, double *out, void *stream);
 
 /* out[nA x nB] = A[rows,A_cols]^T diag(d) B[rows,B_cols]; A sparse (CSR, n x m), B dense (n x r).
  * Replaces _csr_dense{C,F}_sandwich (ext/sparse_helpers-tmpl.cpp:23-146) as bound by

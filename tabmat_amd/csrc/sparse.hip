@@ -414,11 +414,14 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
 // lane&7) loads entry a of the I-list and entry b of the J-list straight from the CSR arrays
 // (L1 hits: a row is ~300 contiguous bytes) and issues one ds_add_f64 into the LDS tile.
 // ---------------------------------------------------------------------------------------
+constexpr int K2_ED = 2;   // groups whose entry loads are in flight
+constexpr int K2_NP = 2;   // further groups whose chunk-pointer loads are in flight
+
 template <typename F, int TS>
 __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
-    int nb_diag, int nb_off, int max_nb, F *__restrict__ ws) {
+    int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
     typedef K2Entry<F> Ent;
@@ -463,66 +466,73 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const int64_t t1 = min(t0 + rows_per_block, n);
     const int stride = nch + 1;
 
-    // A wave owns GROUPS of 8 consecutive rows (8 lanes per row).  Two-stage pipeline: while
-    // group g is processed, the entries of group g + W and the chunk pointers of group g + 2W
-    // are in flight -> one memory round trip per 8 rows instead of one per row.
-    int q_pA = 0, q_nA = 0, q_pB = 0, q_nB = 0;      // stage 2
-    F q_d = F(0);
-    int p_pA = 0, p_nA = 0, p_pB = 0, p_nB = 0;      // stage 1
-    F p_d = F(0), p_va = F(0), p_vb = F(0), p_va2 = F(0), p_vb2 = F(0);
-    int p_ca = 0, p_cb = 0, p_ca2 = 0, p_cb2 = 0;
+    // A wave owns GROUPS of 8 consecutive rows (8 lanes per row).  Software pipeline over the
+    // groups: the entry loads of a group need its chunk pointers (two dependent memory round
+    // trips), and one round trip (~3 us under this kernel's load) is longer than the LDS work of a
+    // group (~1 us).  So the entries of K2_ED groups and the pointers of K2_NP further groups
+    // are in flight while group g is processed: per-group time = max(work, latency / K2_ED)
+    // instead of the latency (PMC before: 62 % of the wave cycles in s_waitcnt, diagonal tiles as
+    // slow as off-diagonal ones although they issue half the atomics).
+    // Every load below is issued unconditionally with a clamped address (no exec-masked
+    // branches, no arithmetic on a loaded value before the next load goes out): the number of
+    // outstanding loads per iteration is then a compile-time constant and the s_waitcnt for a
+    // value loaded two iterations ago leaves everything younger in flight.
+    struct Ptr { int a0, a1, b0, b1; F d; bool valid; };
+    struct Grp { int pA, nA, pB, nB; F d; F va, vb, va2, vb2; int ca, cb, ca2, cb2; };
     auto load_ptrs = [&](int64_t g0) {
-        q_pA = q_nA = q_pB = q_nB = 0;
-        q_d = F(0);
+        Ptr q;
         const int64_t k = g0 + lr;
-        if (g0 < t1 && k < t1) {
-            const int32_t *cp = cptr + k * stride;
-            q_d = d[k];
-            q_pA = cp[I];
-            q_pB = cp[J];
-            if (q_d != F(0)) {
-                q_nA = cp[I + 1] - q_pA;
-                q_nB = cp[J + 1] - q_pB;
-            }
-        }
+        q.valid = k < t1;
+        const int64_t kc = min(k, n - 1);
+        const int32_t *cp = cptr + kc * stride;
+        q.d = d[kc];
+        q.a0 = cp[I];
+        q.a1 = cp[I + 1];
+        q.b0 = cp[J];
+        q.b1 = cp[J + 1];
+        return q;
     };
-    auto load_entries = [&]() {   // slots lt and lt + 8 of both lists: 16 entries per list
-        p_pA = q_pA; p_nA = q_nA; p_pB = q_pB; p_nB = q_nB; p_d = q_d;
-        p_ca = p_cb = p_ca2 = p_cb2 = 0;
-        p_va = p_vb = p_va2 = p_vb2 = F(0);
-        if (lt < p_nA) {
-            p_ca = ind[p_pA + lt];
-            p_va = data[p_pA + lt];
-        }
-        if (lt < p_nB) {
-            p_cb = ind[p_pB + lt];
-            p_vb = data[p_pB + lt];
-        }
-        if (lt + 8 < p_nA) {
-            p_ca2 = ind[p_pA + lt + 8];
-            p_va2 = data[p_pA + lt + 8];
-        }
-        if (lt + 8 < p_nB) {
-            p_cb2 = ind[p_pB + lt + 8];
-            p_vb2 = data[p_pB + lt + 8];
-        }
+    auto load_entries = [&](const Ptr &q) {   // slots lt and lt + 8 of both lists: 16 entries per list
+        Grp e;
+        const bool on = q.valid && q.d != F(0);      // rows with d == 0 contribute nothing
+        e.d = q.d;
+        e.pA = q.a0;
+        e.pB = q.b0;
+        e.nA = on ? q.a1 - q.a0 : 0;
+        e.nB = on ? q.b1 - q.b0 : 0;
+        const int64_t iA = min((int64_t)e.pA + min(lt, max(e.nA - 1, 0)), nnz1);
+        const int64_t iB = min((int64_t)e.pB + min(lt, max(e.nB - 1, 0)), nnz1);
+        const int64_t iA2 = min((int64_t)e.pA + min(lt + 8, max(e.nA - 1, 0)), nnz1);
+        const int64_t iB2 = min((int64_t)e.pB + min(lt + 8, max(e.nB - 1, 0)), nnz1);
+        e.ca = ind[iA];
+        e.va = data[iA];
+        e.cb = ind[iB];
+        e.vb = data[iB];
+        e.ca2 = ind[iA2];
+        e.va2 = data[iA2];
+        e.cb2 = ind[iB2];
+        e.vb2 = data[iB2];
+        return e;
     };
     const int64_t gstep = (int64_t)K2_WAVES * 8;
     const int64_t gw = t0 + (int64_t)wave * 8;
-    load_ptrs(gw);
-    load_entries();
-    load_ptrs(gw + gstep);
+    Grp es[K2_ED];
+    Ptr ps[K2_NP];
+#pragma unroll
+    for (int i = 0; i < K2_ED; ++i) es[i] = load_entries(load_ptrs(gw + i * gstep));
+#pragma unroll
+    for (int i = 0; i < K2_NP; ++i) ps[i] = load_ptrs(gw + (K2_ED + i) * gstep);
     const int pa = lane >> 3, pb = lane & 7;       // pair phase: (a, b) of an 8 x 8 block
-    for (int64_t g0 = gw; g0 < t1; g0 += gstep) {
-        const int nA = p_nA, nB = p_nB, pA0 = p_pA, pB0 = p_pB;
-        const F dk = p_d;
+    static_assert(K2_ED == 2 && K2_NP == 2, "two groups per turn");
+    auto process = [&](const Grp &cur) {
+        const int nA = cur.nA, nB = cur.nB, pA0 = cur.pA, pB0 = cur.pB;
+        const F dk = cur.d;
+        // slots beyond the lists carry clamped (duplicate) entries: masked by the n tests below
         Ent ea, eb, ea2, eb2;
-        ea.val = p_va * dk;   ea.col = p_ca - i0;
-        eb.val = p_vb;        eb.col = p_cb - j0;
-        ea2.val = p_va2 * dk; ea2.col = p_ca2 - i0;
-        eb2.val = p_vb2;      eb2.col = p_cb2 - j0;
-        load_entries();                    // group g + W
-        load_ptrs(g0 + 2 * gstep);         // group g + 2W
+        ea.val = cur.va * dk;   ea.col = cur.ca - i0;
+        eb.val = cur.vb;        eb.col = cur.cb - j0;
+        ea2.val = cur.va2 * dk; ea2.col = cur.ca2 - i0;
+        eb2.val = cur.vb2;      eb2.col = cur.cb2 - j0;
         const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
         // four phases over the (A half, B half) blocks; the per-wave scratch holds one half of
         // each list at a time.  ha/hb = which half (0: entries 0..7, 1: entries 8..15).
@@ -537,6 +547,46 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             else if (phase == 2) { sb[lane] = eb2; }
             else { sa[lane] = ea; sb[lane] = eb2; }
             __builtin_amdgcn_wave_barrier();
+            if (I == J && phase == 0) {
+                // Diagonal tile: only the pairs b <= a of a row are needed (entries are sorted by
+                // column and distinct), i.e. the lower triangle of the 8 x 8 lane block.  Two
+                // rows share one ds_add: lanes pb <= pa take pair (pa, pb) of the `low` row
+                // (lists up to 8), lanes pb > pa take pair (pb - 1, pa) of the `up` row (lists up
+                // to 7); two rows that both have 8+ entries in the chunk go one after the other.
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const int n0 = min(__builtin_amdgcn_readlane(nA, r * 8), 8);
+                    const int n1 = min(__builtin_amdgcn_readlane(nA, r * 8 + 8), 8);
+                    if (n0 == 0 && n1 == 0) continue;
+                    const bool lower = pb <= pa;
+                    if (n0 <= 7 || n1 <= 7) {
+                        const bool swap = n1 > 7;                 // the long row must be `low`
+                        const int rl = swap ? r + 1 : r, ru = swap ? r : r + 1;
+                        const int nl = swap ? n1 : n0, nu = swap ? n0 : n1;
+                        const int row = lower ? rl : ru;
+                        const int a = lower ? pa : pb - 1;
+                        const int b = lower ? pb : pa;
+                        if (a < (lower ? nl : nu)) {
+                            const Ent xa = sa[row * 8 + a];
+                            const Ent xb = sb[row * 8 + b];
+                            atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
+                                       xa.val * xb.val);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if (lower) {
+                                const Ent xa = sa[(r + q) * 8 + pa];
+                                const Ent xb = sb[(r + q) * 8 + pb];
+                                atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
+                                           xa.val * xb.val);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int nAr = __builtin_amdgcn_readlane(nA, r * 8) - 8 * ha;
@@ -580,6 +630,19 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 }
             }
         }
+    };
+    // Two groups per turn: both groups' prefetched entries are taken over, the loads of the next
+    // turn (entries of g + 2, g + 3 from the pointers fetched last turn; pointers of g + 4, g + 5)
+    // are issued back to back, then the two groups are processed -- every load has two groups of
+    // LDS work to land before the next turn touches it.
+    for (int64_t g0 = gw; g0 < t1; g0 += 2 * gstep) {
+        const Grp cur0 = es[0], cur1 = es[1];
+        es[0] = load_entries(ps[0]);
+        es[1] = load_entries(ps[1]);
+        ps[0] = load_ptrs(g0 + 4 * gstep);
+        ps[1] = load_ptrs(g0 + 5 * gstep);
+        process(cur0);
+        if (g0 + gstep < t1) process(cur1);
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
@@ -864,9 +927,10 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
 
 template <typename F>
 static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const int32_t *cptr,
-                                       int64_t n, int64_t m, const F *d, F *out, hipStream_t st) {
+                                       int64_t n, int64_t m, int64_t nnz, const F *d, F *out,
+                                       hipStream_t st) {
     if (m == 0) return TM_OK;
-    if (n == 0) {
+    if (n == 0 || nnz == 0) {
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(m * m), st));
         return TM_OK;
     }
@@ -875,11 +939,12 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
     const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
-    // workgroups per tile.  Measured: diagonal and off-diagonal tiles cost the same per row
-    // (the per-row overhead dominates the pair count), so the split is even.
+    // workgroups per tile.  Measured: diagonal and off-diagonal tiles cost the same per row (the
+    // per-row loads dominate, not the pair count), so the split is even; the off-diagonal tiles
+    // take the workgroups left over by the integer division (25 / 26 at 512 columns: all 256 CUs).
     const int n_off = n_parts - nchunk;
     int nb_diag = std::max(1, NUM_CU / n_parts);
-    int nb_off = nb_diag;
+    int nb_off = n_off > 0 ? std::max(nb_diag, (NUM_CU - nchunk * nb_diag) / n_off) : nb_diag;
     const int cap = (int)std::max<int64_t>(1, ceil_div(n, 1024));
     nb_diag = std::min(nb_diag, cap);
     nb_off = std::min(nb_off, cap);
@@ -894,10 +959,13 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     auto kern = &sparse_sandwich_chunked_kernel<F, TS>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // every tile's partials are reduced over nblk slots: tiles with fewer workgroups leave theirs 0
+    if (nb_diag != nb_off)
+        TM_HIP(hipMemsetAsync(ws, 0, sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS, st));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nchunk * nb_diag + n_off * nb_off)),
-                       dim3(K2_WAVES * 64), lds, st, data, ind, cptr, nchunk, d, n, nb_diag, nb_off,
-                       (int)nblk, ws);
+                       dim3(K2_WAVES * 64), lds, st, data, ind, cptr, nchunk, d, n, nnz - 1, nb_diag,
+                       nb_off, (int)nblk, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,
@@ -1366,15 +1434,15 @@ extern "C" {
 
 int tm_sparse_chunk_cols(void) { return 128; }
 int tm_sparse_sandwich_chunked_f32(const float *csr_data, const int32_t *csr_indices,
-                                   const int32_t *cptr, int64_t n, int64_t m, const float *d,
-                                   float *out, void *stream) {
-    return tmh::run_sparse_sandwich_chunked<float>(csr_data, csr_indices, cptr, n, m, d, out,
+                                   const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                   const float *d, float *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<float>(csr_data, csr_indices, cptr, n, m, nnz, d, out,
                                                    tmh::as_stream(stream));
 }
 int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_indices,
-                                   const int32_t *cptr, int64_t n, int64_t m, const double *d,
-                                   double *out, void *stream) {
-    return tmh::run_sparse_sandwich_chunked<double>(csr_data, csr_indices, cptr, n, m, d, out,
+                                   const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                   const double *d, double *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<double>(csr_data, csr_indices, cptr, n, m, nnz, d, out,
                                                     tmh::as_stream(stream));
 }
 

@@ -80,7 +80,7 @@ def sparse_sandwich_chunked(A: CsrDev, d):
         return out
     cp = A.chunk_ptr()
     call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(cp),
-         A.n, A.m, D.p(d), D.p(out), D.stream_ptr())
+         A.n, A.m, int(A.data.numel()), D.p(d), D.p(out), D.stream_ptr())
     return out
 
 

@@ -37,8 +37,10 @@ class SparseMatrix(MatrixBase):
             self._array.indices = self._array.indices.astype(self.idx_dtype)
         if self._array.indptr.dtype != self.idx_dtype:
             self._array.indptr = self._array.indptr.astype(self.idx_dtype)
-        if not self._array.has_sorted_indices:
-            self._array.sort_indices()
+        if not self._array.has_canonical_format:
+            # sorted, duplicate-free rows/columns: the chunked K2 kernel enumerates the pairs of a
+            # row by entry position (the matrix itself is unchanged by summing duplicates)
+            self._array.sum_duplicates()
         self._array_csr = None
         self._devblk = None
         self._slabblk = None
