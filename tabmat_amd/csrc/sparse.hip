@@ -1062,38 +1062,30 @@ constexpr int GATHER_CPW = 32;                      // sparse columns (static ac
 constexpr int GATHER_NW = 16;                       // waves per workgroup -> 512 sparse columns
 constexpr int GATHER_THREADS = GATHER_NW * 64;
 
-// Stream entries are broadcast to the 64 lanes through a small per-wave LDS ring of 64 entries:
-// a uniform-address ds_read_b128 delivers {value, row offset} to every lane (v_readlane costs
-// ~9 cycles each on this kernel's critical path, 3 per nonzero).  The ring is rewritten in place
-// when its 64 entries are consumed (LDS operations of one wave execute in order).
-template <typename F>
-struct __attribute__((aligned(16))) GEntry {
-    F a;
-    unsigned ko;
-    unsigned pad;
-};
-
-#define TM_GATHER_STEP(E, X, LIDX)                                                        \
-    const GEntry<F> E = ring[(LIDX)];                                                     \
-    const F X = *reinterpret_cast<const F *>(slab + E.ko + lane_off);
+// Stream entries are broadcast to the 64 lanes in two ways: the VALUE through a small per-wave LDS
+// ring of 64 doubles (uniform-address ds_read_b64), the ROW OFFSET with v_readlane from the register
+// that holds the current 64-entry chunk (lane <-> entry), so that the slab read does not wait for
+// an LDS round trip and the LDS sees 4 instead of 6 cycles per nonzero.  The ring / register are
+// rewritten in place when their 64 entries are consumed.
+#define TM_GATHER_STEP(A, X, LIDX)                                                        \
+    const F A = ring[(LIDX)];                                                             \
+    const F X = *reinterpret_cast<const F *>(                                             \
+        slab + (unsigned)__builtin_amdgcn_readlane((int)kcur, (LIDX)) + lane_off);
 
 // SCALE: the dense slab in LDS holds B unscaled (async global->LDS copy); d is folded into the
 // stream value when an entry enters the ring, and entries of rows with d == 0 are redirected to
 // an all-zero LDS row so that excluded rows contribute exactly nothing.
 template <typename F, bool SCALE>
-__device__ __forceinline__ GEntry<F> make_entry(F a, unsigned ko, const F *__restrict__ dl,
-                                                unsigned zero_off) {
-    GEntry<F> e;
-    e.pad = 0;
+__device__ __forceinline__ void make_entry(F a, unsigned ko, const F *__restrict__ dl,
+                                           unsigned zero_off, F &a_out, unsigned &ko_out) {
     if (SCALE) {
         const F dk = dl[ko / (64u * (unsigned)sizeof(F))];
-        e.a = a * dk;
-        e.ko = dk != F(0) ? ko : zero_off;
+        a_out = a * dk;
+        ko_out = dk != F(0) ? ko : zero_off;
     } else {
-        e.a = a;
-        e.ko = ko;
+        a_out = a;
+        ko_out = ko;
     }
-    return e;
 }
 
 template <typename F, bool SCALE, int C>
@@ -1101,7 +1093,7 @@ struct ColLoop {
     // processes static column C of the wave's group, then recurses to C + 1
     static __device__ __forceinline__ void run(F (&acc)[GATHER_CPW],
                                                const unsigned char *__restrict__ slab,
-                                               GEntry<F> *__restrict__ ring,
+                                               F *__restrict__ ring, unsigned &kcur,
                                                const F *__restrict__ dl, unsigned zero_off,
                                                int cntv, int &pos, F &na, unsigned &nk,
                                                const F *__restrict__ vals,
@@ -1114,26 +1106,28 @@ struct ColLoop {
             const int m = min(nc, 64 - l0);
             int t = l0;
             const int tend = l0 + m;
-            for (; t + 4 <= tend; t += 4) {   // 4 independent LDS reads in flight
-                TM_GATHER_STEP(e0, x0, t)
-                TM_GATHER_STEP(e1, x1, t + 1)
-                TM_GATHER_STEP(e2, x2, t + 2)
-                TM_GATHER_STEP(e3, x3, t + 3)
-                acc[C] = fma(e0.a, x0, acc[C]);
-                acc[C] = fma(e1.a, x1, acc[C]);
-                acc[C] = fma(e2.a, x2, acc[C]);
-                acc[C] = fma(e3.a, x3, acc[C]);
+            for (; t + 4 <= tend; t += 4) {   // 8 independent LDS reads in flight
+                TM_GATHER_STEP(a0, x0, t)
+                TM_GATHER_STEP(a1, x1, t + 1)
+                TM_GATHER_STEP(a2, x2, t + 2)
+                TM_GATHER_STEP(a3, x3, t + 3)
+                acc[C] = fma(a0, x0, acc[C]);
+                acc[C] = fma(a1, x1, acc[C]);
+                acc[C] = fma(a2, x2, acc[C]);
+                acc[C] = fma(a3, x3, acc[C]);
             }
             for (; t < tend; ++t) {
-                TM_GATHER_STEP(e0, x0, t)
-                acc[C] = fma(e0.a, x0, acc[C]);
+                TM_GATHER_STEP(a0, x0, t)
+                acc[C] = fma(a0, x0, acc[C]);
             }
             pos += m;
             nc -= m;
             if ((pos & 63) == 0) {
                 // chunk exhausted: the prefetched chunk replaces it, next prefetch is issued
+                F a_new;
+                make_entry<F, SCALE>(na, nk, dl, zero_off, a_new, kcur);
                 __builtin_amdgcn_wave_barrier();
-                ring[lane] = make_entry<F, SCALE>(na, nk, dl, zero_off);
+                ring[lane] = a_new;
                 __builtin_amdgcn_wave_barrier();
                 const int nxt = pos + 64 + lane;
                 if (nxt < total) {
@@ -1143,8 +1137,8 @@ struct ColLoop {
             }
         }
         if constexpr (C + 1 < GATHER_CPW)
-            ColLoop<F, SCALE, C + 1>::run(acc, slab, ring, dl, zero_off, cntv, pos, na, nk, vals,
-                                          koff, base, total, lane, lane_off);
+            ColLoop<F, SCALE, C + 1>::run(acc, slab, ring, kcur, dl, zero_off, cntv, pos, na, nk,
+                                          vals, koff, base, total, lane, lane_off);
     }
 };
 
@@ -1155,7 +1149,7 @@ struct GatherLds {
     static constexpr int ZERO_OFF = 2 * SLABB;                   // all-zero row
     static constexpr int DL_OFF = ZERO_OFF + ROWB;               // d of the slab rows, 2 buffers
     static constexpr int RING_OFF = DL_OFF + 2 * SLAB_R * (int)sizeof(F);
-    static constexpr int TOTAL = RING_OFF + GATHER_NW * 64 * (int)sizeof(GEntry<F>);
+    static constexpr int TOTAL = RING_OFF + GATHER_NW * 64 * (int)sizeof(F);
 };
 
 template <typename F, bool ORDER_F, bool VEC_OK>
@@ -1184,7 +1178,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
     const int lane_off = lane * (int)sizeof(F);
     F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
-    GEntry<F> *ring = reinterpret_cast<GEntry<F> *>(smem_raw + L::RING_OFF) + wave * 64;
+    F *ring = reinterpret_cast<F *>(smem_raw + L::RING_OFF) + wave * 64;
 
     F acc[GATHER_CPW];
 #pragma unroll
@@ -1345,10 +1339,14 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
             int pos = 0;
             const F *dl = dl_all + buf * SLAB_R;
             const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
-            ring[lane] = make_entry<F, ASYNC>(va, vk, dl, zero_off);
+            F a_cur;
+            unsigned kcur;
+            make_entry<F, ASYNC>(va, vk, dl, zero_off, a_cur, kcur);
             __builtin_amdgcn_wave_barrier();
-            ColLoop<F, ASYNC, 0>::run(acc, smem_raw + buf * SLABB, ring, dl, zero_off, cntv, pos, na,
-                                      nk, vals, koff, base, total, lane, lane_off);
+            ring[lane] = a_cur;
+            __builtin_amdgcn_wave_barrier();
+            ColLoop<F, ASYNC, 0>::run(acc, smem_raw + buf * SLABB, ring, kcur, dl, zero_off, cntv, pos,
+                                      na, nk, vals, koff, base, total, lane, lane_off);
         }
         if (s + 1 < s1 && !(dbg & 4)) finish_slab(s + 1, buf ^ 1);
         __syncthreads();
