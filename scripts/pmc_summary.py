@@ -1,16 +1,14 @@
-"""Average the rocprofv3 --pmc counters per tabmat kernel."""
+"""Average (and min / max over dispatches) of the rocprofv3 --pmc counters per tabmat kernel."""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.Counter()
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     name = r["Kernel_Name"]
     if "tmh::" not in name:
         continue
     key = name.split("tmh::")[1][:44]
-    agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
-    cnt[(key, r["Counter_Name"])] += 1
-for k, v in agg.items():
+    vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in vals.items():
     print(k)
-    for c, x in v.items():
-        print(f"    {c:28s} {x / cnt[(k, c)]:.4g}")
+    for c, xs in v.items():
+        print(f"    {c:28s} {sum(xs) / len(xs):.4g}   (min {min(xs):.4g}  max {max(xs):.4g}  n={len(xs)})")
