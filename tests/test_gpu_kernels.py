@@ -137,7 +137,8 @@ def test_dense_matvec_stream_path(dtype, k):
 # ------------------------------------------------------------------ K2 sparse sandwich
 @pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("n,m,dens", [(200, 50, 0.05), (5000, 130, 0.05), (20000, 512, 0.05),
-                                      (3000, 300, 0.3), (1000, 7, 0.9)])
+                                      (3000, 300, 0.3), (1000, 7, 0.9), (8000, 256, 0.09),
+                                      (4001, 384, 0.06)])
 def test_sparse_sandwich(idx_dtype, n, m, dens):
     import tabmat_amd as tm
 
