@@ -54,7 +54,7 @@ constexpr int tri_row(int t) {
     return r;
 }
 
-enum LoadMode { LOAD_C_VEC = 0, LOAD_C_GEN = 1, LOAD_F_GEN = 2 };
+enum LoadMode { LOAD_C_VEC = 0, LOAD_C_GEN = 1, LOAD_F_GEN = 2, LOAD_F_VEC = 3 };
 
 // RECT = false: lower-triangular tiles of one NBLK-block panel (syrk proper).
 // RECT = true : the NBLK/2 x NBLK/2 off-diagonal tiles (row blocks NBLK/2.., column blocks
@@ -81,7 +81,13 @@ struct SyrkCfg {
     static constexpr int NVEC = ELEMS / VEC;            // 16-byte vectors per chunk
     static constexpr int VITER = (NVEC + THREADS - 1) / THREADS;
     static constexpr int NSTAGE = (PER_THREAD > VITER * VEC) ? PER_THREAD : VITER * VEC;
-    static constexpr size_t LDS = sizeof(F) * (size_t)(2 * RS * LDW + 2 * RS);
+    // LOAD_F_VEC keeps the chunk COLUMN-major in LDS ([W][LDR], rows fastest) so that the 16-byte
+    // vectors of an F-ordered X (2 / 4 consecutive rows of one column) are stored as they come.
+    // LDR = RS + 2 (f64) / RS + 4 (f32): the MFMA fragment read lane -> (column 16b + (lane&15),
+    // row 4g + (lane>>4)) is then bank-conflict free (18 i + g, resp. 20 i + g, distinct mod 32 / 64).
+    static constexpr int LDR = RS + (sizeof(F) == 8 ? 2 : 4);
+    static constexpr int CHUNK_ELEMS = (RS * LDW > W * LDR) ? RS * LDW : W * LDR;
+    static constexpr size_t LDS = sizeof(F) * (size_t)(2 * CHUNK_ELEMS + 2 * RS);
 };
 
 template <typename F, int NBLK, bool RECT, int WID, int... S>
@@ -118,7 +124,7 @@ __device__ __forceinline__ void syrk_wave_store(
 
 // HALF = 0 / 1: first / second half of the chunk's row groups (the staging of the next chunk is
 // issued between the two halves, see syrk_kernel).
-template <typename F, int NBLK, bool RECT, int WID, int HALF>
+template <typename F, int NBLK, bool RECT, int WID, int HALF, bool FORD>
 __device__ __forceinline__ void syrk_wave_main(
     const F *__restrict__ lbuf, const F *__restrict__ dbuf,
     typename Mfma<F>::acc_t (&acc)[SyrkCfg<F, NBLK, RECT>::MAXT], int lane) {
@@ -134,11 +140,11 @@ __device__ __forceinline__ void syrk_wave_main(
     for (int g = GB; g < NG; ++g) {
         const int rl = 4 * g + (lane >> 4);
         const F dv = dbuf[rl];
-        const F *lrow = lbuf + rl * C::LDW + (lane & 15);
+        const F *lrow = FORD ? lbuf + (lane & 15) * C::LDR + rl : lbuf + rl * C::LDW + (lane & 15);
         F xa[NBLK], xb[NBLK];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
-            xb[b] = lrow[16 * b];
+            xb[b] = lrow[FORD ? 16 * b * C::LDR : 16 * b];
             xa[b] = dv * xb[b];
         }
         syrk_wave_step<F, NBLK, RECT, WID>(xa, xb, acc, std::make_integer_sequence<int, C::MAXT>{});
@@ -156,8 +162,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     using C = SyrkCfg<F, NBLK, RECT>;
     using acc_t = typename Mfma<F>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *lds = reinterpret_cast<F *>(smem_raw);            // [2][RS][LDW]
-    F *dl = lds + 2 * C::RS * C::LDW;                    // [2][RS]
+    constexpr bool FORD = MODE == LOAD_F_VEC;
+    F *lds = reinterpret_cast<F *>(smem_raw);            // [2][RS][LDW]  (LOAD_F_VEC: [2][W][LDR])
+    F *dl = lds + 2 * C::CHUNK_ELEMS;                    // [2][RS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,6 +207,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
                 for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
             }
+        } else if (MODE == LOAD_F_VEC) {
+            // 16-byte vector loads down the columns of an F-ordered X: q -> (column, row vector)
+            constexpr int VPC = C::RS / C::VEC;
+#pragma unroll
+            for (int i = 0; i < C::VITER; ++i) {
+                const int q = tid + i * C::THREADS;
+                const int c = q / VPC;
+                const int64_t t = tb + (q % VPC) * C::VEC;
+                typedef F vec_t __attribute__((ext_vector_type(C::VEC)));
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) v[e] = F(0);
+                if (q < C::NVEC && c < n_cols) {
+                    const F *src = X + (int64_t)c * n + t;
+                    if (t + C::VEC <= t1) {
+                        v = *reinterpret_cast<const vec_t *>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < C::VEC; ++e)
+                            if (t + e < t1) v[e] = src[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
+            }
         } else if (MODE == LOAD_C_GEN) {
 #pragma unroll
             for (int i = 0; i < C::PER_THREAD; ++i) {
@@ -234,9 +266,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     };
 
     auto store_chunk = [&](int buf) {
-        F *lb = lds + buf * C::RS * C::LDW;
+        F *lb = lds + buf * C::CHUNK_ELEMS;
         if (tid < C::RS) dl[buf * C::RS + tid] = dstage;
-        if (MODE == LOAD_C_VEC) {
+        if (MODE == LOAD_F_VEC) {
+            constexpr int VPC = C::RS / C::VEC;
+#pragma unroll
+            for (int i = 0; i < C::VITER; ++i) {
+                const int q = tid + i * C::THREADS;
+                typedef F vec_t __attribute__((ext_vector_type(C::VEC)));
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < C::VEC; ++e) v[e] = stage[i * C::VEC + e];
+                if (q < C::NVEC)
+                    *reinterpret_cast<vec_t *>(lb + (q / VPC) * C::LDR + (q % VPC) * C::VEC) = v;
+            }
+        } else if (MODE == LOAD_C_VEC) {
             constexpr int VPR = C::W / C::VEC;
 #pragma unroll
             for (int i = 0; i < C::VITER; ++i) {
@@ -282,12 +326,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         __syncthreads();
         for (int ch = 0; ch < nchunk; ++ch) {
             const int buf = ch & 1;
-            const F *lb = lds + buf * C::RS * C::LDW;
+            const F *lb = lds + buf * C::CHUNK_ELEMS;
             const F *db = dl + buf * C::RS;
-            syrk_wave_main<F, NBLK, RECT, WID, 0>(lb, db, acc, lane);
+            syrk_wave_main<F, NBLK, RECT, WID, 0, FORD>(lb, db, acc, lane);
             if (ch + 1 < nchunk) store_chunk(buf ^ 1);
             if (ch + 2 < nchunk) load_chunk(ch + 2);
-            syrk_wave_main<F, NBLK, RECT, WID, 1>(lb, db, acc, lane);
+            syrk_wave_main<F, NBLK, RECT, WID, 1, FORD>(lb, db, acc, lane);
             __syncthreads();
         }
         syrk_wave_store<F, NBLK, RECT, WID>(acc, dst, lane, std::make_integer_sequence<int, C::MAXT>{});
@@ -359,7 +403,11 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
     F *tmp = part + (size_t)nblk * C::T * 256;          // [T][256]
     const bool vec_ok = !order_f && cols == nullptr && (m % C::VEC == 0) &&
                         ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const int mode = order_f ? LOAD_F_GEN : (vec_ok ? LOAD_C_VEC : LOAD_C_GEN);
+    // (the 256-column f32 panel has no registers to spare for the column-major addressing)
+    const bool fvec_ok = order_f && cols == nullptr && rows == nullptr && (n % C::VEC == 0) &&
+                         ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                         !(sizeof(F) == 4 && NBLK == 16 && !RECT);
+    const int mode = order_f ? (fvec_ok ? LOAD_F_VEC : LOAD_F_GEN) : (vec_ok ? LOAD_C_VEC : LOAD_C_GEN);
     auto go = [&](auto kern) -> int {
         if (C::LDS > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -374,6 +422,7 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
     int rc;
     if (mode == LOAD_C_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_C_VEC, RECT>);
     else if (mode == LOAD_C_GEN) rc = go(&syrk_kernel<F, NBLK, LOAD_C_GEN, RECT>);
+    else if (mode == LOAD_F_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_F_VEC, RECT>);
     else rc = go(&syrk_kernel<F, NBLK, LOAD_F_GEN, RECT>);
     if (rc) return rc;
     hipLaunchKernelGGL((syrk_reduce_kernel<F>), dim3(C::T), dim3(256, 4), 0, st, part, (int)nblk,
@@ -722,6 +771,62 @@ __global__ __launch_bounds__(256) void dense_rmatvec_f_kernel(
     }
 }
 
+// F-order fast path (all rows, all columns, 16-byte aligned columns): a block owns a slab of
+// FRS rows whose v (and, for K7, nothing else) is staged in LDS once; its 4 waves then take the
+// columns in turn and stream the slab part of each column with 16-byte nontemporal loads (lane
+// <-> VEC consecutive rows, 4 loads in flight), multiply with v from LDS, reduce across the wave
+// and issue one atomic per (block, column).  SQ: weighted squared deviations (K7).
+constexpr int FRS = 8192;
+
+template <typename F, bool SQ>
+__global__ __launch_bounds__(256) void dense_rmatvec_f_stream_kernel(
+    const F *__restrict__ X, int64_t n, int64_t m, const F *__restrict__ v,
+    const F *__restrict__ shift, F *__restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(F);
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ __attribute__((aligned(16))) F vl[FRS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * FRS;
+    const int nr = (int)min((int64_t)FRS, n - t0);          // rows of this slab (n % VEC == 0)
+    for (int i = threadIdx.x * VEC; i < FRS; i += 256 * VEC) {
+        vec_t w;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[e] = F(0);
+        if (i < nr) w = *reinterpret_cast<const vec_t *>(v + t0 + i);
+        *reinterpret_cast<vec_t *>(vl + i) = w;
+    }
+    __syncthreads();
+    constexpr int UN = 4;
+    for (int64_t c = wave; c < m; c += 4) {
+        const F *xc = X + c * n + t0;
+        const F sh = SQ ? shift[c] : F(0);
+        F acc = F(0);
+        for (int r0 = lane * VEC; r0 < nr; r0 += 64 * VEC * UN) {
+            vec_t x[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = min(r0 + u * 64 * VEC, nr - VEC);
+                x[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(xc + r));
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = r0 + u * 64 * VEC;
+                if (r < nr) {
+                    const vec_t w = *reinterpret_cast<const vec_t *>(vl + r);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const F xv = SQ ? x[u][e] - sh : x[u][e];
+                        acc = fma(SQ ? xv * xv : xv, w[e], acc);
+                    }
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomic_add(&out[c], acc);
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K7  out[j] += sum_i w[i] * (X[i, j] - shift[j])^2      (ext/dense.pyx:103-122,
 // transpose_square_dot_weights; used once per standardize()).  Same decomposition as rmatvec.
@@ -780,6 +885,13 @@ static int run_dense_col_sq_dev(const F *X, int64_t n, int64_t m, int order_f, c
         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0) {
         hipLaunchKernelGGL((dense_rmatvec_c_stream_kernel<F, true>), dim3((unsigned)nblk), dim3(256), 0,
                            st, X, n, m, w, shift, rpb, out);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
+    if (order_f && n % VEC == 0 && n >= VEC &&
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        hipLaunchKernelGGL((dense_rmatvec_f_stream_kernel<F, true>), dim3((unsigned)ceil_div(n, FRS)),
+                           dim3(256), 0, st, X, n, m, w, shift, out);
         TM_LAUNCH_CHECK();
         return TM_OK;
     }
@@ -854,6 +966,15 @@ static int run_dense_rmatvec(const F *X, int64_t n, int64_t m, int order_f, cons
         prof_begin(st);
         hipLaunchKernelGGL((dense_rmatvec_c_stream_kernel<F, false>), dim3((unsigned)nblk), dim3(256),
                            0, st, X, n, m, v, (const F *)nullptr, rpb, out);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
+    if (order_f && !rows && !cols && n % VEC == 0 && n >= VEC &&
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        prof_begin(st);
+        hipLaunchKernelGGL((dense_rmatvec_f_stream_kernel<F, false>), dim3((unsigned)ceil_div(n, FRS)),
+                           dim3(256), 0, st, X, n, m, v, (const F *)nullptr, out);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;

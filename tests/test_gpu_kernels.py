@@ -134,6 +134,34 @@ def test_dense_matvec_stream_path(dtype, k):
         assert np.abs(got_sd - ref_sd).max() < (1e-9 if dtype == np.float64 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,k", [(1000, 16), (4100, 100), (20000, 128), (16388, 7), (8192, 64)])
+def test_dense_f_order_stream_paths(dtype, n, k):
+    """F-ordered dense blocks (what from_csc / pandas hand over) with n a multiple of the
+    16-byte vector: column-major LDS staging in the syrk (LOAD_F_VEC) and the LDS-staged-v
+    transpose_matvec / K7 kernel (dense_rmatvec_f_stream_kernel), against the C-ordered result."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n + k)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    X = rng.standard_normal((n, k)).astype(dtype)
+    XF = np.asfortranarray(X)
+    d = rng.random(n).astype(dtype)
+    w = rng.standard_normal(n).astype(dtype)
+    X64 = X.astype(np.float64)
+    mf = tm.DenseMatrix(XF)
+    ref = X64.T @ (d.astype(np.float64)[:, None] * X64)
+    assert rel_err(mf.sandwich(d), ref) < tol
+    assert rel_err(mf.sandwich(d), _orc().dense_sandwich(XF, d, None, None)) < tol
+    ref_t = X64.T @ w.astype(np.float64)
+    assert np.abs(mf.transpose_matvec(w) - ref_t).max() / max(1.0, np.abs(ref_t).max()) < tol
+    wts = rng.random(n).astype(dtype)
+    wts /= wts.sum()
+    means = (X64 * wts[:, None].astype(np.float64)).sum(axis=0)
+    ref_sd = np.sqrt((((X64 - means) ** 2) * wts[:, None]).sum(axis=0))
+    assert np.abs(mf._get_col_stds(wts, means.astype(dtype)) - ref_sd).max() < (1e-9 if dtype == np.float64 else 2e-3)
+
+
 # ------------------------------------------------------------------ K2 sparse sandwich
 @pytest.mark.parametrize("idx_dtype", [np.int32, np.int64])
 @pytest.mark.parametrize("n,m,dens", [(200, 50, 0.05), (5000, 130, 0.05), (20000, 512, 0.05),
