@@ -1075,7 +1075,9 @@ constexpr int GATHER_THREADS = GATHER_NW * 64;
 // SCALE: the dense slab in LDS holds B unscaled (async global->LDS copy); d is folded into the
 // stream value when an entry enters the ring, and entries of rows with d == 0 are redirected to
 // an all-zero LDS row so that excluded rows contribute exactly nothing.
-template <typename F, bool SCALE>
+// CM: column-major LDS slab (F-ordered B): the stream's row offset row * 64 * sizeof(F) becomes
+// row * sizeof(F).
+template <typename F, bool SCALE, bool CM>
 __device__ __forceinline__ void make_entry(F a, unsigned ko, const F *__restrict__ dl,
                                            unsigned zero_off, F &a_out, unsigned &ko_out) {
     if (SCALE) {
@@ -1084,11 +1086,11 @@ __device__ __forceinline__ void make_entry(F a, unsigned ko, const F *__restrict
         ko_out = dk != F(0) ? ko : zero_off;
     } else {
         a_out = a;
-        ko_out = ko;
+        ko_out = CM ? ko >> 6 : ko;
     }
 }
 
-template <typename F, bool SCALE, int C>
+template <typename F, bool SCALE, bool CM, int C>
 struct ColLoop {
     // processes static column C of the wave's group, then recurses to C + 1
     static __device__ __forceinline__ void run(F (&acc)[GATHER_CPW],
@@ -1125,7 +1127,7 @@ struct ColLoop {
             if ((pos & 63) == 0) {
                 // chunk exhausted: the prefetched chunk replaces it, next prefetch is issued
                 F a_new;
-                make_entry<F, SCALE>(na, nk, dl, zero_off, a_new, kcur);
+                make_entry<F, SCALE, CM>(na, nk, dl, zero_off, a_new, kcur);
                 __builtin_amdgcn_wave_barrier();
                 ring[lane] = a_new;
                 __builtin_amdgcn_wave_barrier();
@@ -1137,15 +1139,21 @@ struct ColLoop {
             }
         }
         if constexpr (C + 1 < GATHER_CPW)
-            ColLoop<F, SCALE, C + 1>::run(acc, slab, ring, kcur, dl, zero_off, cntv, pos, na, nk,
+            ColLoop<F, SCALE, CM, C + 1>::run(acc, slab, ring, kcur, dl, zero_off, cntv, pos, na, nk,
                                           vals, koff, base, total, lane, lane_off);
     }
 };
 
-template <typename F>
+// ORDER_F: the slab is kept COLUMN-major in LDS ([64 columns][SLAB_R + 1 rows], rows fastest,
+// odd column stride): the vectors of an F-ordered B (consecutive rows of one column) are stored
+// contiguously, and the gather's read  lane <-> column, uniform row  hits 64 distinct addresses
+// (lane * (SLAB_R + 1) + row) without bank conflicts.  Row offsets of the stream (row * ROWB for the
+// row-major slab) are divided by 64 when a chunk enters the ring.
+template <typename F, bool ORDER_F>
 struct GatherLds {
-    static constexpr int ROWB = 64 * (int)sizeof(F);             // bytes per LDS slab row
-    static constexpr int SLABB = SLAB_R * ROWB;                  // bytes per slab buffer
+    static constexpr int ROWB = 64 * (int)sizeof(F);             // bytes per LDS slab row (row-major)
+    static constexpr int COLB = (SLAB_R + 1) * (int)sizeof(F);   // bytes per LDS slab column (column-major)
+    static constexpr int SLABB = ORDER_F ? ((64 * COLB + 15) / 16) * 16 : SLAB_R * ROWB;  // per buffer
     static constexpr int ZERO_OFF = 2 * SLABB;                   // all-zero row
     static constexpr int DL_OFF = ZERO_OFF + ROWB;               // d of the slab rows, 2 buffers
     static constexpr int RING_OFF = DL_OFF + 2 * SLAB_R * (int)sizeof(F);
@@ -1159,7 +1167,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
     int nB, const F *__restrict__ d, F *__restrict__ ws, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using L = GatherLds<F>;
+    using L = GatherLds<F, ORDER_F>;
     constexpr bool ASYNC = !ORDER_F && VEC_OK;   // global_load_lds staging, d folded into the stream
     constexpr int VEC = 16 / (int)sizeof(F);
     constexpr int ROWB = L::ROWB;
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const int j0 = blockIdx.y * 64;
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
-    const int lane_off = lane * (int)sizeof(F);
+    const int lane_off = ORDER_F ? lane * L::COLB : lane * (int)sizeof(F);
     F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
     F *ring = reinterpret_cast<F *>(smem_raw + L::RING_OFF) + wave * 64;
 
@@ -1188,7 +1196,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
 
     // ---------------- staging of the dense slab ----------------
     vec_t stage[ASYNC ? 1 : NV];
-    vec_t dstage[ORDER_F ? NV : 1];
+    vec_t dstage[1];   // ORDER_F: d of the thread's row vector (the same rows for all of its NV vectors)
     F dsc = F(0);
     // ASYNC: every wave copies NV KiB-sized pieces (64 lanes x 16 B) of the slab straight into
     // LDS with global_load_lds (no VGPRs, no ds_write pass); d of the slab rows goes to LDS (dl).
@@ -1233,13 +1241,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 if (VEC_OK) {
                     const int64_t kk = min(k, n - VEC);
                     stage[ASYNC ? 0 : i] = *reinterpret_cast<const vec_t *>(B + (int64_t)c * n + kk);
-                    dstage[ORDER_F ? i : 0] = *reinterpret_cast<const vec_t *>(d + kk);
+                    if (i == 0) dstage[0] = *reinterpret_cast<const vec_t *>(d + kk);
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         const int64_t kk = min(k + e, n - 1);
                         stage[ASYNC ? 0 : i][e] = B[(int64_t)c * n + kk];
-                        dstage[ORDER_F ? i : 0][e] = d[kk];
+                        if (i == 0) dstage[0][e] = d[kk];
                     }
                 }
             }
@@ -1274,9 +1282,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
                 const bool cok = j0 + c < nB;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const F dv = dstage[ORDER_F ? i : 0][e];
+                    const F dv = dstage[0][e];
                     const bool ok = cok && (s * SLAB_R + row + e < n) && dv != F(0);
-                    *reinterpret_cast<F *>(dst + (row + e) * ROWB + c * (int)sizeof(F)) =
+                    *reinterpret_cast<F *>(dst + c * L::COLB + (row + e) * (int)sizeof(F)) =
                         ok ? dv * stage[ASYNC ? 0 : i][e] : F(0);
                 }
             }
@@ -1341,11 +1349,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
             const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
             F a_cur;
             unsigned kcur;
-            make_entry<F, ASYNC>(va, vk, dl, zero_off, a_cur, kcur);
+            make_entry<F, ASYNC, ORDER_F>(va, vk, dl, zero_off, a_cur, kcur);
             __builtin_amdgcn_wave_barrier();
             ring[lane] = a_cur;
             __builtin_amdgcn_wave_barrier();
-            ColLoop<F, ASYNC, 0>::run(acc, smem_raw + buf * SLABB, ring, kcur, dl, zero_off, cntv, pos,
+            ColLoop<F, ASYNC, ORDER_F, 0>::run(acc, smem_raw + buf * SLABB, ring, kcur, dl, zero_off, cntv, pos,
                                       na, nk, vals, koff, base, total, lane, lane_off);
         }
         if (s + 1 < s1 && !(dbg & 4)) finish_slab(s + 1, buf ^ 1);
@@ -1398,7 +1406,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    const size_t lds = (size_t)GatherLds<F>::TOTAL;
+    const size_t lds = order_f ? (size_t)GatherLds<F, true>::TOTAL : (size_t)GatherLds<F, false>::TOTAL;
     // 16-byte vector loads need aligned bases and row/column strides that keep every vector
     // 16-byte aligned and entirely inside the matrix
     constexpr int VEC = 16 / (int)sizeof(F);
