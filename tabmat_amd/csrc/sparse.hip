@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff,
     const unsigned short *__restrict__ cnt, const int64_t *__restrict__ gptr, int n_groups,
     int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
-    int nB, const F *__restrict__ d, F *__restrict__ ws, int dbg) {
+    int nB, const F *__restrict__ d, F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using L = GatherLds<F, ORDER_F>;
     constexpr bool ASYNC = !ORDER_F && VEC_OK;   // global_load_lds staging, d folded into the stream
@@ -1340,10 +1340,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
         unsigned vk = h_vk, nk = h_nk;
         if (s + 1 < s1) {
             load_head();                  // head(s + 1) from meta(s + 1), loaded last iteration
-            if (!(dbg & 2)) issue_slab(s + 1, buf ^ 1);
+            issue_slab(s + 1, buf ^ 1);
         }
         load_meta(s + 2);
-        if (active && total > 0 && !(dbg & 1)) {
+        if (active && total > 0) {
             int pos = 0;
             const F *dl = dl_all + buf * SLAB_R;
             const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
             ColLoop<F, ASYNC, ORDER_F, 0>::run(acc, smem_raw + buf * SLABB, ring, kcur, dl, zero_off, cntv, pos,
                                       na, nk, vals, koff, base, total, lane, lane_off);
         }
-        if (s + 1 < s1 && !(dbg & 4)) finish_slab(s + 1, buf ^ 1);
+        if (s + 1 < s1) finish_slab(s + 1, buf ^ 1);
         __syncthreads();
     }
     if (active) {
@@ -1421,8 +1421,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS), lds,
-                       st, vals, koff, cnt, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws,
-                       getenv("TM_GATHER_DBG") ? atoi(getenv("TM_GATHER_DBG")) : 0);
+                       st, vals, koff, cnt, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false,
