@@ -413,9 +413,9 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
                            rows, n_iter, rpb, cols, n_cols, part);
-    prof_end(st);
+        prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
     };
@@ -915,9 +915,9 @@ static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const
     if (order_f) {
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256), NUM_CU * 8);
         prof_begin(st);
-    hipLaunchKernelGGL((dense_matvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, n,
+        hipLaunchKernelGGL((dense_matvec_f_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, n,
                            v, rows, n_iter, cols, (int)n_cols, out);
-    prof_end(st);
+        prof_end(st);
     } else {
         constexpr int VEC = 16 / (int)sizeof(F);
         const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
@@ -942,9 +942,9 @@ static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const
         }
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 4), NUM_CU * 8);
         prof_begin(st);
-    hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
+        hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
                            v, rows, n_iter, cols, (int)n_cols, out);
-    prof_end(st);
+        prof_end(st);
     }
     TM_LAUNCH_CHECK();
     return TM_OK;

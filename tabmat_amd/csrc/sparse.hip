@@ -774,9 +774,9 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, data, ind, ptr, v, rows,
                            n_iter, rpb, col_map, (int)n_out, ws, out, square);
-    prof_end(st);
+        prof_end(st);
         TM_LAUNCH_CHECK();
         return launch_reduce_partials<F>(ws, n_out, (int)nblk, 1, out, n_out, true, st);
     }
@@ -836,10 +836,10 @@ static int run_csr_dense(const F *data, const int32_t *ind, const int64_t *ptr, 
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(256), lds, st, data,
                            ind, ptr, B, n, r, d, rows, n_iter, rpb, a_map, (int)nA, B_cols, (int)nB,
                            ws, stride);
-    prof_end(st);
+        prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
     };
