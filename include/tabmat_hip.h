@@ -139,16 +139,18 @@ int tm_sparse_sandwich_f64(const double *csr_data, const int32_t *csr_indices,
                            const int32_t *rows, int64_t n_rows, const int32_t *cols,
                            int64_t n_cols, double *out, void *stream);
 
-/* Unrestricted fast path of the same product on precomputed per-row chunk pointers:
- * cptr[k * (NCH + 1) + c] = index (into csr_data / csr_indices, < 2^31) of the first entry of
- * row k whose column is >= c * tm_sparse_chunk_cols(), c = 0 .. NCH = ceil(m / chunk_cols).
- * nnz = number of stored entries (rows must be sorted by column and duplicate-free).
+/* Unrestricted fast path of the same product on the CHUNK-MAJOR twin of the block: the nnz
+ * entries regrouped by column chunk c = column / tm_sparse_chunk_cols(), inside a chunk by row,
+ * column order kept (cm_data / cm_indices, global column numbers);
+ * cptr[c * (n + 1) + k] = index (into cm_data / cm_indices, < 2^31) of the first entry of row k in
+ * chunk c, cptr[c * (n + 1) + n] = end of chunk c; c = 0 .. NCH - 1, NCH = ceil(m / chunk_cols).
+ * Rows must be sorted by column and duplicate-free.
  * Restrictions are applied by the host side (masked d, sub-selection of the result). */
 int tm_sparse_chunk_cols(void);
-int tm_sparse_sandwich_chunked_f32(const float *csr_data, const int32_t *csr_indices,
+int tm_sparse_sandwich_chunked_f32(const float *cm_data, const int32_t *cm_indices,
                                    const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                    const float *d, float *out, void *stream);
-int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_indices,
+int tm_sparse_sandwich_chunked_f64(const double *cm_data, const int32_t *cm_indices,
                                    const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                    const double *d, double *out, void *stream);
 

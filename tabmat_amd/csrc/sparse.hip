@@ -408,11 +408,14 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
 
 // ---------------------------------------------------------------------------------------
 // K2 (v3)  unrestricted sparse self sandwich on precomputed per-row CHUNK POINTERS:
-// cptr[k][c] = index of the first entry of row k whose column is >= 128 c (c = 0..NCH), so the
-// entries of row k that fall into tile chunk I are data[cptr[k][I] .. cptr[k][I+1]) -- no
-// ballots, no compaction, no scratch.  One wave per (row, tile) unit; lane (a, b) = (lane>>3,
-// lane&7) loads entry a of the I-list and entry b of the J-list straight from the CSR arrays
-// (L1 hits: a row is ~300 contiguous bytes) and issues one ds_add_f64 into the LDS tile.
+// The block is stored CHUNK-MAJOR: the entries are regrouped by 128-column chunk, inside a chunk by
+// row (column order kept), so chunk c is a CSR matrix of its own whose rows follow each other in
+// memory; cptr[c][k] (an [NCH][n + 1] table) is the start of row k in chunk c.  A tile (I, J)
+// streams chunk I and chunk J: the lists of the 8 rows of a group are ADJACENT (one coalesced
+// ~0.5 KB region per chunk) -- with the row-major CSR they were ~300 B apart and every (row, tile)
+// pulled 4 half-used sectors (32 GB of HBM traffic for 3.2 GB of data; loads alone 4.4 ms).
+// Lane (a, b) = (lane>>3, lane&7) pairs entry a of the I-list with entry b of the J-list and
+// issues one ds_add_f64 into the LDS tile -- no ballots, no compaction.
 // ---------------------------------------------------------------------------------------
 constexpr int K2_ED = 2;   // groups whose entry loads are in flight
 constexpr int K2_NP = 2;   // further groups whose chunk-pointer loads are in flight
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     Ent *sb = scratch + (wave * 2 + 1) * 64;
     const int64_t t0 = (int64_t)blk * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
-    const int stride = nch + 1;
+    const int64_t pstride = n + 1;          // cptr is [nch][n + 1] (chunk-major twin)
 
     // A wave owns GROUPS of 8 consecutive rows (8 lanes per row).  Software pipeline over the
     // groups: the entry loads of a group need its chunk pointers (two dependent memory round
@@ -484,12 +487,13 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         const int64_t k = g0 + lr;
         q.valid = k < t1;
         const int64_t kc = min(k, n - 1);
-        const int32_t *cp = cptr + kc * stride;
+        const int32_t *cpa = cptr + (int64_t)I * pstride + kc;
+        const int32_t *cpb = cptr + (int64_t)J * pstride + kc;
         q.d = d[kc];
-        q.a0 = cp[I];
-        q.a1 = cp[I + 1];
-        q.b0 = cp[J];
-        q.b1 = cp[J + 1];
+        q.a0 = cpa[0];
+        q.a1 = cpa[1];
+        q.b0 = cpb[0];
+        q.b1 = cpb[1];
         return q;
     };
     auto load_entries = [&](const Ptr &q) {   // slots lt and lt + 8 of both lists: 16 entries per list

@@ -62,29 +62,39 @@ class CsrDev:
     def dtype(self):
         return self.data.dtype
 
-    def chunk_ptr(self) -> torch.Tensor:
-        """int32 [n, NCH + 1]: first entry of each row at or after column c * chunk (see
-        tm_sparse_sandwich_chunked_*).  Built once per block (ingest), cached."""
-        cp = getattr(self, "_cptr", None)
-        if cp is None:
+    def chunk_major(self):
+        """(cm_data, cm_indices, cptr int32 [NCH, n + 1]): the entries regrouped by column chunk,
+        inside a chunk by row (see tm_sparse_sandwich_chunked_*).  Built once per block (ingest:
+        one device key sort), cached."""
+        cm = getattr(self, "_cm", None)
+        if cm is None:
             from .._lib import lib
 
             ch = int(lib().tm_sparse_chunk_cols())
-            nch = (self.m + ch - 1) // ch
-            if self.data.numel() >= 2**31:
+            nch = max(1, (self.m + ch - 1) // ch)
+            nnz = int(self.data.numel())
+            if nnz >= 2**31:
                 raise ValueError("chunk pointers need nnz < 2^31")
+            dev = self.data.device
             counts = self.indptr[1:] - self.indptr[:-1]
-            rows = torch.repeat_interleave(
-                torch.arange(self.n, device=self.data.device, dtype=torch.int64), counts)
-            key = rows * nch + torch.div(self.indices.to(torch.int64), ch, rounding_mode="floor")
-            per = torch.bincount(key, minlength=self.n * nch).view(self.n, nch)
-            cp = torch.empty((self.n, nch + 1), dtype=torch.int64, device=self.data.device)
-            cp[:, 0] = self.indptr[:-1]
-            torch.cumsum(per, dim=1, out=cp[:, 1:])
-            cp[:, 1:] += self.indptr[:-1, None]
-            cp = cp.to(torch.int32).contiguous()
-            self._cptr = cp
-        return cp
+            rows = torch.repeat_interleave(torch.arange(self.n, device=dev, dtype=torch.int64), counts)
+            key = torch.div(self.indices.to(torch.int64), ch, rounding_mode="floor") * self.n + rows
+            del rows
+            # CSR rows are column-sorted: a STABLE sort by (chunk, row) keeps the column order
+            key_sorted, perm = torch.sort(key, stable=True)
+            del key
+            cm_data = self.data[perm].contiguous()
+            cm_ind = self.indices[perm].contiguous()
+            del perm
+            per = torch.bincount(key_sorted, minlength=nch * self.n) if nnz else \
+                torch.zeros(nch * self.n, dtype=torch.int64, device=dev)
+            del key_sorted
+            start = (torch.cumsum(per, dim=0) - per).view(nch, self.n)
+            ends = torch.cat([start[1:, 0], torch.tensor([nnz], device=dev, dtype=torch.int64)])
+            cptr = torch.cat([start, ends[:, None]], dim=1).to(torch.int32).contiguous()
+            cm = (cm_data, cm_ind, cptr)
+            self._cm = cm
+        return cm
 
     @staticmethod
     def from_scipy(csr) -> "CsrDev":

@@ -74,13 +74,13 @@ def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
 
 
 def sparse_sandwich_chunked(A: CsrDev, d):
-    """Unrestricted fast path of ext/sparse.pyx:17-77 on per-row chunk pointers (K2 v3)."""
+    """Unrestricted fast path of ext/sparse.pyx:17-77 on the chunk-major twin (K2)."""
     out = D.zeros((A.m, A.m), A.dtype)
     if A.m == 0 or A.n == 0:
         return out
-    cp = A.chunk_ptr()
-    call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(cp),
-         A.n, A.m, int(A.data.numel()), D.p(d), D.p(out), D.stream_ptr())
+    cm_data, cm_ind, cptr = A.chunk_major()
+    call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr),
+         A.n, A.m, int(cm_data.numel()), D.p(d), D.p(out), D.stream_ptr())
     return out
 
 

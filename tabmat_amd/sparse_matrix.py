@@ -113,7 +113,7 @@ class SparseMatrix(MatrixBase):
         return self._slabblk
 
     def to_device(self):
-        self._dev().chunk_ptr()
+        self._dev().chunk_major()
         self._slab()
         return self
 
