@@ -591,16 +591,34 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
+            if (phase == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int nAr = __builtin_amdgcn_readlane(nA, r * 8) - 8 * ha;
-                const int nBr = __builtin_amdgcn_readlane(nB, r * 8) - 8 * hb;
-                if (nAr <= 0 || nBr <= 0) continue;
-                const Ent xa = sa[r * 8 + pa];
-                const Ent xb = sb[r * 8 + pb];
-                if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
-                    atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
-                               xa.val * xb.val);
+                for (int r = 0; r < 8; ++r) {
+                    const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
+                    const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
+                    if (nAr <= 0 || nBr <= 0) continue;
+                    const Ent xa = sa[r * 8 + pa];
+                    const Ent xb = sb[r * 8 + pb];
+                    if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                        atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
+                                   xa.val * xb.val);
+                }
+            } else {
+                // second-half phases: only ~1.5 of the 8 rows have a list longer than 8 -- visit
+                // those (one mask bit per row, at the row's first lane) instead of testing all 8
+                unsigned long long todo =
+                    __builtin_amdgcn_ballot_w64(nA > 8 * ha && nB > 8 * hb) & 0x0101010101010101ull;
+                while (todo) {
+                    const int l0 = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int nAr = __builtin_amdgcn_readlane(nA, l0) - 8 * ha;
+                    const int nBr = __builtin_amdgcn_readlane(nB, l0) - 8 * hb;
+                    const Ent xa = sa[l0 + pa];
+                    const Ent xb = sb[l0 + pb];
+                    if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                        atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
+                                   xa.val * xb.val);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
