@@ -533,10 +533,11 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         const F dk = cur.d;
         // slots beyond the lists carry clamped (duplicate) entries: masked by the n tests below
         Ent ea, eb, ea2, eb2;
-        ea.val = cur.va * dk;   ea.col = cur.ca - i0;
-        eb.val = cur.vb;        eb.col = cur.cb - j0;
-        ea2.val = cur.va2 * dk; ea2.col = cur.ca2 - i0;
-        eb2.val = cur.vb2;      eb2.col = cur.cb2 - j0;
+        // (a slot beyond its list gets column -1: the sign bit of colA | colB masks the pair)
+        ea.val = cur.va * dk;   ea.col = lt < nA ? cur.ca - i0 : -1;
+        eb.val = cur.vb;        eb.col = lt < nB ? cur.cb - j0 : -1;
+        ea2.val = cur.va2 * dk; ea2.col = lt + 8 < nA ? cur.ca2 - i0 : -1;
+        eb2.val = cur.vb2;      eb2.col = lt + 8 < nB ? cur.cb2 - j0 : -1;
         const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
         // four phases over the (A half, B half) blocks; the per-wave scratch holds one half of
         // each list at a time.  ha/hb = which half (0: entries 0..7, 1: entries 8..15).
@@ -566,16 +567,14 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                     if (n0 <= 7 || n1 <= 7) {
                         const bool swap = n1 > 7;                 // the long row must be `low`
                         const int rl = swap ? r + 1 : r, ru = swap ? r : r + 1;
-                        const int nl = swap ? n1 : n0, nu = swap ? n0 : n1;
                         const int row = lower ? rl : ru;
                         const int a = lower ? pa : pb - 1;
                         const int b = lower ? pb : pa;
-                        if (a < (lower ? nl : nu)) {
-                            const Ent xa = sa[row * 8 + a];
-                            const Ent xb = sb[row * 8 + b];
+                        const Ent xa = sa[row * 8 + a];
+                        const Ent xb = sb[row * 8 + b];
+                        if ((xa.col | xb.col) >= 0)
                             atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
                                        xa.val * xb.val);
-                        }
                     } else {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -594,12 +593,9 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             if (phase == 0) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
-                    const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
-                    if (nAr <= 0 || nBr <= 0) continue;
                     const Ent xa = sa[r * 8 + pa];
                     const Ent xb = sb[r * 8 + pb];
-                    if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                    if ((xa.col | xb.col) >= 0 && (I != J || xb.col <= xa.col))
                         atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
                                    xa.val * xb.val);
                 }
@@ -611,11 +607,9 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 while (todo) {
                     const int l0 = __builtin_ctzll(todo);
                     todo &= todo - 1;
-                    const int nAr = __builtin_amdgcn_readlane(nA, l0) - 8 * ha;
-                    const int nBr = __builtin_amdgcn_readlane(nB, l0) - 8 * hb;
                     const Ent xa = sa[l0 + pa];
                     const Ent xb = sb[l0 + pb];
-                    if (pa < nAr && pb < nBr && (I != J || xb.col <= xa.col))
+                    if ((xa.col | xb.col) >= 0 && (I != J || xb.col <= xa.col))
                         atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
                                    xa.val * xb.val);
                 }
