@@ -59,7 +59,9 @@ class SparseMatrix(MatrixBase):
 
     @classmethod
     def from_device(cls, csr: CsrDev):
-        """Wrap a CSR twin that already lives in HBM (no host copy)."""
+        """Wrap a CSR twin that already lives in HBM (no host copy).  The rows must be in
+        canonical form (column indices ascending, no duplicates), as scipy's `sum_duplicates()`
+        leaves them: the sparse self-sandwich enumerates the pairs of a row by entry position."""
         self = cls.__new__(cls)
         self._array = None
         self._array_csr = None
