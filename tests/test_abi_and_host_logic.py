@@ -168,3 +168,34 @@ def test_sparse_matrix_construction():
     assert m.indices.dtype == m.indptr.dtype
     np.testing.assert_allclose(m.toarray(), S.toarray())
     assert m.array_csr.shape == (30, 7)
+
+
+def test_chunk_major_twin_round_trip():
+    """Host-side ingest of the chunk-major twin K2 streams (tabmat_amd/ext/_types.py
+    CsrDev.chunk_major): every 128-column chunk is a CSR matrix of its own, rows adjacent, column
+    order kept (pure host logic on CPU tensors; the kernel consuming it is tested under -m gpu)."""
+    import scipy.sparse as sps
+    import torch
+
+    from tabmat_amd._lib import lib
+    from tabmat_amd.ext._types import CsrDev
+
+    n, m = 300, 300
+    A = sps.random(n, m, density=0.07, format="csr", random_state=5, dtype=np.float64)
+    A.sort_indices()
+    csr = CsrDev(torch.from_numpy(A.data), torch.from_numpy(A.indices.astype(np.int32)),
+                 torch.from_numpy(A.indptr.astype(np.int64)), n, m)
+    data, ind, cptr = (t.numpy() for t in csr.chunk_major())
+    ch = lib().tm_sparse_chunk_cols()
+    nch = (m + ch - 1) // ch
+    assert cptr.shape == (nch, n + 1) and cptr.dtype == np.int32
+    assert cptr[0, 0] == 0 and cptr[-1, -1] == A.nnz
+    B = np.zeros((n, m))
+    for c in range(nch):
+        assert c == 0 or cptr[c, 0] == cptr[c - 1, n]          # chunks follow each other
+        for k in range(n):
+            lo, hi = cptr[c, k], cptr[c, k + 1]
+            cols = ind[lo:hi]
+            assert np.all(cols // ch == c) and np.all(np.diff(cols) > 0)
+            B[k, cols] += data[lo:hi]
+    np.testing.assert_array_equal(B, A.toarray())
