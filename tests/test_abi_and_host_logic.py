@@ -199,3 +199,44 @@ def test_chunk_major_twin_round_trip():
             assert np.all(cols // ch == c) and np.all(np.diff(cols) > 0)
             B[k, cols] += data[lo:hi]
     np.testing.assert_array_equal(B, A.toarray())
+
+
+def test_slab_stream_round_trip():
+    """Host-side ingest of the slab-blocked stream of the gather / cat x sparse kernels
+    (tabmat_amd/ext/_types.py SlabCsc): runs per (slab, column), group pointers, row offsets and
+    the in-group column of every entry reproduce the matrix (pure host logic on CPU tensors)."""
+    import scipy.sparse as sps
+    import torch
+
+    from tabmat_amd._lib import lib
+    from tabmat_amd.ext._types import CsrDev, SlabCsc
+
+    n, m = 700, 70
+    A = sps.random(n, m, density=0.08, format="csr", random_state=3, dtype=np.float64)
+    A.sort_indices()
+    csr = CsrDev(torch.from_numpy(A.data), torch.from_numpy(A.indices.astype(np.int32)),
+                 torch.from_numpy(A.indptr.astype(np.int64)), n, m)
+    S = SlabCsc.from_csr(csr)
+    R, C = lib().tm_slab_rows(), lib().tm_slab_group_cols()
+    G = (m + C - 1) // C
+    mpad = G * C
+    ns = (n + R - 1) // R
+    vals, koff, ecol = S.vals.numpy(), S.koff.numpy(), S.ecol.numpy()
+    cnt = S.cnt.numpy().astype(np.uint16).reshape(ns, mpad)
+    gptr = S.gptr.numpy()
+    assert len(vals) == A.nnz and gptr[-1] == A.nnz
+    B = np.zeros((n, m))
+    pos = 0
+    for s in range(ns):
+        for c in range(mpad):
+            if c % C == 0:
+                assert gptr[s * G + c // C] == pos
+            last = -1
+            for e in range(pos, pos + int(cnt[s, c])):
+                assert ecol[e] == c % C
+                r = koff[e] // (64 * 8)
+                assert r > last                      # rows ascending inside a run
+                last = r
+                B[s * R + r, c] += vals[e]
+            pos += int(cnt[s, c])
+    np.testing.assert_array_equal(B, A.toarray())
