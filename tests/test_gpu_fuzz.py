@@ -1,0 +1,90 @@
+"""-m gpu: seeded random SplitMatrix configurations (block mix, shapes, storage orders, dtypes,
+drop_first / missing codes, row and column restrictions) against a dense float64 numpy evaluation
+of the same matrix -- a net under the specialised fast paths (streams, twins, packed tiles), whose
+dispatch depends on shapes and alignments.  Tolerances: float64 1e-10 relative (north_star), float32
+blocks 5e-4 relative to the largest entry of the result."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_split(rng, dtype):
+    import tabmat_amd as tm
+
+    n = int(rng.choice([1, 7, 64, 129, 1000, 4096, 5003, 20000]))
+    blocks, dense_parts = [], []
+    kinds = rng.permutation(["dense", "sparse", "cat", "cat", "sparse", "dense"])[: rng.integers(1, 6)]
+    for kind in kinds:
+        if kind == "dense":
+            k = int(rng.choice([1, 3, 16, 17, 64, 128, 130]))
+            X = rng.standard_normal((n, k)).astype(dtype)
+            if rng.random() < 0.5:
+                X = np.asfortranarray(X)
+            blocks.append(tm.DenseMatrix(X))
+            dense_parts.append(X.astype(np.float64))
+        elif kind == "sparse":
+            m = int(rng.choice([1, 5, 33, 128, 200, 513]))
+            dens = float(rng.choice([0.0, 0.02, 0.05, 0.12, 0.4]))
+            S = sps.random(n, m, density=dens, format="csc", random_state=rng).astype(dtype)
+            blocks.append(tm.SparseMatrix(S))
+            dense_parts.append(S.toarray().astype(np.float64))
+        else:
+            ncat = int(rng.choice([1, 2, 5, 40, 300]))
+            drop = bool(rng.random() < 0.4)
+            codes = rng.integers(0, ncat, n)
+            missing = rng.random() < 0.3
+            if missing:
+                codes = np.where(rng.random(n) < 0.1, -1, codes)
+            blocks.append(tm.CategoricalMatrix(codes, categories=np.arange(ncat), drop_first=drop,
+                                               dtype=dtype, cat_missing_method="zero" if missing else "fail"))
+            oh = np.zeros((n, ncat))
+            ok = codes >= 0
+            oh[np.nonzero(ok)[0], codes[ok]] = 1.0
+            dense_parts.append(oh[:, int(drop):])
+    E = np.hstack(dense_parts) if dense_parts else np.zeros((n, 0))
+    keep = [b for b, p in zip(blocks, dense_parts) if p.shape[1] > 0]
+    if not keep:
+        return None, None
+    X = tm.SplitMatrix(keep) if len(keep) > 1 else keep[0]
+    return X, E
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TM_FUZZ_CASES", "40"))))
+def test_random_split_products(seed):
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(1000 + seed)
+    dtype = np.float64 if seed % 4 else np.float32
+    X, E = _random_split(rng, dtype)
+    if X is None:
+        pytest.skip("degenerate draw")
+    n, p = E.shape
+    tol = 1e-10 if dtype == np.float64 else 5e-4
+    d = rng.random(n).astype(dtype)
+    d[rng.random(n) < 0.1] = 0.0
+    v = rng.standard_normal(p).astype(dtype)
+    w = rng.standard_normal(n).astype(dtype)
+    d64, v64, w64 = d.astype(np.float64), v.astype(np.float64), w.astype(np.float64)
+
+    def close(a, b):
+        a = np.asarray(a.toarray() if sps.issparse(a) else a, dtype=np.float64)
+        scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+        assert a.shape == b.shape
+        assert float(np.abs(a - b).max()) / scale < tol
+
+    close(X.sandwich(d), E.T @ (d64[:, None] * E))
+    close(X.matvec(v), E @ v64)
+    close(X.transpose_matvec(w), E.T @ w64)
+    rows = np.sort(rng.choice(n, size=max(1, n // 2), replace=False)).astype(np.int32)
+    cols = np.sort(rng.choice(p, size=max(1, (2 * p) // 3), replace=False)).astype(np.int32)
+    Er = E[np.ix_(rows, cols)]
+    close(X.sandwich(d, rows, cols), Er.T @ (d64[rows, None] * Er))
+    close(X.matvec(v, cols), E[:, cols] @ v64[cols])
+    close(X.transpose_matvec(w, rows, cols), Er.T @ w64[rows])
+    if isinstance(X, tm.SplitMatrix):
+        Xd = X.to_device()
+        close(Xd.sandwich(d), E.T @ (d64[:, None] * E))
