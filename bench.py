@@ -35,6 +35,18 @@ MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (AMD datasheet; not in the g
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
 
 
+def _baseline_metric():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "SplitMatrix.sandwich GFLOP/s + effective HBM GB/s, 10M\u00d71k mixed"
+
+
+METRIC = _baseline_metric()
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,7 +348,7 @@ def main():
             "cfg3": f"CategoricalMatrix.sandwich {n_local} rows x 10k categories float64 (BASELINE configs[2])",
         }
         result = {
-            "metric": "SplitMatrix.sandwich GFLOP/s + effective HBM GB/s, 10M x 1k mixed",
+            "metric": METRIC,
             "value": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
             "unit": "GB/s",
             "gflops": round(flops / (ms_per_step * 1e-3) / 1e9, 1),
