@@ -565,6 +565,25 @@ __global__ __launch_bounds__(256) void dense_matvec_c_kernel(
 // LPR = lanes per row (m / VEC when that is a power of two <= 64; 64 with NL loads per row else).
 constexpr int MV_R = 8;
 
+// value of lane (lane ^ S) for S in {1, 2, 4, 8} with DPP moves (no LDS crossbar)
+template <int S>
+__device__ __forceinline__ int dpp_xor_i32(int v) {
+    if constexpr (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    else if constexpr (S == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);                 // row_half_mirror: i ^ 7
+        return __builtin_amdgcn_update_dpp(0, m, 0x1B, 0xF, 0xF, false);                         // quad_perm [3,2,1,0]: ^ 3
+    } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);                     // row_ror:8: i ^ 8
+}
+template <int S>
+__device__ __forceinline__ double dpp_xor(double v) {
+    return __hiloint2double(dpp_xor_i32<S>(__double2hiint(v)), dpp_xor_i32<S>(__double2loint(v)));
+}
+template <int S>
+__device__ __forceinline__ float dpp_xor(float v) {
+    return __int_as_float(dpp_xor_i32<S>(__float_as_int(v)));
+}
+
 template <typename F, int LPR, int NL>
 __global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__restrict__ X,
                                                                    int64_t n, int64_t m,
@@ -604,44 +623,47 @@ __global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__r
                 for (int e = 0; e < VEC; ++e) a = fma(x[r][q][e], vv[q][e], a);
             acc[r] = a;
         }
-        // halving butterfly inside each LPR-lane segment: after the step with mask s the lanes
-        // with bit s set own the upper half of the remaining row values
+        // Halving butterfly inside each LPR-lane segment.  The three halving exchanges (4 + 2 + 1
+        // values) use the lane strides 1, 2, 4 and the remaining plain sums the strides 8 .. LPR/2,
+        // because strides < 16 are DPP moves on the VALU (quad_perm, row_half_mirror, row_ror)
+        // while larger ones go through the LDS crossbar (ds_bpermute): 2 crossbar exchanges per 8
+        // rows instead of 10.  After the step with stride s the lanes with bit s set own the upper
+        // half of the remaining row values.
+        static_assert(MV_R == 8 && LPR >= 8, "three halving steps at strides 1, 2, 4");
         int sel = 0;
-        int live = MV_R;
+        {
+            const bool up = (lane & 1) != 0;
 #pragma unroll
-        for (int s = LPR / 2; s >= 1; s >>= 1) {
-            if (live > 1) {
-                const int half = live / 2;
-                const bool up = (lane & s) != 0;
-#pragma unroll
-                for (int i = 0; i < MV_R / 2; ++i) {
-                    if (i < half) {
-                        const F keep = up ? acc[i + half] : acc[i];
-                        const F send = up ? acc[i] : acc[i + half];
-                        acc[i] = keep + __shfl_xor(send, s, 64);
-                    }
-                }
-                sel += up ? half : 0;
-                live = half;
-            } else {
-                acc[0] += __shfl_xor(acc[0], s, 64);
+            for (int i = 0; i < 4; ++i) {
+                const F keep = up ? acc[i + 4] : acc[i];
+                const F send = up ? acc[i] : acc[i + 4];
+                acc[i] = keep + dpp_xor<1>(send);
             }
+            sel += up ? 4 : 0;
         }
-        if (live == 1) {
-            // one value per lane group: the lane whose low bits are zero writes row `sel`
-            constexpr int GRP = (LPR >= MV_R) ? LPR / MV_R : 1;
-            const int64_t row = r0 + (int64_t)sel * RPL + seg;
-            if ((sl % GRP) == 0 && row < n) out[row] += acc[0];
-        } else {
-            // LPR < MV_R: `live` values remain per lane after the segment is exhausted
+        {
+            const bool up = (lane & 2) != 0;
 #pragma unroll
-            for (int i = 0; i < MV_R; ++i) {
-                if (i < live) {
-                    const int64_t row = r0 + (int64_t)(sel + i) * RPL + seg;
-                    if (row < n) out[row] += acc[i];
-                }
+            for (int i = 0; i < 2; ++i) {
+                const F keep = up ? acc[i + 2] : acc[i];
+                const F send = up ? acc[i] : acc[i + 2];
+                acc[i] = keep + dpp_xor<2>(send);
             }
+            sel += up ? 2 : 0;
         }
+        {
+            const bool up = (lane & 4) != 0;
+            const F keep = up ? acc[1] : acc[0];
+            const F send = up ? acc[0] : acc[1];
+            acc[0] = keep + dpp_xor<4>(send);
+            sel += up ? 1 : 0;
+        }
+        if (LPR >= 16) acc[0] += dpp_xor<8>(acc[0]);
+#pragma unroll
+        for (int s = 16; s <= LPR / 2; s <<= 1) acc[0] += __shfl_xor(acc[0], s, 64);
+        // every lane of the segment with the same low 3 bits now holds the sum of row `sel`
+        const int64_t row = r0 + (int64_t)sel * RPL + seg;
+        if (sl < 8 && row < n) out[row] += acc[0];
     }
 }
 
