@@ -64,9 +64,23 @@ struct Col {
                     acc[C] = fma(a3, x3, acc[C]);
                 }
             }
+            if (MODE == 9) {
+                const int rem = tend - t;
+                if (rem == 3) {
+                    STEP(a0, x0, t) STEP(a1, x1, t + 1) STEP(a2, x2, t + 2)
+                    acc[C] = fma(a0, x0, acc[C]); acc[C] = fma(a1, x1, acc[C]); acc[C] = fma(a2, x2, acc[C]);
+                } else if (rem == 2) {
+                    STEP(a0, x0, t) STEP(a1, x1, t + 1)
+                    acc[C] = fma(a0, x0, acc[C]); acc[C] = fma(a1, x1, acc[C]);
+                } else if (rem == 1) {
+                    STEP(a0, x0, t)
+                    acc[C] = fma(a0, x0, acc[C]);
+                }
+            } else {
             for (; t < tend; ++t) {
                 STEP(a0, x0, t)
                 acc[C] = fma(a0, x0, acc[C]);
+            }
             }
             pos += m;
             nc -= m;
@@ -148,6 +162,7 @@ int main() {
     run(kdyn<2>, "no value ring");
     run(kdyn<3>, "no v_readlane");
     run(kdyn<4>, "neither (slab read + fma + loop control)");
+    run(kdyn<9>, "as MODE 0 with the tail as straight-line code (switch on 1..3)");
     run(kdyn<7>, "branch-free: 2 masked batches of 4 per column (8 slots)");
     run(kdyn<8>, "branch-free: 3 masked batches of 4 per column (12 slots)");
     run(kdyn<5>, "neither, no chunk rotation / boundary split");
