@@ -185,6 +185,21 @@ int tm_csr_dense_sandwich_slab_f64(const double *vals, const uint32_t *koff, con
                                    const int64_t *gptr, int64_t n, int64_t m, const double *B,
                                    int64_t r, int order_f, const double *d, double *out, void *stream);
 
+/* Same unrestricted product for a C-ordered B with 16-byte aligned rows on the interleaved-ELL
+ * twin of the sparse block.  Rows cut into slabs of R = tm_slab_rows() rows, columns into groups
+ * of C = tm_slab_group_cols() = 32, G = ceil(m / C).  The nonzeros of one (slab, group) are I
+ * iterations of 64 slots, I = ceil(longest column run of the group in the slab / 2);
+ * slot it*64 + 2c + u = the (2 it + u)-th nonzero (rows ascending) of column c of the group,
+ * or padding {vals 0, koff 0xFFFFFFFF}; vals[e] = A[k,i], koff[e] = (k - slab*R) * 64 * sizeof(F).
+ * gptr[slab*G + g] = first slot of the block (a multiple of 64), one trailing total.
+ * m = G*C kernel columns (the host may permute / pad the columns); out is [m x r] row-major. */
+int tm_csr_dense_sandwich_ell_f32(const float *vals, const uint32_t *koff, const int64_t *gptr,
+                                  int64_t n, int64_t m, const float *B, int64_t r, const float *d,
+                                  float *out, void *stream);
+int tm_csr_dense_sandwich_ell_f64(const double *vals, const uint32_t *koff, const int64_t *gptr,
+                                  int64_t n, int64_t m, const double *B, int64_t r, const double *d,
+                                  double *out, void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

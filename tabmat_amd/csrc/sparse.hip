@@ -1384,6 +1384,184 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_gather_kernel(
     }
 }
 
+// =======================================================================================
+// K3 (ELL)  sparse x dense on an interleaved-ELL twin: static iterations with skip masks.
+//
+// The run loop of the kernel above spends ~10 cycles per nonzero and CU on a 5 % dense block (its
+// dynamic control flow, not the LDS or the FMAs: scripts/ubench/gather_dyn.hip reproduces the rate
+// without any staging).  Here a (slab, 32-column group) block is I ITERATIONS of 64 slots,
+// slot it*64 + 2c + u = the (2 it + u)-th nonzero (rows ascending) of column c, padded to the
+// longest run of the group (I = ceil(longest / 2)).  An iteration is one coalesced 64-lane load
+// {value, row offset}; its code is straight-line with STATIC accumulators and constant lanes:
+// per slot v_readlane (row offset -> SGPR), v_add, ds_read_b64 of the slab row, half a uniform
+// 16-byte ring read (two values), v_fma_f64.  The padding (x1.9 at 5 % density) is not executed:
+// a ballot of the real slots gives a 64-bit mask, and every batch of 4 slots (2 columns) whose
+// mask bits are all clear is skipped with one scalar test -- 6.9 cycles per real nonzero and CU in
+// isolation (scripts/ubench/gather_ellmask.hip) against 10.0 for the run loop.
+// Staging, d folding and the zero row are those of csr_dense_gather_kernel's asynchronous path.
+// =======================================================================================
+constexpr unsigned ELL_PADKEY = 0xFFFFFFFFu;
+
+template <typename F>
+__global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ell_kernel(
+    const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ gptr,
+    int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n,
+    int64_t r, int nB, const F *__restrict__ d, F *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using L = GatherLds<F, false>;
+    constexpr int VEC = 16 / (int)sizeof(F);
+    constexpr int ROWB = L::ROWB;
+    constexpr int SLABB = L::SLABB;
+    constexpr int NV = SLAB_R * 64 / VEC / GATHER_THREADS;
+    constexpr int RPP = 1024 / ROWB;
+    constexpr int NA = 16 / (int)sizeof(F);          // values per 16-byte ring read
+    typedef F avec_t __attribute__((ext_vector_type(NA)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.z * GATHER_NW + wave;
+    const bool active = group < n_groups;
+    const int j0 = blockIdx.y * 64;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const unsigned lane_off = lane * (unsigned)sizeof(F);
+    F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
+    F *ring = reinterpret_cast<F *>(smem_raw + L::RING_OFF) + wave * 64;
+
+    F acc[GATHER_CPW];
+#pragma unroll
+    for (int c = 0; c < GATHER_CPW; ++c) acc[c] = F(0);
+    for (int i = tid; i < ROWB / (int)sizeof(F); i += GATHER_THREADS)
+        reinterpret_cast<F *>(smem_raw + L::ZERO_OFF)[i] = F(0);
+
+    F dsc = F(0);
+    auto issue_slab = [&](int64_t s, int buf) {       // async copy of B[slab rows, j0 .. j0 + 64)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int piece = wave * NV + i;
+            const int row = piece * RPP + (lane * 16) / ROWB;
+            const int c = ((lane * 16) % ROWB) / (int)sizeof(F);
+            const int64_t k = min(s * SLAB_R + row, n - 1);
+            const int cc = min(j0 + c, nB - VEC);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(B + k * r + cc),
+                (__attribute__((address_space(3))) void *)(smem_raw + buf * SLABB + piece * 1024), 16, 0,
+                0);
+        }
+        if (tid < SLAB_R) dsc = d[min(s * SLAB_R + tid, n - 1)];
+    };
+    auto finish_slab = [&](int64_t s, int buf) {
+        if (tid < SLAB_R) dl_all[buf * SLAB_R + tid] = (s * SLAB_R + tid < n) ? dsc : F(0);
+    };
+    // value scaled by d, row offset redirected to the zero row for padding and d == 0 rows
+    auto enter = [&](F a, unsigned ko, const F *dl, unsigned zero_off, F &a_out, unsigned &k_out) {
+        const bool real = ko != ELL_PADKEY;
+        const F dk = real ? dl[ko / (unsigned)ROWB] : F(0);
+        a_out = real ? a * dk : F(0);
+        k_out = dk != F(0) ? ko : zero_off;
+        return dk != F(0);
+    };
+
+    // meta(s + 2) / head(s + 1) pipeline as in csr_dense_gather_kernel
+    int m_iters = 0, h_iters = 0;
+    int64_t m_base = 0, h_base = 0;
+    F h_va = F(0), h_na = F(0);
+    unsigned h_vk = ELL_PADKEY, h_nk = ELL_PADKEY;
+    auto load_meta = [&](int64_t s) {
+        m_iters = 0;
+        m_base = 0;
+        if (!active || s >= s1) return;
+        m_base = gptr[s * n_groups + group];
+        m_iters = (int)((gptr[s * n_groups + group + 1] - m_base) >> 6);
+    };
+    auto load_head = [&]() {
+        h_iters = m_iters;
+        h_base = m_base;
+        if (h_iters > 0) {
+            h_va = vals[h_base + lane];
+            h_vk = koff[h_base + lane];
+            const int64_t q = h_base + (h_iters > 1 ? 64 : 0) + lane;
+            h_na = vals[q];
+            h_nk = koff[q];
+        }
+    };
+
+    if (s0 < s1) {
+        load_meta(s0);
+        load_head();
+        load_meta(s0 + 1);
+        issue_slab(s0, 0);
+        finish_slab(s0, 0);
+    }
+    __syncthreads();
+    for (int64_t s = s0; s < s1; ++s) {
+        const int buf = (int)((s - s0) & 1);
+        const int iters = h_iters;
+        const int64_t base = h_base;
+        F va = h_va, na = h_na;
+        unsigned vk = h_vk, nk = h_nk;
+        if (s + 1 < s1) {
+            load_head();
+            issue_slab(s + 1, buf ^ 1);
+        }
+        load_meta(s + 2);
+        if (active && iters > 0) {
+            const F *dl = dl_all + buf * SLAB_R;
+            const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
+            const unsigned char *slab = smem_raw + buf * SLABB;
+            F a_cur;
+            unsigned k_cur;
+            unsigned long long live = __builtin_amdgcn_ballot_w64(enter(va, vk, dl, zero_off, a_cur, k_cur));
+            __builtin_amdgcn_wave_barrier();
+            ring[lane] = a_cur;
+            __builtin_amdgcn_wave_barrier();
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int g0 = 0; g0 < 64; g0 += 4) {
+                    if (((live >> g0) & 0xFull) == 0) continue;      // 2 columns of padding / d == 0
+                    F x[4], a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        x[e] = *reinterpret_cast<const F *>(
+                            slab + (unsigned)__builtin_amdgcn_readlane((int)k_cur, g0 + e) + lane_off);
+#pragma unroll
+                    for (int e = 0; e < 4; e += NA) {
+                        const avec_t av = *reinterpret_cast<const avec_t *>(ring + g0 + e);
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) a[e + q] = av[q];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[(g0 + e) / 2] = fma(a[e], x[e], acc[(g0 + e) / 2]);
+                    // pin the FMAs here (else the selector sinks them behind all loads)
+                    asm volatile("" : "+v"(acc[g0 / 2]));
+                    asm volatile("" : "+v"(acc[g0 / 2 + 1]));
+                    if ((g0 & 4) != 0) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (it + 1 < iters) {
+                    // the prefetched chunk replaces the consumed one, the next prefetch is issued
+                    // (unconditional clamped loads: nothing waits for them before the next turn)
+                    live = __builtin_amdgcn_ballot_w64(enter(na, nk, dl, zero_off, a_cur, k_cur));
+                    __builtin_amdgcn_wave_barrier();
+                    ring[lane] = a_cur;
+                    __builtin_amdgcn_wave_barrier();
+                    const int64_t q = base + (int64_t)min(it + 2, iters - 1) * 64 + lane;
+                    na = vals[q];
+                    nk = koff[q];
+                }
+            }
+        }
+        if (s + 1 < s1) finish_slab(s + 1, buf ^ 1);
+        __syncthreads();
+    }
+    if (active) {
+        F *dst = ws + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_groups + group) *
+                          (GATHER_CPW * 64);
+#pragma unroll
+        for (int c = 0; c < GATHER_CPW; ++c) dst[c * 64 + lane] = acc[c];
+    }
+}
+
 // tmp [part][n_groups*64][64] -> out[m][nB]
 template <typename F>
 __global__ void gather_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t nB,
@@ -1449,6 +1627,55 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     return TM_OK;
 }
 
+template <typename F>
+static int run_csr_dense_ell(const F *vals, const unsigned *koff, const int64_t *gptr, int64_t n,
+                             int64_t m, const F *B, int64_t r, const F *d, F *out, hipStream_t st) {
+    const int64_t nB = r;
+    const int64_t total = m * nB;
+    if (total == 0) return TM_OK;
+    constexpr int VEC = 16 / (int)sizeof(F);
+    if ((reinterpret_cast<uintptr_t>(B) & 15) != 0 || r % VEC != 0 || nB < VEC) {
+        set_error("tm_csr_dense_sandwich_ell: B must be C-ordered with 16-byte aligned rows");
+        return TM_EUNSUPPORTED;
+    }
+    const int64_t n_slabs = ceil_div(n, SLAB_R);
+    const int n_groups = (int)ceil_div(m, GATHER_CPW);
+    const int64_t mpad = (int64_t)n_groups * GATHER_CPW;
+    const int n_parts = (int)ceil_div(nB, 64);
+    const int nz = (int)ceil_div(n_groups, GATHER_NW);
+    if (n_slabs == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / ((int64_t)n_parts * nz));
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const int64_t stride = mpad * 64;  // per (part, block)
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
+    void *wsv = nullptr;
+    int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
+                           &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    const size_t lds = (size_t)GatherLds<F, false>::TOTAL;
+    auto kern = &csr_dense_ell_kernel<F>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS),
+                       lds, st, vals, koff, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gather_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                       st, tmp, m, nB, mpad, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 }  // namespace tmh
 
 extern "C" {
@@ -1469,6 +1696,17 @@ int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_in
 
 int tm_slab_rows(void) { return tmh::SLAB_R; }
 int tm_slab_group_cols(void) { return tmh::GATHER_CPW; }
+
+int tm_csr_dense_sandwich_ell_f32(const float *vals, const uint32_t *koff, const int64_t *gptr,
+                                  int64_t n, int64_t m, const float *B, int64_t r, const float *d,
+                                  float *out, void *stream) {
+    return tmh::run_csr_dense_ell<float>(vals, koff, gptr, n, m, B, r, d, out, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_ell_f64(const double *vals, const uint32_t *koff, const int64_t *gptr,
+                                  int64_t n, int64_t m, const double *B, int64_t r, const double *d,
+                                  double *out, void *stream) {
+    return tmh::run_csr_dense_ell<double>(vals, koff, gptr, n, m, B, r, d, out, tmh::as_stream(stream));
+}
 
 int tm_csr_dense_sandwich_slab_f32(const float *vals, const uint32_t *koff, const uint16_t *cnt,
                                    const int64_t *gptr, int64_t n, int64_t m, const float *B,

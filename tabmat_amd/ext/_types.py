@@ -162,6 +162,76 @@ class SlabCsc:
         return SlabCsc(vals, koff, cnt, gptr, ecol, n, m)
 
 
+@dataclass
+class SlabEll:
+    """Interleaved-ELL twin of a sparse block for the static gather kernel
+    (tm_csr_dense_sandwich_ell_* in include/tabmat_hip.h): rows cut into slabs of R rows, the
+    columns -- sorted by density, so that the runs of a group have similar lengths -- into groups
+    of C = 32; the nonzeros of one (slab, group) are I iterations of 64 slots, slot (it, c, u) =
+    the (2 it + u)-th nonzero of column c, padded to the longest run of the group (the kernel skips
+    the padding two columns at a time).  Built once per block (ingest: one device key sort)."""
+
+    vals: torch.Tensor     # F[E]
+    koff: torch.Tensor     # int32[E]  byte offset of the entry's row in the LDS slab, -1 = padding
+    gptr: torch.Tensor     # int64[S * G + 1]  block starts (slots, multiples of 64)
+    inv: torch.Tensor      # int64[m]  kernel row of column c of the block
+    n: int
+    m: int                 # columns of the block
+    mk: int                # kernel rows = G * C
+
+    @staticmethod
+    def from_csr(csr: CsrDev) -> "SlabEll":
+        from .._lib import lib
+
+        R = int(lib().tm_slab_rows())
+        C = int(lib().tm_slab_group_cols())
+        U = 64 // C
+        n, m = csr.n, csr.m
+        dev = csr.data.device
+        fbytes = csr.data.element_size()
+        S = (n + R - 1) // R
+        G = max(1, (m + C - 1) // C)
+        mpad = G * C
+        nnz = int(csr.data.numel())
+        idx64 = csr.indices.to(torch.int64)
+        colcnt = torch.bincount(idx64, minlength=m) if nnz else \
+            torch.zeros(m, dtype=torch.int64, device=dev)
+        order = torch.sort(colcnt, descending=True, stable=True).indices
+        inv = torch.empty(m, dtype=torch.int64, device=dev)
+        inv[order] = torch.arange(m, device=dev, dtype=torch.int64)
+        del order, colcnt
+        counts = csr.indptr[1:] - csr.indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
+        key = torch.div(rows, R, rounding_mode="floor") * mpad + (inv[idx64] if nnz else idx64)
+        del idx64
+        # CSR order is row-sorted: a STABLE sort by (slab, kernel column) keeps rows ascending
+        key_sorted, perm = torch.sort(key, stable=True)
+        del key
+        cnt64 = torch.bincount(key_sorted, minlength=S * mpad) if nnz else \
+            torch.zeros(S * mpad, dtype=torch.int64, device=dev)
+        iters = torch.div(cnt64.view(S * G, C).max(dim=1).values + (U - 1), U, rounding_mode="floor") \
+            if S else torch.zeros(0, dtype=torch.int64, device=dev)
+        gptr = torch.zeros(S * G + 1, dtype=torch.int64, device=dev)
+        if S * G:
+            torch.cumsum(iters * 64, dim=0, out=gptr[1:])
+        total = int(gptr[-1].item())
+        vals = torch.zeros(total, dtype=csr.data.dtype, device=dev)
+        koff = torch.full((total,), -1, dtype=torch.int32, device=dev)      # 0xFFFFFFFF = padding
+        if nnz:
+            rank = torch.arange(nnz, device=dev, dtype=torch.int64) - \
+                (torch.cumsum(cnt64, dim=0) - cnt64)[key_sorted]
+            del cnt64
+            dst = gptr[torch.div(key_sorted, C, rounding_mode="floor")] \
+                + torch.div(rank, U, rounding_mode="floor") * 64 \
+                + torch.remainder(key_sorted, C) * U + torch.remainder(rank, U)
+            del rank
+            vals[dst] = csr.data[perm]
+            rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
+            koff[dst] = (rloc * (64 * fbytes)).to(torch.int32)
+            del rloc, dst
+        return SlabEll(vals, koff, gptr, inv, n, m, mpad)
+
+
 def onehot_slab(cats, n: int, dtype: torch.dtype):
     """Slab form of the STACKED one-hot encodings of several categorical blocks: a sparse
     matrix with (at most) one unit entry per row and categorical, columns = the categoricals'

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from .. import _device as D
 from .._lib import call
-from ._types import CsrDev, DenseDev, SlabCsc
+from ._types import CsrDev, DenseDev, SlabCsc, SlabEll
 
 
 def _csr_args(A: CsrDev):
@@ -71,6 +71,24 @@ def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
     call(f"tm_csr_dense_sandwich_slab_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.cnt),
          D.p(A.gptr), A.n, A.m, D.p(B.buf), B.m, B.order_f, D.p(d), D.p(out), D.stream_ptr())
     return out
+
+
+def ell_supported(B: DenseDev) -> bool:
+    """The static ELL gather kernel needs a C-ordered B with 16-byte aligned rows."""
+    vec = 16 // B.buf.element_size()
+    return (not B.order_f) and B.m % vec == 0 and B.m >= vec and B.buf.data_ptr() % 16 == 0
+
+
+def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
+    """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B:
+    interleaved-ELL twin, static iterations with skip masks (csrc/sparse.hip, K3 ELL)."""
+    assert B.n == A.n and ell_supported(B)
+    if A.m == 0 or B.m == 0 or A.n == 0:
+        return D.zeros((A.m, B.m), A.vals.dtype)
+    out = D.zeros((A.mk, B.m), A.vals.dtype)
+    call(f"tm_csr_dense_sandwich_ell_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.gptr),
+         A.n, A.mk, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
+    return out[A.inv]      # kernel rows are the density-sorted columns
 
 
 def sparse_sandwich_chunked(A: CsrDev, d):

@@ -8,7 +8,7 @@ from scipy import sparse as sps
 
 from . import _device as D
 from .ext import sparse as xs
-from .ext._types import CsrDev, SlabCsc
+from .ext._types import CsrDev, SlabCsc, SlabEll
 from .matrix_base import MatrixBase
 from .util import (
     check_indexer,
@@ -44,6 +44,7 @@ class SparseMatrix(MatrixBase):
         self._array_csr = None
         self._devblk = None
         self._slabblk = None
+        self._ellblk = None
         self._shape = self._array.shape
         self._dtype = self._array.dtype
         self._init_names(column_names, term_names)
@@ -67,6 +68,7 @@ class SparseMatrix(MatrixBase):
         self._array_csr = None
         self._devblk = csr
         self._slabblk = None
+        self._ellblk = None
         self._shape = (csr.n, csr.m)
         self._dtype = np.dtype(np.float64 if csr.data.dtype == torch.float64 else np.float32)
         self.idx_dtype = np.dtype(np.int32)
@@ -114,9 +116,16 @@ class SparseMatrix(MatrixBase):
             self._slabblk = SlabCsc.from_csr(self._dev())
         return self._slabblk
 
+    def _ell(self) -> SlabEll:
+        """Interleaved-ELL twin used by the static sparse x dense gather kernel (C-ordered B)."""
+        if getattr(self, "_ellblk", None) is None:
+            self._ellblk = SlabEll.from_csr(self._dev())
+        return self._ellblk
+
     def to_device(self):
         self._dev().chunk_major()
         self._slab()
+        self._ell()
         return self
 
     @property
@@ -231,7 +240,10 @@ class SparseMatrix(MatrixBase):
                     r64 = rows.to(torch.int64)
                     dm[r64] = d[r64]
                     d = dm
-                res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)
+                if xs.ell_supported(Bd):
+                    res = xs.csr_dense_sandwich_ell(self._ell(), Bd, d)
+                else:
+                    res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)
                 if L_cols is not None:
                     res = res[L_cols.to(torch.int64)]
                 if R_cols is not None:

@@ -240,3 +240,52 @@ def test_slab_stream_round_trip():
                 B[s * R + r, c] += vals[e]
             pos += int(cnt[s, c])
     np.testing.assert_array_equal(B, A.toarray())
+
+
+def test_slab_ell_round_trip():
+    """Host-side ingest of the interleaved-ELL twin of the static gather kernel
+    (tabmat_amd/ext/_types.py SlabEll): iterations, padding, group pointers, row offsets and the
+    column permutation reproduce the matrix (pure host logic on CPU tensors)."""
+    import scipy.sparse as sps
+    import torch
+
+    from tabmat_amd._lib import lib
+    from tabmat_amd.ext._types import CsrDev, SlabEll
+
+    n, m = 700, 70
+    A = sps.random(n, m, density=0.08, format="csr", random_state=3, dtype=np.float64)
+    A.sort_indices()
+    csr = CsrDev(torch.from_numpy(A.data), torch.from_numpy(A.indices.astype(np.int32)),
+                 torch.from_numpy(A.indptr.astype(np.int64)), n, m)
+    E = SlabEll.from_csr(csr)
+    R, C = lib().tm_slab_rows(), lib().tm_slab_group_cols()
+    U = 64 // C
+    G = (m + C - 1) // C
+    assert E.mk == G * C
+    ns = (n + R - 1) // R
+    vals, koff, gptr, inv = E.vals.numpy(), E.koff.numpy(), E.gptr.numpy(), E.inv.numpy()
+    assert sorted(inv.tolist()) == list(range(m))
+    kcol_to_col = {int(inv[c]): c for c in range(m)}
+    B = np.zeros((n, m))
+    n_real = 0
+    for s in range(ns):
+        for g in range(G):
+            b0, b1 = gptr[s * G + g], gptr[s * G + g + 1]
+            assert (b1 - b0) % 64 == 0
+            longest, last = 0, {}
+            for e in range(b0, b1):
+                it, rem = divmod(e - b0, 64)
+                c, u = divmod(rem, U)
+                if koff[e] == -1:
+                    assert vals[e] == 0
+                    continue
+                kc = g * C + c
+                r = koff[e] // (64 * 8)
+                assert r > last.get(kc, -1)          # rows ascending along (it, u)
+                last[kc] = r
+                B[s * R + r, kcol_to_col[kc]] += vals[e]
+                longest = max(longest, it * U + u + 1)
+                n_real += 1
+            assert (b1 - b0) // 64 == (longest + U - 1) // U   # padded to the longest run only
+    assert gptr[-1] == len(vals) and n_real == A.nnz
+    np.testing.assert_array_equal(B, A.toarray())
