@@ -1536,7 +1536,6 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ell_kernel(
                     // pin the FMAs here (else the selector sinks them behind all loads)
                     asm volatile("" : "+v"(acc[g0 / 2]));
                     asm volatile("" : "+v"(acc[g0 / 2 + 1]));
-                    if ((g0 & 4) != 0) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (it + 1 < iters) {
                     // the prefetched chunk replaces the consumed one, the next prefetch is issued
