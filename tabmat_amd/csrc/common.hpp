@@ -63,6 +63,27 @@ __device__ __forceinline__ F wave_sum(F v) {
     return v;
 }
 
+// value of lane (lane ^ S) for S in {1, 2, 3, 4, 8} with DPP moves on the VALU (no LDS crossbar)
+template <int S>
+__device__ __forceinline__ int dpp_xor_i32(int v) {
+    if constexpr (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    else if constexpr (S == 3) return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false);  // quad_perm [3,2,1,0]
+    else if constexpr (S == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);                 // row_half_mirror: i ^ 7
+        return __builtin_amdgcn_update_dpp(0, m, 0x1B, 0xF, 0xF, false);                         // quad_perm [3,2,1,0]: ^ 3
+    } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);                     // row_ror:8: i ^ 8
+}
+template <int S>
+__device__ __forceinline__ double dpp_xor(double v) {
+    return __hiloint2double(dpp_xor_i32<S>(__double2hiint(v)), dpp_xor_i32<S>(__double2loint(v)));
+}
+template <int S>
+__device__ __forceinline__ float dpp_xor(float v) {
+    return __int_as_float(dpp_xor_i32<S>(__float_as_int(v)));
+}
+
+
 // column of a categorical code: code - drop_first, negative = contributes nothing
 __device__ __forceinline__ int cat_col(int code, int drop_first) { return code - drop_first; }
 

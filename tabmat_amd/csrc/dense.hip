@@ -565,25 +565,6 @@ __global__ __launch_bounds__(256) void dense_matvec_c_kernel(
 // LPR = lanes per row (m / VEC when that is a power of two <= 64; 64 with NL loads per row else).
 constexpr int MV_R = 8;
 
-// value of lane (lane ^ S) for S in {1, 2, 4, 8} with DPP moves (no LDS crossbar)
-template <int S>
-__device__ __forceinline__ int dpp_xor_i32(int v) {
-    if constexpr (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
-    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-    else if constexpr (S == 4) {
-        const int m = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);                 // row_half_mirror: i ^ 7
-        return __builtin_amdgcn_update_dpp(0, m, 0x1B, 0xF, 0xF, false);                         // quad_perm [3,2,1,0]: ^ 3
-    } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);                     // row_ror:8: i ^ 8
-}
-template <int S>
-__device__ __forceinline__ double dpp_xor(double v) {
-    return __hiloint2double(dpp_xor_i32<S>(__double2hiint(v)), dpp_xor_i32<S>(__double2loint(v)));
-}
-template <int S>
-__device__ __forceinline__ float dpp_xor(float v) {
-    return __int_as_float(dpp_xor_i32<S>(__float_as_int(v)));
-}
-
 template <typename F, int LPR, int NL>
 __global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__restrict__ X,
                                                                    int64_t n, int64_t m,

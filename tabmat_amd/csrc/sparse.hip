@@ -547,59 +547,35 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             const int hb = (phase >= 2) ? 1 : 0;
             if (ha && !anyA2) continue;
             if (hb && !anyB2) continue;
-            if (phase == 0) { sa[lane] = ea; sb[lane] = eb; }
-            else if (phase == 1) { sa[lane] = ea2; }
+            if (phase == 0) {
+                // First halves: every lane pairs its own A entry with the B entry of lane
+                // (lane ^ s), s = 0..7, fetched with DPP moves inside the 8 lanes of its row --
+                // 8 x 64 pairs = all 8 x 8 combinations of the 8 rows without any LDS scratch
+                // traffic.  Diagonal tiles keep the pairs b <= a (entries are sorted by column and
+                // distinct): half-empty ds_adds, still cheaper than staging the lists.
+                const int rowbase = ea.col * TS, swz = (ea.col & 15) << 3;
+                auto pair = [&](int cb, F vb) {
+                    if ((ea.col | cb) >= 0 && (I != J || cb <= ea.col))
+                        atomic_add(&tile[rowbase + (cb ^ swz)], ea.val * vb);
+                };
+                pair(eb.col, eb.val);
+                pair(dpp_xor_i32<1>(eb.col), dpp_xor<1>(eb.val));
+                pair(dpp_xor_i32<2>(eb.col), dpp_xor<2>(eb.val));
+                pair(dpp_xor_i32<3>(eb.col), dpp_xor<3>(eb.val));
+                const int c4 = dpp_xor_i32<4>(eb.col);
+                const F v4 = dpp_xor<4>(eb.val);
+                pair(c4, v4);
+                pair(dpp_xor_i32<1>(c4), dpp_xor<1>(v4));
+                pair(dpp_xor_i32<2>(c4), dpp_xor<2>(v4));
+                pair(dpp_xor_i32<3>(c4), dpp_xor<3>(v4));
+                continue;
+            }
+            // second-half phases go through the per-wave scratch
+            if (phase == 1) { sa[lane] = ea2; sb[lane] = eb; }
             else if (phase == 2) { sb[lane] = eb2; }
             else { sa[lane] = ea; sb[lane] = eb2; }
             __builtin_amdgcn_wave_barrier();
-            if (I == J && phase == 0) {
-                // Diagonal tile: only the pairs b <= a of a row are needed (entries are sorted by
-                // column and distinct), i.e. the lower triangle of the 8 x 8 lane block.  Two
-                // rows share one ds_add: lanes pb <= pa take pair (pa, pb) of the `low` row
-                // (lists up to 8), lanes pb > pa take pair (pb - 1, pa) of the `up` row (lists up
-                // to 7); two rows that both have 8+ entries in the chunk go one after the other.
-#pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    const int n0 = min(__builtin_amdgcn_readlane(nA, r * 8), 8);
-                    const int n1 = min(__builtin_amdgcn_readlane(nA, r * 8 + 8), 8);
-                    if (n0 == 0 && n1 == 0) continue;
-                    const bool lower = pb <= pa;
-                    if (n0 <= 7 || n1 <= 7) {
-                        const bool swap = n1 > 7;                 // the long row must be `low`
-                        const int rl = swap ? r + 1 : r, ru = swap ? r : r + 1;
-                        const int row = lower ? rl : ru;
-                        const int a = lower ? pa : pb - 1;
-                        const int b = lower ? pb : pa;
-                        const Ent xa = sa[row * 8 + a];
-                        const Ent xb = sb[row * 8 + b];
-                        if ((xa.col | xb.col) >= 0)
-                            atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
-                                       xa.val * xb.val);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            if (lower) {
-                                const Ent xa = sa[(r + q) * 8 + pa];
-                                const Ent xb = sb[(r + q) * 8 + pb];
-                                atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
-                                           xa.val * xb.val);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-            if (phase == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const Ent xa = sa[r * 8 + pa];
-                    const Ent xb = sb[r * 8 + pb];
-                    if ((xa.col | xb.col) >= 0 && (I != J || xb.col <= xa.col))
-                        atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
-                                   xa.val * xb.val);
-                }
-            } else {
+            {
                 // second-half phases: only ~1.5 of the 8 rows have a list longer than 8 -- visit
                 // those (one mask bit per row, at the row's first lane) instead of testing all 8
                 unsigned long long todo =
