@@ -66,13 +66,14 @@ __device__ __forceinline__ F wave_sum(F v) {
 // value of lane (lane ^ S) for S in {1, 2, 3, 4, 8} with DPP moves on the VALU (no LDS crossbar)
 template <int S>
 __device__ __forceinline__ int dpp_xor_i32(int v) {
-    if constexpr (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
-    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-    else if constexpr (S == 3) return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false);  // quad_perm [3,2,1,0]
+    // mov_dpp: no `old` operand to initialise (every lane has a valid source for these controls)
+    if constexpr (S == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (S == 3) return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true);  // quad_perm [3,2,1,0]
     else if constexpr (S == 4) {
-        const int m = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);                 // row_half_mirror: i ^ 7
-        return __builtin_amdgcn_update_dpp(0, m, 0x1B, 0xF, 0xF, false);                         // quad_perm [3,2,1,0]: ^ 3
-    } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);                     // row_ror:8: i ^ 8
+        const int m = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);                 // row_half_mirror: i ^ 7
+        return __builtin_amdgcn_mov_dpp(m, 0x1B, 0xF, 0xF, true);                         // quad_perm [3,2,1,0]: ^ 3
+    } else return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);                     // row_ror:8: i ^ 8
 }
 template <int S>
 __device__ __forceinline__ double dpp_xor(double v) {

@@ -553,16 +553,27 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 // 8 x 64 pairs = all 8 x 8 combinations of the 8 rows without any LDS scratch
                 // traffic.  Diagonal tiles keep the pairs b <= a (entries are sorted by column and
                 // distinct): half-empty ds_adds, still cheaper than staging the lists.
-                const int rowbase = ea.col * TS, swz = (ea.col & 15) << 3;
-                auto pair = [&](int cb, F vb) {
-                    if ((ea.col | cb) >= 0 && (I != J || cb <= ea.col))
-                        atomic_add(&tile[rowbase + (cb ^ swz)], ea.val * vb);
+                // One signed compare per pair: B slots beyond their list carry a huge key, lanes
+                // whose A slot is empty get the limit -8; diagonal tiles limit b to a's column.
+                // Keys, swizzle and row base are pre-scaled to byte offsets (<< SH).
+                constexpr int BIG = 0x7ffffff0;
+                constexpr int SH = sizeof(F) == 8 ? 3 : 2;
+                const int lim8 = ea.col < 0 ? -8 : (I != J ? BIG - 8 : ea.col << SH);
+                const unsigned rowbase8 = (unsigned)ea.col * (unsigned)(TS * sizeof(F)),
+                               swz8 = (ea.col & 15) << (3 + SH);
+                const F av = ea.val;
+                auto pair = [&](int k8, F vb) {
+                    if (k8 <= lim8)
+                        atomic_add(reinterpret_cast<F *>(reinterpret_cast<char *>(tile) +
+                                                         ((((unsigned)k8) ^ swz8) + rowbase8)),
+                                   av * vb);
                 };
-                pair(eb.col, eb.val);
-                pair(dpp_xor_i32<1>(eb.col), dpp_xor<1>(eb.val));
-                pair(dpp_xor_i32<2>(eb.col), dpp_xor<2>(eb.val));
-                pair(dpp_xor_i32<3>(eb.col), dpp_xor<3>(eb.val));
-                const int c4 = dpp_xor_i32<4>(eb.col);
+                const int kb8 = eb.col < 0 ? BIG : eb.col << SH;
+                pair(kb8, eb.val);
+                pair(dpp_xor_i32<1>(kb8), dpp_xor<1>(eb.val));
+                pair(dpp_xor_i32<2>(kb8), dpp_xor<2>(eb.val));
+                pair(dpp_xor_i32<3>(kb8), dpp_xor<3>(eb.val));
+                const int c4 = dpp_xor_i32<4>(kb8);
                 const F v4 = dpp_xor<4>(eb.val);
                 pair(c4, v4);
                 pair(dpp_xor_i32<1>(c4), dpp_xor<1>(v4));
