@@ -3,7 +3,7 @@
  * tabmat's sandwich / matvec / transpose-matvec hot path.
  *
  * This is the drop-in boundary.  Each entry point replaces one native loop that
- * Quantco/tabmat's Cython layer (src/tabmat/ext/*.pyx) binds; the reference
+ * Quantco/tabmat's Cython layer (the .pyx files under src/tabmat/ext/) binds; the reference
  * interface it stands in for is cited per function (paths relative to the
  * reference repository).  Signatures are plain C: raw pointers and sizes, no
  * torch / numpy types.

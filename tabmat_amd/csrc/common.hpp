@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -84,6 +85,34 @@ __device__ __forceinline__ float dpp_xor(float v) {
     return __int_as_float(dpp_xor_i32<S>(__float_as_int(v)));
 }
 
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, int K0 = 0, typename Fn>
+__device__ __forceinline__ void static_for(Fn &&f) {
+    if constexpr (K0 < N) {
+        f(std::integral_constant<int, K0>{});
+        static_for<N, K0 + 1>(f);
+    }
+}
+
+// value of slot K (0..7) of the lane's own 8-lane group, broadcast to the 8 lanes; x4 must be
+// dpp_xor_i32<4>(v).  Two DPP moves: quad_perm [k,k,k,k] of x4 for the lanes of the other quad,
+// then the same pattern of v written only to the quads (DPP banks) that hold slot K themselves.
+template <int K>
+__device__ __forceinline__ int dpp_bcast8_i32(int v, int x4) {
+    constexpr int QP = (K & 3) * 0x55;
+    const int t = __builtin_amdgcn_mov_dpp(x4, QP, 0xF, 0xF, true);
+    return __builtin_amdgcn_update_dpp(t, v, QP, 0xF, K < 4 ? 0x5 : 0xA, false);
+}
+template <int K>
+__device__ __forceinline__ double dpp_bcast8(double v, double x4) {
+    return __hiloint2double(dpp_bcast8_i32<K>(__double2hiint(v), __double2hiint(x4)),
+                            dpp_bcast8_i32<K>(__double2loint(v), __double2loint(x4)));
+}
+template <int K>
+__device__ __forceinline__ float dpp_bcast8(float v, float x4) {
+    return __int_as_float(dpp_bcast8_i32<K>(__float_as_int(v), __float_as_int(x4)));
+}
 
 // column of a categorical code: code - drop_first, negative = contributes nothing
 __device__ __forceinline__ int cat_col(int code, int drop_first) { return code - drop_first; }

@@ -427,8 +427,6 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
-    typedef K2Entry<F> Ent;
-    Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(F) * TS * TS);   // [waves][2][64]
     // 1-D grid: the nch diagonal tiles come first with nb_diag workgroups each, then the
     // off-diagonal tiles with nb_off each (a diagonal tile has ~40 % fewer pairs per row).
     int part, blk, nblk_part;
@@ -463,8 +461,6 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane >> 3, lt = lane & 7;       // load phase: row-in-group, entry slot
-    Ent *sa = scratch + (wave * 2 + 0) * 64;
-    Ent *sb = scratch + (wave * 2 + 1) * 64;
     const int64_t t0 = (int64_t)blk * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
     const int64_t pstride = n + 1;          // cptr is [nch][n + 1] (chunk-major twin)
@@ -526,82 +522,87 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     for (int i = 0; i < K2_ED; ++i) es[i] = load_entries(load_ptrs(gw + i * gstep));
 #pragma unroll
     for (int i = 0; i < K2_NP; ++i) ps[i] = load_ptrs(gw + (K2_ED + i) * gstep);
-    const int pa = lane >> 3, pb = lane & 7;       // pair phase: (a, b) of an 8 x 8 block
+    const int pa = lane >> 3, pb = lane & 7;       // (a, b) of an 8 x 8 block (long-list fallback)
     static_assert(K2_ED == 2 && K2_NP == 2, "two groups per turn");
+    // Pair keys, pre-scaled to byte offsets of the tile (<< SH):
+    //   B entry: kb = col << SH, or BIGKEY for a slot beyond its list;
+    //   A entry: limit la = (col << SH) | offmask (-8 for an empty slot) and base
+    //            ba = row base | column swizzle, so that the target of (a, b) is tile + (kb ^ ba)
+    //            (the swizzle bits and the row-base bits are disjoint from each other and the row
+    //            base from kb) and the pair is wanted iff kb <= la -- one signed compare covering
+    //            both validities and, on diagonal tiles (offmask 0), the b <= a triangle.
+    constexpr int SH = sizeof(F) == 8 ? 3 : 2;
+    constexpr int BIGKEY = 0x7ffffff0;
+    const int offmask = (I != J) ? 0x70000000 : 0;
+    char *const tile_bytes = reinterpret_cast<char *>(tile);
+    auto a_lim = [&](int col) { return (col < 0 ? -8 : col << SH) | offmask; };
+    auto a_base = [&](int col) { return (int)(((unsigned)col << (7 + SH)) | ((col & 15) << (3 + SH))); };
+    auto b_key = [&](int col) { return col < 0 ? BIGKEY : col << SH; };
+    auto add_pair = [&](int kb, int la, int ba, F prod) {
+        if (kb <= la) atomic_add(reinterpret_cast<F *>(tile_bytes + (unsigned)(kb ^ ba)), prod);
+    };
     auto process = [&](const Grp &cur) {
         const int nA = cur.nA, nB = cur.nB, pA0 = cur.pA, pB0 = cur.pB;
         const F dk = cur.d;
-        // slots beyond the lists carry clamped (duplicate) entries: masked by the n tests below
-        Ent ea, eb, ea2, eb2;
-        // (a slot beyond its list gets column -1: the sign bit of colA | colB masks the pair)
-        ea.val = cur.va * dk;   ea.col = lt < nA ? cur.ca - i0 : -1;
-        eb.val = cur.vb;        eb.col = lt < nB ? cur.cb - j0 : -1;
-        ea2.val = cur.va2 * dk; ea2.col = lt + 8 < nA ? cur.ca2 - i0 : -1;
-        eb2.val = cur.vb2;      eb2.col = lt + 8 < nB ? cur.cb2 - j0 : -1;
+        // first halves (slots 0..7): every lane pairs its own A entry with the B entry of lane
+        // (lane ^ s), s = 0..7, fetched with DPP moves inside the 8 lanes of its row -- 8 x 64
+        // pairs = all 8 x 8 combinations of the 8 rows, no LDS scratch traffic
+        const int colA = lt < nA ? cur.ca - i0 : -1, colB = lt < nB ? cur.cb - j0 : -1;
+        const int la = a_lim(colA), ba = a_base(colA), kb = b_key(colB);
+        const F av = cur.va * dk, vb = cur.vb;
+        add_pair(kb, la, ba, av * vb);
+        add_pair(dpp_xor_i32<1>(kb), la, ba, av * dpp_xor<1>(vb));
+        add_pair(dpp_xor_i32<2>(kb), la, ba, av * dpp_xor<2>(vb));
+        add_pair(dpp_xor_i32<3>(kb), la, ba, av * dpp_xor<3>(vb));
+        const int kb4 = dpp_xor_i32<4>(kb);
+        const F vb4 = dpp_xor<4>(vb);
+        add_pair(kb4, la, ba, av * vb4);
+        add_pair(dpp_xor_i32<1>(kb4), la, ba, av * dpp_xor<1>(vb4));
+        add_pair(dpp_xor_i32<2>(kb4), la, ba, av * dpp_xor<2>(vb4));
+        add_pair(dpp_xor_i32<3>(kb4), la, ba, av * dpp_xor<3>(vb4));
+        // second halves (slots 8..15, ~19 % of the rows have one): slot 8 + k of a row is
+        // broadcast to the row's 8 lanes, k = 0 .. (longest overhang of the 8 rows) - 1, ~2 steps
         const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
-        // four phases over the (A half, B half) blocks; the per-wave scratch holds one half of
-        // each list at a time.  ha/hb = which half (0: entries 0..7, 1: entries 8..15).
-#pragma unroll
-        for (int phase = 0; phase < 4; ++phase) {
-            const int ha = (phase == 1 || phase == 2) ? 1 : 0;
-            const int hb = (phase >= 2) ? 1 : 0;
-            if (ha && !anyA2) continue;
-            if (hb && !anyB2) continue;
-            if (phase == 0) {
-                // First halves: every lane pairs its own A entry with the B entry of lane
-                // (lane ^ s), s = 0..7, fetched with DPP moves inside the 8 lanes of its row --
-                // 8 x 64 pairs = all 8 x 8 combinations of the 8 rows without any LDS scratch
-                // traffic.  Diagonal tiles keep the pairs b <= a (entries are sorted by column and
-                // distinct): half-empty ds_adds, still cheaper than staging the lists.
-                // One signed compare per pair: B slots beyond their list carry a huge key, lanes
-                // whose A slot is empty get the limit -8; diagonal tiles limit b to a's column.
-                // Keys, swizzle and row base are pre-scaled to byte offsets (<< SH).
-                constexpr int BIG = 0x7ffffff0;
-                constexpr int SH = sizeof(F) == 8 ? 3 : 2;
-                const int lim8 = ea.col < 0 ? -8 : (I != J ? BIG - 8 : ea.col << SH);
-                const unsigned rowbase8 = (unsigned)ea.col * (unsigned)(TS * sizeof(F)),
-                               swz8 = (ea.col & 15) << (3 + SH);
-                const F av = ea.val;
-                auto pair = [&](int k8, F vb) {
-                    if (k8 <= lim8)
-                        atomic_add(reinterpret_cast<F *>(reinterpret_cast<char *>(tile) +
-                                                         ((((unsigned)k8) ^ swz8) + rowbase8)),
-                                   av * vb);
-                };
-                const int kb8 = eb.col < 0 ? BIG : eb.col << SH;
-                pair(kb8, eb.val);
-                pair(dpp_xor_i32<1>(kb8), dpp_xor<1>(eb.val));
-                pair(dpp_xor_i32<2>(kb8), dpp_xor<2>(eb.val));
-                pair(dpp_xor_i32<3>(kb8), dpp_xor<3>(eb.val));
-                const int c4 = dpp_xor_i32<4>(kb8);
-                const F v4 = dpp_xor<4>(eb.val);
-                pair(c4, v4);
-                pair(dpp_xor_i32<1>(c4), dpp_xor<1>(v4));
-                pair(dpp_xor_i32<2>(c4), dpp_xor<2>(v4));
-                pair(dpp_xor_i32<3>(c4), dpp_xor<3>(v4));
-                continue;
-            }
-            // second-half phases go through the per-wave scratch
-            if (phase == 1) { sa[lane] = ea2; sb[lane] = eb; }
-            else if (phase == 2) { sb[lane] = eb2; }
-            else { sa[lane] = ea; sb[lane] = eb2; }
-            __builtin_amdgcn_wave_barrier();
-            {
-                // second-half phases: only ~1.5 of the 8 rows have a list longer than 8 -- visit
-                // those (one mask bit per row, at the row's first lane) instead of testing all 8
-                unsigned long long todo =
-                    __builtin_amdgcn_ballot_w64(nA > 8 * ha && nB > 8 * hb) & 0x0101010101010101ull;
-                while (todo) {
-                    const int l0 = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const Ent xa = sa[l0 + pa];
-                    const Ent xb = sb[l0 + pb];
-                    if ((xa.col | xb.col) >= 0 && (I != J || xb.col <= xa.col))
-                        atomic_add(&tile[xa.col * TS + (xb.col ^ ((xa.col & 15) << 3))],
-                                   xa.val * xb.val);
+        const int colB2 = lt + 8 < nB ? cur.cb2 - j0 : -1;
+        const int kb2 = b_key(colB2);
+        const F vb2 = cur.vb2;
+        if (anyA2) {
+            // A overhang x (B first half, B overhang)
+            const int colA2 = lt + 8 < nA ? cur.ca2 - i0 : -1;
+            const int la2 = a_lim(colA2), ba2 = a_base(colA2);
+            const F av2 = cur.va2 * dk;
+            const int la2x = dpp_xor_i32<4>(la2), ba2x = dpp_xor_i32<4>(ba2);
+            const F av2x = dpp_xor<4>(av2);
+            bool go = true;
+            static_for<8>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (go) {
+                    if (!__any(nA > 8 + K)) {
+                        go = false;
+                    } else {
+                        const int lk = dpp_bcast8_i32<K>(la2, la2x), bk = dpp_bcast8_i32<K>(ba2, ba2x);
+                        const F ak = dpp_bcast8<K>(av2, av2x);
+                        add_pair(kb, lk, bk, ak * vb);
+                        if (anyB2) add_pair(kb2, lk, bk, ak * vb2);
+                    }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
+            });
+        }
+        if (anyB2 && I != J) {
+            // A first half x B overhang (empty on diagonal tiles: those columns are all > a's)
+            const int kb2x = dpp_xor_i32<4>(kb2);
+            const F vb2x = dpp_xor<4>(vb2);
+            bool go = true;
+            static_for<8>([&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (go) {
+                    if (!__any(nB > 8 + K)) {
+                        go = false;
+                    } else {
+                        add_pair(dpp_bcast8_i32<K>(kb2, kb2x), la, ba, av * dpp_bcast8<K>(vb2, vb2x));
+                    }
+                }
+            });
         }
         if (__any(nA > 16) || __any(nB > 16)) {
             // very long lists (> 16 entries of one row in one 128-column chunk): remaining
@@ -941,7 +942,7 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int nchunk = (int)ceil_div(m, TS);
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
-    const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
+    const size_t lds = sizeof(F) * (size_t)(TS * TS);   // the tile only: pairs are formed in registers
     // workgroups per tile.  Measured: diagonal and off-diagonal tiles cost the same per row (the
     // per-row loads dominate, not the pair count), so the split is even; the off-diagonal tiles
     // take the workgroups left over by the integer division (25 / 26 at 512 columns: all 256 CUs).
