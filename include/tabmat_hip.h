@@ -200,6 +200,21 @@ int tm_csr_dense_sandwich_ell_f64(const double *vals, const uint32_t *koff, cons
                                   int64_t n, int64_t m, const double *B, int64_t r, const double *d,
                                   double *out, void *stream);
 
+/* Wide form of the interleaved-ELL product for dense operands with more than 64 columns: the
+ * kernel keeps 128 dense columns per lane pair, so the sparse stream is read once per 128 dense
+ * columns.  Same layout as tm_csr_dense_sandwich_ell_* with R = tm_ellw_rows() = 64 rows per slab,
+ * C = tm_ellw_group_cols() = 16 columns per group, 4 slots per column and iteration
+ * (slot it*64 + 4c + u = the (4 it + u)-th nonzero of column c, I = ceil(longest run / 4)) and
+ * koff[e] = (k - slab*R) * 128 * sizeof(F).  m must be a multiple of C. */
+int tm_ellw_rows(void);
+int tm_ellw_group_cols(void);
+int tm_csr_dense_sandwich_ellw_f32(const float *vals, const uint32_t *koff, const int64_t *gptr,
+                                   int64_t n, int64_t m, const float *B, int64_t r, const float *d,
+                                   float *out, void *stream);
+int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, const int64_t *gptr,
+                                   int64_t n, int64_t m, const double *B, int64_t r, const double *d,
+                                   double *out, void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

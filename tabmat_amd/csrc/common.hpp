@@ -86,6 +86,12 @@ __device__ __forceinline__ float dpp_xor(float v) {
 }
 
 
+__device__ __forceinline__ int64_t readfirstlane_i64(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
 template <int N, int K0 = 0, typename Fn>
 __device__ __forceinline__ void static_for(Fn &&f) {

@@ -1451,20 +1451,29 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ell_kernel(
     };
 
     // meta(s + 2) / head(s + 1) pipeline as in csr_dense_gather_kernel
-    int m_iters = 0, h_iters = 0;
-    int64_t m_base = 0, h_base = 0;
+    int h_iters = 0;
+    int64_t h_base = 0;
+    int64_t mv_base = 0, mv_end = 0;    // meta of slab s + 2 as loaded (per-lane copies)
+    bool m_valid = false;
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));     // a zero the compiler cannot see through (kept in a VGPR)
     F h_va = F(0), h_na = F(0);
     unsigned h_vk = ELL_PADKEY, h_nk = ELL_PADKEY;
     auto load_meta = [&](int64_t s) {
-        m_iters = 0;
-        m_base = 0;
+        m_valid = false;
         if (!active || s >= s1) return;
-        m_base = gptr[s * n_groups + group];
-        m_iters = (int)((gptr[s * n_groups + group + 1] - m_base) >> 6);
+        // VECTOR loads on purpose (lane-dependent zero offset): a scalar load would share lgkmcnt
+        // with the LDS reads, and since scalar loads return out of order the compiler waits for
+        // it (one memory round trip per slab) before the next LDS access
+        // (kept in VGPRs until load_head turns them into wave-uniform values one slab later)
+        const int64_t *gp = gptr + s * n_groups + group + vzero;
+        mv_base = gp[0];
+        mv_end = gp[1];
+        m_valid = true;
     };
     auto load_head = [&]() {
-        h_iters = m_iters;
-        h_base = m_base;
+        h_base = m_valid ? readfirstlane_i64(mv_base) : 0;
+        h_iters = m_valid ? (int)((readfirstlane_i64(mv_end) - h_base) >> 6) : 0;
         if (h_iters > 0) {
             h_va = vals[h_base + lane];
             h_vk = koff[h_base + lane];
@@ -1549,14 +1558,219 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ell_kernel(
     }
 }
 
-// tmp [part][n_groups*64][64] -> out[m][nB]
+// =======================================================================================
+// K3 (wide ELL)  the same static-iteration gather with lane <-> TWO dense columns: the LDS slab
+// holds ELLW_R = 64 rows x 128 dense columns, a nonzero costs one 16-byte LDS read + two FMAs and
+// its {value, row offset} is streamed and broadcast ONCE for 128 dense columns instead of once per
+// 64-column part (the 64-column kernel spends 2 x 6.9 cycles per nonzero and CU on 128 columns,
+// this geometry 11.0: scripts/ubench/gather_ellwide.hip; the floor is the LDS read bandwidth,
+// 8 cycles per KiB row).  A wave owns ELLW_C = 16 sparse columns (32 accumulators), an iteration
+// is 16 columns x 4 slots, slot it*64 + 4c + u = the (4 it + u)-th nonzero of column c; padding
+// is skipped two slots at a time.  A workgroup covers 256 sparse columns; wider blocks use
+// blockIdx.z, whose workgroups read the same slabs at the same time on the same XCD (L2 hits).
+// =======================================================================================
+constexpr int ELLW_R = 64;
+constexpr int ELLW_C = 16;
+constexpr int ELLW_W = 128;                          // dense columns per part
+constexpr int ELLW_HC = 3;                           // chunks of a block prefetched one slab ahead
+constexpr int ELLW_SK = 2;                           // slots per skip batch
+
 template <typename F>
+struct EllwLds {
+    static constexpr int ROWB = ELLW_W * (int)sizeof(F);
+    static constexpr int SLABB = ELLW_R * ROWB;
+    static constexpr int ZERO_OFF = 2 * SLABB;
+    static constexpr int DL_OFF = ZERO_OFF + ROWB;
+    static constexpr int RING_OFF = DL_OFF + 2 * ELLW_R * (int)sizeof(F);
+    static constexpr int TOTAL = RING_OFF + GATHER_NW * 64 * (int)sizeof(F);
+};
+
+template <typename F>
+__global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ellw_kernel(
+    const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ gptr,
+    int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n,
+    int64_t r, int nB, const F *__restrict__ d, F *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using L = EllwLds<F>;
+    constexpr int VEC = 16 / (int)sizeof(F);
+    constexpr int ROWB = L::ROWB;
+    constexpr int SLABB = L::SLABB;
+    constexpr int NV = SLABB / 16 / GATHER_THREADS;      // 16-byte pieces staged per thread
+    constexpr int RPP = 1024 / ROWB;                     // slab rows per 1 KiB wave piece (1 or 2)
+    typedef F pair_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.z * GATHER_NW + wave;
+    const bool active = group < n_groups;
+    const int j0 = blockIdx.y * ELLW_W;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const unsigned lane_off = lane * 2u * (unsigned)sizeof(F);
+    F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
+    F *ring = reinterpret_cast<F *>(smem_raw + L::RING_OFF) + wave * 64;
+
+    pair_t acc[ELLW_C];
+#pragma unroll
+    for (int c = 0; c < ELLW_C; ++c) acc[c] = pair_t{F(0), F(0)};
+    for (int i = tid; i < ROWB / (int)sizeof(F); i += GATHER_THREADS)
+        reinterpret_cast<F *>(smem_raw + L::ZERO_OFF)[i] = F(0);
+
+    F dsc = F(0);
+    auto issue_slab = [&](int64_t s, int buf) {       // async copy of B[slab rows, j0 .. j0 + 128)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int piece = wave * NV + i;
+            const int row = piece * RPP + (lane * 16) / ROWB;
+            const int c = ((lane * 16) % ROWB) / (int)sizeof(F);
+            const int64_t k = min(s * ELLW_R + row, n - 1);
+            const int cc = min(j0 + c, nB - VEC);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(B + k * r + cc),
+                (__attribute__((address_space(3))) void *)(smem_raw + buf * SLABB + piece * 1024), 16, 0,
+                0);
+        }
+        if (tid < ELLW_R) dsc = d[min(s * ELLW_R + tid, n - 1)];
+    };
+    auto finish_slab = [&](int64_t s, int buf) {
+        if (tid < ELLW_R) dl_all[buf * ELLW_R + tid] = (s * ELLW_R + tid < n) ? dsc : F(0);
+    };
+    auto enter = [&](F a, unsigned ko, const F *dl, unsigned zero_off, F &a_out, unsigned &k_out) {
+        const bool real = ko != ELL_PADKEY;
+        const F dk = real ? dl[ko / (unsigned)ROWB] : F(0);
+        a_out = real ? a * dk : F(0);
+        k_out = dk != F(0) ? ko : zero_off;
+        return dk != F(0);
+    };
+
+    // Pipeline over the slabs: meta(s + 2) = block start / length, head(s + 1) = the first
+    // ELLW_HC chunks of the block (from meta(s + 1)), slab(s + 1) = async copy of the dense rows.
+    // The head holds ALL chunks of a typical block (~2 iterations at 5 % density): vector loads
+    // complete in order, so a chunk requested inside the slab loop would sit behind the 64 KB slab
+    // copy issued at the top of the iteration and the wave would wait for that round trip after
+    // its first chunk (measured: 6.4 ms with 2 head chunks + in-loop prefetch).
+    int h_iters = 0;
+    int64_t h_base = 0;
+    int64_t mv_base = 0, mv_end = 0;    // meta of slab s + 2 as loaded (per-lane copies)
+    bool m_valid = false;
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));     // a zero the compiler cannot see through (kept in a VGPR)
+    F h_v[ELLW_HC];
+    unsigned h_k[ELLW_HC];
+#pragma unroll
+    for (int c = 0; c < ELLW_HC; ++c) { h_v[c] = F(0); h_k[c] = ELL_PADKEY; }
+    auto load_meta = [&](int64_t s) {
+        m_valid = false;
+        if (!active || s >= s1) return;
+        // VECTOR loads on purpose (lane-dependent zero offset): a scalar load would share lgkmcnt
+        // with the LDS reads, and since scalar loads return out of order the compiler waits for
+        // it (one memory round trip per slab) before the next LDS access
+        // (kept in VGPRs until load_head turns them into wave-uniform values one slab later)
+        const int64_t *gp = gptr + s * n_groups + group + vzero;
+        mv_base = gp[0];
+        mv_end = gp[1];
+        m_valid = true;
+    };
+    auto load_head = [&]() {
+        h_base = m_valid ? readfirstlane_i64(mv_base) : 0;
+        h_iters = m_valid ? (int)((readfirstlane_i64(mv_end) - h_base) >> 6) : 0;
+        if (h_iters > 0) {
+#pragma unroll
+            for (int c = 0; c < ELLW_HC; ++c) {
+                const int64_t q = h_base + (int64_t)min(c, h_iters - 1) * 64 + lane;
+                h_v[c] = vals[q];
+                h_k[c] = koff[q];
+            }
+        }
+    };
+
+    if (s0 < s1) {
+        load_meta(s0);
+        load_head();
+        load_meta(s0 + 1);
+        issue_slab(s0, 0);
+        finish_slab(s0, 0);
+    }
+    __syncthreads();
+    for (int64_t s = s0; s < s1; ++s) {
+        const int buf = (int)((s - s0) & 1);
+        const int iters = h_iters;
+        const int64_t base = h_base;
+        F cv[ELLW_HC];
+        unsigned ck[ELLW_HC];
+#pragma unroll
+        for (int c = 0; c < ELLW_HC; ++c) { cv[c] = h_v[c]; ck[c] = h_k[c]; }
+        if (s + 1 < s1) {
+            load_head();
+            issue_slab(s + 1, buf ^ 1);
+        }
+        load_meta(s + 2);
+        if (active && iters > 0) {
+            const F *dl = dl_all + buf * ELLW_R;
+            const unsigned zero_off = (unsigned)(L::ZERO_OFF - buf * SLABB);
+            const unsigned char *slab = smem_raw + buf * SLABB;
+            auto do_chunk = [&](F va, unsigned vk) {
+                F a_cur;
+                unsigned k_cur;
+                const unsigned long long live =
+                    __builtin_amdgcn_ballot_w64(enter(va, vk, dl, zero_off, a_cur, k_cur));
+                __builtin_amdgcn_wave_barrier();
+                ring[lane] = a_cur;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g0 = 0; g0 < 64; g0 += ELLW_SK) {
+                    if (((live >> g0) & ((1ull << ELLW_SK) - 1)) == 0) continue;   // padding / d == 0 slots
+                    pair_t x[ELLW_SK];
+                    F a[ELLW_SK];
+#pragma unroll
+                    for (int e = 0; e < ELLW_SK; ++e)
+                        x[e] = *reinterpret_cast<const pair_t *>(
+                            slab + (unsigned)__builtin_amdgcn_readlane((int)k_cur, g0 + e) + lane_off);
+#pragma unroll
+                    for (int e = 0; e < ELLW_SK; e += 2) {
+                        const pair_t av = *reinterpret_cast<const pair_t *>(ring + g0 + e);
+                        a[e] = av[0];
+                        a[e + 1] = av[1];
+                    }
+                    pair_t &A = acc[g0 / 4];
+#pragma unroll
+                    for (int e = 0; e < ELLW_SK; ++e) {
+                        A[0] = fma(a[e], x[e][0], A[0]);
+                        A[1] = fma(a[e], x[e][1], A[1]);
+                    }
+                    asm volatile("" : "+v"(A));      // pin the FMAs here
+                }
+                __builtin_amdgcn_wave_barrier();     // ring is rewritten by the next chunk
+            };
+#pragma unroll
+            for (int c = 0; c < ELLW_HC; ++c)
+                if (c < iters) do_chunk(cv[c], ck[c]);
+            for (int it = ELLW_HC; it < iters; ++it) {      // long blocks: the rest synchronously
+                const int64_t q = base + (int64_t)it * 64 + lane;
+                do_chunk(vals[q], koff[q]);
+            }
+        }
+        if (s + 1 < s1) finish_slab(s + 1, buf ^ 1);
+        __syncthreads();
+    }
+    if (active) {
+        // ws layout: [part][block][n_groups * ELLW_C columns][128]
+        F *dst = ws + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_groups + group) *
+                          (ELLW_C * ELLW_W);
+#pragma unroll
+        for (int c = 0; c < ELLW_C; ++c)
+            *reinterpret_cast<pair_t *>(dst + c * ELLW_W + lane * 2) = acc[c];
+    }
+}
+
+// tmp [part][n_groups*64][64] -> out[m][nB]
+template <typename F, int W = 64>
 __global__ void gather_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t nB,
                                      int64_t mpad, F *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * nB) return;
     const int64_t i = e / nB, j = e % nB;
-    out[e] = tmp[((j / 64) * mpad + i) * 64 + (j % 64)];
+    out[e] = tmp[((j / W) * mpad + i) * W + (j % W)];
 }
 
 template <typename F>
@@ -1663,6 +1877,58 @@ static int run_csr_dense_ell(const F *vals, const unsigned *koff, const int64_t 
     return TM_OK;
 }
 
+template <typename F>
+static int run_csr_dense_ellw(const F *vals, const unsigned *koff, const int64_t *gptr, int64_t n,
+                              int64_t m, const F *B, int64_t r, const F *d, F *out, hipStream_t st) {
+    const int64_t nB = r;
+    const int64_t total = m * nB;
+    if (total == 0) return TM_OK;
+    constexpr int VEC = 16 / (int)sizeof(F);
+    if ((reinterpret_cast<uintptr_t>(B) & 15) != 0 || r % VEC != 0 || nB < VEC) {
+        set_error("tm_csr_dense_sandwich_ellw: B must be C-ordered with 16-byte aligned rows");
+        return TM_EUNSUPPORTED;
+    }
+    if (m % ELLW_C != 0) {
+        set_error("tm_csr_dense_sandwich_ellw: m must be a multiple of tm_ellw_group_cols()");
+        return TM_EINVAL;
+    }
+    const int64_t n_slabs = ceil_div(n, ELLW_R);
+    const int n_groups = (int)(m / ELLW_C);
+    const int n_parts = (int)ceil_div(nB, ELLW_W);
+    const int nz = (int)ceil_div(n_groups, GATHER_NW);
+    if (n_slabs == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / ((int64_t)n_parts * nz));
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const int64_t stride = m * ELLW_W;  // per (part, block)
+    const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
+    void *wsv = nullptr;
+    int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
+                           &wsv);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    const size_t lds = (size_t)EllwLds<F>::TOTAL;
+    auto kern = &csr_dense_ellw_kernel<F>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS),
+                       lds, st, vals, koff, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gather_untile_kernel<F, ELLW_W>), dim3((unsigned)ceil_div(total, 256)),
+                       dim3(256), 0, st, tmp, m, nB, m, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 }  // namespace tmh
 
 extern "C" {
@@ -1681,6 +1947,18 @@ int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_in
                                                     tmh::as_stream(stream));
 }
 
+int tm_ellw_rows(void) { return tmh::ELLW_R; }
+int tm_ellw_group_cols(void) { return tmh::ELLW_C; }
+int tm_csr_dense_sandwich_ellw_f32(const float *vals, const uint32_t *koff, const int64_t *gptr,
+                                   int64_t n, int64_t m, const float *B, int64_t r, const float *d,
+                                   float *out, void *stream) {
+    return tmh::run_csr_dense_ellw<float>(vals, koff, gptr, n, m, B, r, d, out, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, const int64_t *gptr,
+                                   int64_t n, int64_t m, const double *B, int64_t r, const double *d,
+                                   double *out, void *stream) {
+    return tmh::run_csr_dense_ellw<double>(vals, koff, gptr, n, m, B, r, d, out, tmh::as_stream(stream));
+}
 int tm_slab_rows(void) { return tmh::SLAB_R; }
 int tm_slab_group_cols(void) { return tmh::GATHER_CPW; }
 

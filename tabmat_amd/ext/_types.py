@@ -178,14 +178,18 @@ class SlabEll:
     n: int
     m: int                 # columns of the block
     mk: int                # kernel rows = G * C
+    wide: bool = False     # geometry of the wide kernel (tm_csr_dense_sandwich_ellw_*)
 
     @staticmethod
-    def from_csr(csr: CsrDev) -> "SlabEll":
+    def from_csr(csr: CsrDev, wide: bool = False) -> "SlabEll":
+        """wide=True: geometry of tm_csr_dense_sandwich_ellw_* (64-row slabs of 128 dense columns,
+        16 columns x 4 slots per iteration) instead of tm_csr_dense_sandwich_ell_*."""
         from .._lib import lib
 
-        R = int(lib().tm_slab_rows())
-        C = int(lib().tm_slab_group_cols())
+        R = int(lib().tm_ellw_rows() if wide else lib().tm_slab_rows())
+        C = int(lib().tm_ellw_group_cols() if wide else lib().tm_slab_group_cols())
         U = 64 // C
+        W = 128 if wide else 64     # dense columns per LDS slab row
         n, m = csr.n, csr.m
         dev = csr.data.device
         fbytes = csr.data.element_size()
@@ -227,9 +231,9 @@ class SlabEll:
             del rank
             vals[dst] = csr.data[perm]
             rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
-            koff[dst] = (rloc * (64 * fbytes)).to(torch.int32)
+            koff[dst] = (rloc * (W * fbytes)).to(torch.int32)
             del rloc, dst
-        return SlabEll(vals, koff, gptr, inv, n, m, mpad)
+        return SlabEll(vals, koff, gptr, inv, n, m, mpad, wide)
 
 
 def onehot_slab(cats, n: int, dtype: torch.dtype):

@@ -86,7 +86,8 @@ def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
     if A.m == 0 or B.m == 0 or A.n == 0:
         return D.zeros((A.m, B.m), A.vals.dtype)
     out = D.zeros((A.mk, B.m), A.vals.dtype)
-    call(f"tm_csr_dense_sandwich_ell_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.gptr),
+    fn = "tm_csr_dense_sandwich_ellw_" if A.wide else "tm_csr_dense_sandwich_ell_"
+    call(fn + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.gptr),
          A.n, A.mk, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
     return out[A.inv]      # kernel rows are the density-sorted columns
 

@@ -116,11 +116,13 @@ class SparseMatrix(MatrixBase):
             self._slabblk = SlabCsc.from_csr(self._dev())
         return self._slabblk
 
-    def _ell(self) -> SlabEll:
-        """Interleaved-ELL twin used by the static sparse x dense gather kernel (C-ordered B)."""
-        if getattr(self, "_ellblk", None) is None:
-            self._ellblk = SlabEll.from_csr(self._dev())
-        return self._ellblk
+    def _ell(self, wide: bool = False) -> SlabEll:
+        """Interleaved-ELL twin used by the static sparse x dense gather kernel (C-ordered B);
+        wide: the 128-dense-column geometry used when B has more than 64 columns."""
+        name = "_ellwblk" if wide else "_ellblk"
+        if getattr(self, name, None) is None:
+            setattr(self, name, SlabEll.from_csr(self._dev(), wide=wide))
+        return getattr(self, name)
 
     def to_device(self):
         self._dev().chunk_major()
@@ -241,7 +243,7 @@ class SparseMatrix(MatrixBase):
                     dm[r64] = d[r64]
                     d = dm
                 if xs.ell_supported(Bd):
-                    res = xs.csr_dense_sandwich_ell(self._ell(), Bd, d)
+                    res = xs.csr_dense_sandwich_ell(self._ell(wide=Bd.m > 64), Bd, d)
                 else:
                     res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)
                 if L_cols is not None:

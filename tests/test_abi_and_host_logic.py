@@ -242,10 +242,12 @@ def test_slab_stream_round_trip():
     np.testing.assert_array_equal(B, A.toarray())
 
 
-def test_slab_ell_round_trip():
+@pytest.mark.parametrize("wide", [False, True])
+def test_slab_ell_round_trip(wide):
     """Host-side ingest of the interleaved-ELL twin of the static gather kernel
     (tabmat_amd/ext/_types.py SlabEll): iterations, padding, group pointers, row offsets and the
-    column permutation reproduce the matrix (pure host logic on CPU tensors)."""
+    column permutation reproduce the matrix (pure host logic on CPU tensors); wide = the geometry
+    of tm_csr_dense_sandwich_ellw_* (64-row slabs, 16 columns x 4 slots, 128-column LDS rows)."""
     import scipy.sparse as sps
     import torch
 
@@ -257,8 +259,13 @@ def test_slab_ell_round_trip():
     A.sort_indices()
     csr = CsrDev(torch.from_numpy(A.data), torch.from_numpy(A.indices.astype(np.int32)),
                  torch.from_numpy(A.indptr.astype(np.int64)), n, m)
-    E = SlabEll.from_csr(csr)
-    R, C = lib().tm_slab_rows(), lib().tm_slab_group_cols()
+    E = SlabEll.from_csr(csr, wide=wide)
+    assert E.wide == wide
+    if wide:
+        R, C, W = lib().tm_ellw_rows(), lib().tm_ellw_group_cols(), 128
+        assert (R, C) == (64, 16)
+    else:
+        R, C, W = lib().tm_slab_rows(), lib().tm_slab_group_cols(), 64
     U = 64 // C
     G = (m + C - 1) // C
     assert E.mk == G * C
@@ -280,7 +287,9 @@ def test_slab_ell_round_trip():
                     assert vals[e] == 0
                     continue
                 kc = g * C + c
-                r = koff[e] // (64 * 8)
+                assert koff[e] % (W * 8) == 0
+                r = koff[e] // (W * 8)
+                assert 0 <= r < R
                 assert r > last.get(kc, -1)          # rows ascending along (it, u)
                 last[kc] = r
                 B[s * R + r, kcol_to_col[kc]] += vals[e]

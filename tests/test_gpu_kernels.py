@@ -226,6 +226,34 @@ def test_csr_dense_sandwich(order, n, m, r):
     assert rel_err(sm._cross_sandwich(dm, d, rows, Ac, Bc), ref) < F64_TOL
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,r,dens", [(1000, 50, 128, 0.05), (777, 37, 100, 0.2), (5000, 300, 256, 0.03),
+                                        (130, 16, 72, 0.5), (64, 3, 68, 1.0), (4099, 513, 132, 0.01),
+                                        (63, 1, 260, 0.9), (20000, 40, 66, 0.0)])
+def test_csr_dense_sandwich_wide_ell(dtype, n, m, r, dens):
+    """Dense operands with more than 64 columns take the wide interleaved-ELL kernel
+    (tm_csr_dense_sandwich_ellw_*, sparse.hip K3 wide): part widths that are not multiples of 128,
+    more than 256 sparse columns (blockIdx.z), row counts around the 64-row slab, blocks longer than
+    the 3 prefetched chunks (dense columns), rows excluded by d == 0, an empty matrix."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(n + 3 * m + r)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng).astype(dtype)
+    B = rng.standard_normal((n, r)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[::7] = 0
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
+    assert sm._ell(wide=True).wide
+    ref = _orc().csr_dense_sandwich(S.tocsr().astype(np.float64), B.astype(np.float64),
+                                    d.astype(np.float64), None, None, None)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < tol
+    rows = _rows_subset(rng, n)
+    ref_r = _orc().csr_dense_sandwich(S.tocsr().astype(np.float64), B.astype(np.float64),
+                                      d.astype(np.float64), rows, None, None)
+    assert rel_err(sm._cross_sandwich(dm, d, rows), ref_r) < tol
+
+
 # ------------------------------------------------------------------ K6 sparse matvec
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sparse_matvec_rmatvec(dtype):
