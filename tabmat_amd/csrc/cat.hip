@@ -571,6 +571,113 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
 }
 
+// C-ordered dense, wide loads (the fast path for aligned operands and <= 4 categoricals):
+// a wave step covers MCW_RS = 32 rows x TJ = 16 * VEC columns (VEC = columns per 16-byte load):
+// 8 global_load_dwordx4 per lane bring the 32 rows in (16 lanes per row, 4 rows per instruction),
+// d and the codes arrive lane <-> row with one coalesced load each and are parked in a per-wave
+// LDS scratch as {d, byte offset of the level's tile row}, read back per 4-row group (4 distinct
+// addresses per read).  The loads of step t + 1 are in flight while step t issues its atomics
+// (two register sets, the loop is unrolled by two: no copies of in-flight loads).
+// Tile layout [level][TJ] with the columns of a lane de-interleaved: column c sits at
+// (c / VEC) + 16 * (c % VEC), so one ds_add covers 16 consecutive elements per row.
+// The narrow kernel above spends one 8-byte load instruction per lane and element and reloads the
+// codes in every lane: ~20 vector-memory instructions per 2 KB of the dense operand.
+constexpr int MCW_RS = 32;
+
+template <typename F, int NC>
+__global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
+    int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
+    constexpr int VEC = 16 / (int)sizeof(F);
+    constexpr int TJ = 16 * VEC;
+    constexpr int NI = MCW_RS / 4;               // load instructions per step
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][TJ], lane-column de-interleaved
+    const int nel = cs.total * TJ;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    // per-wave scratch: d[MCW_RS] then NC x int[MCW_RS] tile-row byte offsets (-1: no level)
+    unsigned char *scr = smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16 +
+                         (size_t)wave * MCW_RS * (sizeof(F) + NC * sizeof(int));
+    F *sd = reinterpret_cast<F *>(scr);
+    int *sc = reinterpret_cast<int *>(scr + MCW_RS * sizeof(F));
+    __syncthreads();
+    const int q = lane >> 4, jl = lane & 15;
+    const int64_t j = (int64_t)blockIdx.y * TJ + jl * VEC;
+    const int64_t jc = min(j, m - VEC);          // clamped (a part past the last column adds nothing)
+    const bool jok = j < m;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    const int64_t step = (int64_t)nwave * MCW_RS;
+    const int lr = lane & (MCW_RS - 1);          // row of the step this lane loads d / codes for
+
+    struct Regs { vec_t x[NI]; F dk; int code[NC]; };
+    auto load = [&](int64_t k0, Regs &R) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t k = min(k0 + 4 * i + q, n - 1);
+            R.x[i] = *reinterpret_cast<const vec_t *>(M + k * m + jc);
+        }
+        const int64_t k = k0 + lr;
+        const int64_t kc = min(k, n - 1);
+        R.dk = d[kc];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = cs.codes[c][kc] - cs.drop[c];
+            R.code[c] = (k < t1 && col >= 0) ? (cs.off[c] + col) * TJ * (int)sizeof(F) : -1;
+        }
+    };
+    auto process = [&](const Regs &R) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < MCW_RS) {
+            sd[lr] = R.dk;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)     // rows with d == 0 contribute exactly nothing
+                sc[c * MCW_RS + lr] = R.dk != F(0) ? R.code[c] : -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = 4 * i + q;
+            const F dk = sd[row];
+            int off[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) off[c] = sc[c * MCW_RS + row];
+            vec_t x = R.x[i];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[v] *= dk;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (jok && off[c] >= 0) {
+                    F *dst = reinterpret_cast<F *>(smem_raw + off[c]) + jl;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) atomic_add(dst + 16 * v, x[v]);
+                }
+            }
+        }
+    };
+    Regs ra, rb;
+    int64_t k0 = t0 + (int64_t)wave * MCW_RS;
+    if (k0 < t1) load(k0, ra);
+    for (; k0 < t1; k0 += 2 * step) {
+        const bool more = k0 + step < t1;
+        if (more) load(k0 + step, rb);
+        process(ra);
+        if (more) {
+            if (k0 + 2 * step < t1) load(k0 + 2 * step, ra);
+            process(rb);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) {
+        const int c = b % TJ;
+        dst[b] = tile[(b / TJ) * TJ + (c / VEC) + 16 * (c % VEC)];
+    }
+}
+
 // F-ordered dense: lane <-> row, loop over the TJ columns of the part.
 template <typename F, int TJ>
 __global__ __launch_bounds__(1024) void multi_cat_dense_f_kernel(
@@ -838,6 +945,51 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     if (total == 0) return TM_OK;
     TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
     if (n == 0) return TM_OK;
+    {
+        // wide-load path: C-ordered, 16-byte aligned rows, <= 4 categoricals, tile + scratch in LDS
+        constexpr int VEC = 16 / (int)sizeof(F);
+        constexpr int TJW = 16 * VEC;
+        const size_t tile_b = ((sizeof(F) * (size_t)cs.total * TJW + 15) / 16) * 16;
+        const size_t lds_w = tile_b + (size_t)16 * MCW_RS * (sizeof(F) + (size_t)n_cats * sizeof(int));
+        if (!order_f && n_cats <= 4 && m >= VEC && m % VEC == 0 &&
+            (reinterpret_cast<uintptr_t>(M) & 15) == 0 && lds_w <= 150 * 1024 &&
+            (int64_t)cs.total * TJW * (int64_t)sizeof(F) < (1ll << 30)) {
+            const int64_t n_parts = ceil_div(m, TJW);
+            const int64_t stride = (int64_t)cs.total * TJW;
+            int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
+            nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 4096)));
+            const int64_t rpb = ceil_div(ceil_div(n, nblk), MCW_RS) * MCW_RS;
+            nblk = ceil_div(n, rpb);
+            const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_parts * stride) + 255) / 256) * 256;
+            void *wsv = nullptr;
+            rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+            if (rc) return rc;
+            F *tmp = reinterpret_cast<F *>(wsv);
+            F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+            auto gow = [&](auto kern) -> int {
+                TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+                prof_begin(st);
+                hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(1024), lds_w, st,
+                                   cs, d, M, n, m, rpb, ws, stride);
+                prof_end(st);
+                TM_LAUNCH_CHECK();
+                return TM_OK;
+            };
+            if (n_cats == 1) rc = gow(&multi_cat_dense_wide_kernel<F, 1>);
+            else if (n_cats == 2) rc = gow(&multi_cat_dense_wide_kernel<F, 2>);
+            else if (n_cats == 3) rc = gow(&multi_cat_dense_wide_kernel<F, 3>);
+            else rc = gow(&multi_cat_dense_wide_kernel<F, 4>);
+            if (rc) return rc;
+            rc = launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, tmp, n_parts * stride,
+                                           false, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL((multi_cat_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)),
+                               dim3(256), 0, st, tmp, (int64_t)cs.total, m, TJW, out);
+            TM_LAUNCH_CHECK();
+            return TM_OK;
+        }
+    }
     int TJ = 64;
     while (TJ > 1 && sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) TJ >>= 1;
     while (TJ > 1 && TJ / 2 >= m) TJ >>= 1;
