@@ -476,20 +476,33 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     // branches, no arithmetic on a loaded value before the next load goes out): the number of
     // outstanding loads per iteration is then a compile-time constant and the s_waitcnt for a
     // value loaded two iterations ago leaves everything younger in flight.
+    // All indices are 32-bit offsets relative to the workgroup's row range [t0, t1) and to the
+    // first entry of that range in chunk I / chunk J (uniform bases in SGPRs): the clamps are single
+    // v_min_u32 and the loads use the SGPR-base + 32-bit-offset form instead of 64-bit arithmetic.
     struct Ptr { int a0, a1, b0, b1; F d; bool valid; };
     struct Grp { int pA, nA, pB, nB; F d; F va, vb, va2, vb2; int ca, cb, ca2, cb2; };
-    auto load_ptrs = [&](int64_t g0) {
+    const int nrows = (int)(t1 - t0);                       // < 2^31 (host: rows_per_block)
+    const int kmax = (int)min(n - 1 - t0, (int64_t)0x7fffffff);
+    const int32_t *cpA = cptr + (int64_t)I * pstride + t0;
+    const int32_t *cpB = cptr + (int64_t)J * pstride + t0;
+    const F *dW = d + t0;
+    const int baseA = __builtin_amdgcn_readfirstlane(cpA[0]);
+    const int baseB = __builtin_amdgcn_readfirstlane(cpB[0]);
+    const unsigned spanA1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpA[nrows]) - baseA - 1, 0);
+    const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[nrows]) - baseB - 1, 0);
+    const F *dataA = data + min((int64_t)baseA, nnz1), *dataB = data + min((int64_t)baseB, nnz1);
+    const int32_t *indA = ind + min((int64_t)baseA, nnz1), *indB = ind + min((int64_t)baseB, nnz1);
+    auto load_ptrs = [&](int g) {              // g: first row of the group, relative to t0
         Ptr q;
-        const int64_t k = g0 + lr;
-        q.valid = k < t1;
-        const int64_t kc = min(k, n - 1);
-        const int32_t *cpa = cptr + (int64_t)I * pstride + kc;
-        const int32_t *cpb = cptr + (int64_t)J * pstride + kc;
-        q.d = d[kc];
-        q.a0 = cpa[0];
-        q.a1 = cpa[1];
-        q.b0 = cpb[0];
-        q.b1 = cpb[1];
+        const int k = g + lr;
+        q.valid = k < nrows;
+        const unsigned kc = (unsigned)min(k, kmax);
+        const unsigned kb = kc << 2;
+        q.d = *reinterpret_cast<const F *>(reinterpret_cast<const char *>(dW) + kc * (unsigned)sizeof(F));
+        q.a0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb);
+        q.a1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb + 4);
+        q.b0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb);
+        q.b1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb + 4);
         return q;
     };
     auto load_entries = [&](const Ptr &q) {   // slots lt and lt + 8 of both lists: 16 entries per list
@@ -500,26 +513,36 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         e.pB = q.b0;
         e.nA = on ? q.a1 - q.a0 : 0;
         e.nB = on ? q.b1 - q.b0 : 0;
-        const int64_t iA = min((int64_t)e.pA + min(lt, max(e.nA - 1, 0)), nnz1);
-        const int64_t iB = min((int64_t)e.pB + min(lt, max(e.nB - 1, 0)), nnz1);
-        const int64_t iA2 = min((int64_t)e.pA + min(lt + 8, max(e.nA - 1, 0)), nnz1);
-        const int64_t iB2 = min((int64_t)e.pB + min(lt + 8, max(e.nB - 1, 0)), nnz1);
-        e.ca = ind[iA];
-        e.va = data[iA];
-        e.cb = ind[iB];
-        e.vb = data[iB];
-        e.ca2 = ind[iA2];
-        e.va2 = data[iA2];
-        e.cb2 = ind[iB2];
-        e.vb2 = data[iB2];
+        const unsigned rA = (unsigned)(q.a0 - baseA), rB = (unsigned)(q.b0 - baseB);
+        const unsigned lA = (unsigned)max(e.nA - 1, 0), lB = (unsigned)max(e.nB - 1, 0);
+        const unsigned iA = min(rA + min((unsigned)lt, lA), spanA1);
+        const unsigned iB = min(rB + min((unsigned)lt, lB), spanB1);
+        const unsigned iA2 = min(rA + min((unsigned)lt + 8u, lA), spanA1);
+        const unsigned iB2 = min(rB + min((unsigned)lt + 8u, lB), spanB1);
+        // 32-bit BYTE offsets (host: < 2^32 per workgroup range) -> SGPR base + VGPR offset loads
+        auto ldi = [](const int32_t *base, unsigned i) {
+            return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (i << 2));
+        };
+        auto ldf = [](const F *base, unsigned i) {
+            return *reinterpret_cast<const F *>(reinterpret_cast<const char *>(base) +
+                                                (i * (unsigned)sizeof(F)));
+        };
+        e.ca = ldi(indA, iA);
+        e.va = ldf(dataA, iA);
+        e.cb = ldi(indB, iB);
+        e.vb = ldf(dataB, iB);
+        e.ca2 = ldi(indA, iA2);
+        e.va2 = ldf(dataA, iA2);
+        e.cb2 = ldi(indB, iB2);
+        e.vb2 = ldf(dataB, iB2);
         return e;
     };
-    const int64_t gstep = (int64_t)K2_WAVES * 8;
-    const int64_t gw = t0 + (int64_t)wave * 8;
-    Grp es[K2_ED];
+    const int gstep = K2_WAVES * 8;
+    const int gw = wave * 8;
+    Grp ea[K2_ED], eb[K2_ED];      // two register sets: the loop is unrolled by two turns
     Ptr ps[K2_NP];
 #pragma unroll
-    for (int i = 0; i < K2_ED; ++i) es[i] = load_entries(load_ptrs(gw + i * gstep));
+    for (int i = 0; i < K2_ED; ++i) ea[i] = load_entries(load_ptrs(gw + i * gstep));
 #pragma unroll
     for (int i = 0; i < K2_NP; ++i) ps[i] = load_ptrs(gw + (K2_ED + i) * gstep);
     const int pa = lane >> 3, pb = lane & 7;       // (a, b) of an 8 x 8 block (long-list fallback)
@@ -635,18 +658,25 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
             }
         }
     };
-    // Two groups per turn: both groups' prefetched entries are taken over, the loads of the next
-    // turn (entries of g + 2, g + 3 from the pointers fetched last turn; pointers of g + 4, g + 5)
-    // are issued back to back, then the two groups are processed -- every load has two groups of
-    // LDS work to land before the next turn touches it.
-    for (int64_t g0 = gw; g0 < t1; g0 += 2 * gstep) {
-        const Grp cur0 = es[0], cur1 = es[1];
-        es[0] = load_entries(ps[0]);
-        es[1] = load_entries(ps[1]);
-        ps[0] = load_ptrs(g0 + 4 * gstep);
-        ps[1] = load_ptrs(g0 + 5 * gstep);
-        process(cur0);
-        if (g0 + gstep < t1) process(cur1);
+    // Two groups per turn: the loads of the next turn (entries of g + 2, g + 3 from the pointers
+    // fetched last turn; pointers of g + 4, g + 5) are issued back to back, then the two groups of
+    // this turn are processed -- every load has two groups of work to land before it is touched.
+    // Two turns per iteration with alternating entry registers: no register copies of values that
+    // are still in flight (a copy would wait for the load).
+    for (int g = gw; g < nrows; g += 4 * gstep) {
+        eb[0] = load_entries(ps[0]);
+        eb[1] = load_entries(ps[1]);
+        ps[0] = load_ptrs(g + 4 * gstep);
+        ps[1] = load_ptrs(g + 5 * gstep);
+        process(ea[0]);
+        if (g + gstep < nrows) process(ea[1]);
+        if (g + 2 * gstep >= nrows) break;
+        ea[0] = load_entries(ps[0]);
+        ea[1] = load_entries(ps[1]);
+        ps[0] = load_ptrs(g + 6 * gstep);
+        ps[1] = load_ptrs(g + 7 * gstep);
+        process(eb[0]);
+        if (g + 3 * gstep < nrows) process(eb[1]);
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
@@ -952,6 +982,14 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int cap = (int)std::max<int64_t>(1, ceil_div(n, 1024));
     nb_diag = std::min(nb_diag, cap);
     nb_off = std::min(nb_off, cap);
+    // the kernel indexes rows and entries relative to a workgroup's range with 32 bits
+    // (byte offsets: rows per workgroup * 128 entries * 8 bytes must stay below 2^32)
+    {
+        const int min_nb = (int)ceil_div(n, (int64_t)1 << 21);
+        nb_diag = std::max(nb_diag, min_nb);
+        nb_off = std::max(nb_off, min_nb);
+    }
+    TM_REQUIRE(nnz < (1ll << 31), "sparse block too large for the tiled sandwich (nnz >= 2^31)");
     const int64_t nblk = std::max(nb_diag, nb_off);   // stride of the partial-tile buffer
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)n_parts * TS * TS);
     void *wsv = nullptr;
