@@ -1609,6 +1609,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ell_kernel(
 // =======================================================================================
 constexpr int ELLW_R = 64;
 constexpr int ELLW_C = 16;
+constexpr int ELLW_NW = 256 / ELLW_C;               // waves per workgroup: 256 sparse columns
+constexpr int ELLW_THREADS = ELLW_NW * 64;
+constexpr int ELLW_U = 64 / ELLW_C;                  // slots per column and iteration
 constexpr int ELLW_W = 128;                          // dense columns per part
 constexpr int ELLW_HC = 3;                           // chunks of a block prefetched one slab ahead
 constexpr int ELLW_SK = 2;                           // slots per skip batch
@@ -1620,11 +1623,11 @@ struct EllwLds {
     static constexpr int ZERO_OFF = 2 * SLABB;
     static constexpr int DL_OFF = ZERO_OFF + ROWB;
     static constexpr int RING_OFF = DL_OFF + 2 * ELLW_R * (int)sizeof(F);
-    static constexpr int TOTAL = RING_OFF + GATHER_NW * 64 * (int)sizeof(F);
+    static constexpr int TOTAL = RING_OFF + ELLW_NW * 64 * (int)sizeof(F);
 };
 
 template <typename F>
-__global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ellw_kernel(
+__global__ __launch_bounds__(ELLW_THREADS) void csr_dense_ellw_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ gptr,
     int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n,
     int64_t r, int nB, const F *__restrict__ d, F *__restrict__ ws) {
@@ -1633,13 +1636,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ellw_kernel(
     constexpr int VEC = 16 / (int)sizeof(F);
     constexpr int ROWB = L::ROWB;
     constexpr int SLABB = L::SLABB;
-    constexpr int NV = SLABB / 16 / GATHER_THREADS;      // 16-byte pieces staged per thread
+    constexpr int NV = SLABB / 16 / ELLW_THREADS;      // 16-byte pieces staged per thread
     constexpr int RPP = 1024 / ROWB;                     // slab rows per 1 KiB wave piece (1 or 2)
     typedef F pair_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = blockIdx.z * GATHER_NW + wave;
+    const int group = blockIdx.z * ELLW_NW + wave;
     const bool active = group < n_groups;
     const int j0 = blockIdx.y * ELLW_W;
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
@@ -1651,7 +1654,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ellw_kernel(
     pair_t acc[ELLW_C];
 #pragma unroll
     for (int c = 0; c < ELLW_C; ++c) acc[c] = pair_t{F(0), F(0)};
-    for (int i = tid; i < ROWB / (int)sizeof(F); i += GATHER_THREADS)
+    for (int i = tid; i < ROWB / (int)sizeof(F); i += ELLW_THREADS)
         reinterpret_cast<F *>(smem_raw + L::ZERO_OFF)[i] = F(0);
 
     F dsc = F(0);
@@ -1770,7 +1773,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_dense_ellw_kernel(
                         a[e] = av[0];
                         a[e + 1] = av[1];
                     }
-                    pair_t &A = acc[g0 / 4];
+                    pair_t &A = acc[g0 / ELLW_U];
 #pragma unroll
                     for (int e = 0; e < ELLW_SK; ++e) {
                         A[0] = fma(a[e], x[e][0], A[0]);
@@ -1933,7 +1936,7 @@ static int run_csr_dense_ellw(const F *vals, const unsigned *koff, const int64_t
     const int64_t n_slabs = ceil_div(n, ELLW_R);
     const int n_groups = (int)(m / ELLW_C);
     const int n_parts = (int)ceil_div(nB, ELLW_W);
-    const int nz = (int)ceil_div(n_groups, GATHER_NW);
+    const int nz = (int)ceil_div(n_groups, ELLW_NW);
     if (n_slabs == 0) {
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
         return TM_OK;
@@ -1955,7 +1958,7 @@ static int run_csr_dense_ellw(const F *vals, const unsigned *koff, const int64_t
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(GATHER_THREADS),
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(ELLW_THREADS),
                        lds, st, vals, koff, gptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
