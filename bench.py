@@ -108,10 +108,14 @@ def kernel_breakdown(mat, d, reps=3):
                 if isinstance(mw, tm.DenseMatrix):
                     from tabmat_amd.ext import sparse as xs
 
-                    cat_ids = [k for k, m in enumerate(mats) if isinstance(m, tm.CategoricalMatrix)]
-                    oh, _ = mat._onehot_slab(cat_ids)
-                    fused.append((f"allcats_x_dense{i}", lambda mw=mw, oh=oh: xs.csr_dense_sandwich_slab(
-                        oh, mw._dev(), d)))
+                    if xsplit.multi_cat_dense_wide_ok(cats, mw._dev()):      # same choice as the product
+                        fused.append((f"allcats_x_dense{i}", lambda mw=mw: xsplit.multi_cat_dense_sandwich(
+                            cats, d, mw._dev())))
+                    else:
+                        cat_ids = [k for k, m in enumerate(mats) if isinstance(m, tm.CategoricalMatrix)]
+                        oh, _ = mat._onehot_slab(cat_ids)
+                        fused.append((f"allcats_x_dense{i}", lambda mw=mw, oh=oh: xs.csr_dense_sandwich_slab(
+                            oh, mw._dev(), d)))
                 elif isinstance(mw, tm.SparseMatrix):
                     fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
                         cats, d, mw._slab())))

@@ -2,8 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows if "tmh::" in r["Name"])
-print("# csr_dense_gather_kernel is launched twice per step (sparse x dense: the larger time = bench.py's")
-print("# dense0xsparse1; one-hot categoricals x dense: the smaller = allcats_x_dense0): see min_ms / max_ms.")
+print("# per-kernel durations of one rocprofv3 --kernel-trace --stats run of bench.py (tabmat kernels only)")
 print(f"{'kernel':60s} {'calls':>6s} {'avg_ms':>10s} {'min_ms':>10s} {'max_ms':>10s} {'total_ms':>10s} {'%tmh':>6s}")
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
     if "tmh::" not in r["Name"]:

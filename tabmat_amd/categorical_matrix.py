@@ -308,8 +308,10 @@ class CategoricalMatrix(MatrixBase):
         """X' diag(d) Y, device in / device out (categorical_matrix.py:655-671)."""
         if isinstance(other, DenseMatrix):
             if self.shape[0] >= 4096 and self.shape[1] > 0:
-                # large n: atomic-free gather kernel on the one-hot slab (masked d for a row
-                # restriction, sub-selection of the small result for column restrictions)
+                # large n: one pass over the whole dense block (masked d for a row restriction,
+                # sub-selection of the small result for column restrictions) -- the wide-load LDS
+                # tile kernel when the levels fit one tile, else the atomic-free gather kernel on
+                # the one-hot slab
                 from .ext import sparse as xs
 
                 if rows is not None:
@@ -317,8 +319,13 @@ class CategoricalMatrix(MatrixBase):
                     r64 = rows.to(torch.int64)
                     dm[r64] = d[r64]
                     d = dm
-                oh, inv = self._onehot()
-                res = xs.csr_dense_sandwich_slab(oh, other._dev(), d)[inv]
+                cats = [(self._dev(), self.shape[1], self.drop_first)]
+                if (other.dtype == self.dtype and d.dtype == other._dev().buf.dtype
+                        and xsplit.multi_cat_dense_wide_ok(cats, other._dev())):
+                    res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev())
+                else:
+                    oh, inv = self._onehot()
+                    res = xs.csr_dense_sandwich_slab(oh, other._dev(), d)[inv]
                 return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_dense(self._dev(), self.shape[1], d, other._dev(), rows,
                                             R_cols, self.drop_first)
