@@ -409,6 +409,44 @@ def test_cat_dense(order, ncat, k):
     assert rel_err(cm._cross_sandwich(dm, d, rows, lc, jc), ref) < F64_TOL
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,k,ncats", [(1, 4, (3,)), (31, 32, (5, 2)), (32, 36, (7,)), (33, 128, (256, 96, 32)),
+                                       (4097, 132, (11, 3, 2, 9)), (70_000, 8, (300, 40)), (5000, 260, (64,))])
+def test_multi_cat_dense_wide_kernel(dtype, n, k, ncats):
+    """tm_multi_cat_dense_sandwich_* on its wide-load path (cat.hip multi_cat_dense_wide_kernel):
+    1..4 categoricals, row counts around the 32-row wave step, column counts that are not multiples
+    of the 16 * VEC part width, drop_first, missing codes, rows with d == 0 holding inf."""
+    import tabmat_amd as tm
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import split as xsplit
+
+    rng = np.random.default_rng(n + k + len(ncats))
+    X = rng.standard_normal((n, k)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[::5] = 0
+    X[::5, 0] = np.inf                      # excluded rows must not leak inf * 0
+    dm = tm.DenseMatrix(X)
+    cats, blocks = [], []
+    for ci, nc in enumerate(ncats):
+        codes = rng.integers(0, nc, n).astype(np.int32)
+        codes[rng.random(n) < 0.05] = -1
+        drop = bool(ci % 2)
+        cm = to_tm_block(("cat", codes, nc, drop), dtype)
+        blocks.append((codes, cm.shape[1], drop))
+        cats.append((cm._dev(), cm.shape[1], drop))
+    assert xsplit.multi_cat_dense_wide_ok(cats, dm._dev())
+    res = D.to_host(xsplit.multi_cat_dense_sandwich(cats, D.to_dev(d), dm._dev()))
+    Xc = X.astype(np.float64).copy()
+    Xc[::5, 0] = 0.0
+    orc, off = _orc(), 0
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    for codes, ncol, drop in blocks:
+        ref = orc.sandwich_cat_dense(codes, ncol, d.astype(np.float64), Xc, None, None, drop)
+        assert rel_err(res[off:off + ncol], ref) < tol
+        off += ncol
+    assert off == res.shape[0]
+
+
 @pytest.mark.parametrize("ncat,m", [(5, 3), (256, 512), (1000, 100), (3000, 2000)])
 def test_cat_sparse(ncat, m):
     import tabmat_amd as tm
