@@ -320,12 +320,12 @@ class CategoricalMatrix(MatrixBase):
                     dm[r64] = d[r64]
                     d = dm
                 cats = [(self._dev(), self.shape[1], self.drop_first)]
-                if (other.dtype == self.dtype and d.dtype == other._dev().buf.dtype
-                        and xsplit.multi_cat_dense_wide_ok(cats, other._dev())):
-                    res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev())
+                if (other.dtype == self.dtype and d.dtype == other._dev_c().buf.dtype
+                        and xsplit.multi_cat_dense_wide_ok(cats, other._dev_c())):
+                    res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev_c())
                 else:
                     oh, inv = self._onehot()
-                    res = xs.csr_dense_sandwich_slab(oh, other._dev(), d)[inv]
+                    res = xs.csr_dense_sandwich_slab(oh, other._dev_c(), d)[inv]
                 return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_dense(self._dev(), self.shape[1], d, other._dev(), rows,
                                             R_cols, self.drop_first)

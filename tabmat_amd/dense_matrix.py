@@ -3,6 +3,7 @@
 matvec / transpose_matvec -> streaming gemv kernels (tabmat_amd/csrc/dense.hip)."""
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -21,6 +22,11 @@ from .util import (
     normalize_index,
     np_dtype_of,
 )
+
+
+# F-ordered blocks get a row-major twin in HBM for the sandwich kernels (DenseMatrix._dev_c);
+# TABMAT_AMD_ROW_MAJOR_TWIN=0 keeps the caller's layout only (column-major kernel variants).
+ROW_MAJOR_TWIN = os.environ.get("TABMAT_AMD_ROW_MAJOR_TWIN", "1") != "0"
 
 
 class DenseMatrix(MatrixBase):
@@ -65,9 +71,29 @@ class DenseMatrix(MatrixBase):
             self._devblk = DenseDev.from_host(self._array)
         return self._devblk
 
+    def _dev_c(self) -> DenseDev:
+        """C-ordered (row-major) device view for the sandwich kernels.  An F-ordered block gets a
+        row-major TWIN in HBM on first use (the kernels that stream rows -- MFMA syrk, the gather
+        K3, categorical x dense -- are built around 16-byte row segments; the reference likewise
+        keeps a CSR twin next to its CSC arrays, sparse_matrix.py:133-143).  matvec /
+        transpose_matvec keep using the caller's layout.  When HBM is short the native layout is
+        returned and the (slower) column-major kernel variants run."""
+        blk = self._dev()
+        if not blk.order_f or not ROW_MAJOR_TWIN:
+            return blk
+        twin = getattr(self, "_devblk_c", None)
+        if twin is None:
+            need = blk.buf.numel() * blk.buf.element_size()
+            free = torch.cuda.mem_get_info(blk.buf.device)[0] if blk.buf.is_cuda else 0
+            if free < 2 * need + (1 << 30):
+                return blk
+            twin = DenseDev(blk.as_2d().contiguous(), blk.n, blk.m, 0)
+            self._devblk_c = twin
+        return twin
+
     def to_device(self):
         """Upload now (otherwise the first product does it)."""
-        self._dev()
+        self._dev_c()
         return self
 
     @property
@@ -127,7 +153,7 @@ class DenseMatrix(MatrixBase):
 
     # ---- hot path -----------------------------------------------------------------------
     def _sandwich_dev(self, d, rows, cols):
-        return xd.dense_sandwich(self._dev(), d, rows, cols)
+        return xd.dense_sandwich(self._dev_c(), d, rows, cols)
 
     def sandwich(self, d, rows=None, cols=None):
         """X[rows, cols].T @ diag(d[rows]) @ X[rows, cols] (dense_matrix.py:153-163)."""

@@ -232,7 +232,7 @@ class SparseMatrix(MatrixBase):
                     "self, B and d all need to be of same dtype, either np.float64 or "
                     f"np.float32. This matrix is of type {self.dtype}, B is of type "
                     f"{other.dtype}.")
-            Bd = other._dev()
+            Bd = other._dev_c()
             if self.shape[0] > 0 and self._dev().data.numel() > 0 and (
                     rows is None or self._values_finite()):
                 # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded

@@ -172,7 +172,7 @@ class SplitMatrix(MatrixBase):
         if 1 <= len(cat_ids) <= xsplit.MAX_FUSED_CATS:
             cats = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
                     for i in cat_ids]
-            if any(isinstance(m, DenseMatrix) and not xsplit.multi_cat_dense_wide_ok(cats, m._dev())
+            if any(isinstance(m, DenseMatrix) and not xsplit.multi_cat_dense_wide_ok(cats, m._dev_c())
                    for m in self.matrices):
                 self._onehot_slab(cat_ids)
         return self
@@ -272,17 +272,17 @@ class SplitMatrix(MatrixBase):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
                 stacked = None
-                if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_wide_ok(cats, mw._dev()):
+                if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_wide_ok(cats, mw._dev_c()):
                     # few enough levels for one LDS tile: one pass of 16-byte loads over the dense
                     # block, one LDS atomic per (row, categorical, 16 columns)
-                    stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev())
+                    stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
                 elif isinstance(mw, DenseMatrix):
                     # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
                     # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
                     from .ext import sparse as xs
 
                     oh, inv = self._onehot_slab(cat_ids)
-                    stacked = xs.csr_dense_sandwich_slab(oh, mw._dev(), d_eff)[inv]
+                    stacked = xs.csr_dense_sandwich_slab(oh, mw._dev_c(), d_eff)[inv]
                 elif (isinstance(mw, SparseMatrix) and total * 33 <= budget
                       and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
                     stacked = xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())

@@ -254,6 +254,39 @@ def test_csr_dense_sandwich_wide_ell(dtype, n, m, r, dens):
     assert rel_err(sm._cross_sandwich(dm, d, rows), ref_r) < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_f_ordered_dense_block_uses_row_major_twin(dtype):
+    """An F-ordered dense block gets a row-major twin in HBM for the sandwich kernels
+    (DenseMatrix._dev_c): same results as the column-major kernel variants and as the oracle;
+    matvec / transpose_matvec keep the caller's layout."""
+    import tabmat_amd as tm
+    import tabmat_amd.dense_matrix as dmod
+
+    specs, idx = cs.mixed_specs(9000, 130, 70, (9, 4), seed=5, dtype=dtype, order="F")
+    assert specs[0][1].flags["F_CONTIGUOUS"]
+    rng = np.random.default_rng(8)
+    d = rng.random(9000).astype(dtype)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    ref = _orc().split_sandwich([cs.to_oracle_block(s) for s in specs], idx, d.astype(np.float64), None)
+    assert dmod.ROW_MAJOR_TWIN
+    mat = to_tm_split(specs, idx, dtype)
+    res_twin = mat.sandwich(d)
+    dense = mat.matrices[0]
+    assert dense._dev().order_f == 1 and dense._dev_c().order_f == 0
+    assert dense._dev_c() is dense._dev_c()          # built once
+    assert rel_err(res_twin, ref) < tol
+    dmod.ROW_MAJOR_TWIN = False
+    try:
+        mat2 = to_tm_split(specs, idx, dtype)
+        assert mat2.matrices[0]._dev_c().order_f == 1
+        assert rel_err(mat2.sandwich(d), ref) < tol
+    finally:
+        dmod.ROW_MAJOR_TWIN = True
+    v = rng.standard_normal(mat.shape[1]).astype(dtype)
+    E = np.hstack([np.asarray(cs.spec_toarray(s), dtype=np.float64) for s in specs])
+    assert rel_err(mat.matvec(v), E @ v.astype(np.float64)) < tol
+
+
 # ------------------------------------------------------------------ K6 sparse matvec
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_sparse_matvec_rmatvec(dtype):
