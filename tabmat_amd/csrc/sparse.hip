@@ -482,7 +482,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     struct Ptr { int a0, a1, b0, b1; F d; bool valid; };
     struct Grp { int pA, nA, pB, nB; F d; F va, vb, va2, vb2; int ca, cb, ca2, cb2; };
     const int nrows = (int)(t1 - t0);                       // < 2^31 (host: rows_per_block)
-    const int kmax = (int)min(n - 1 - t0, (int64_t)0x7fffffff);
+    const int kmax = (int)max((int64_t)0, min(n - 1 - t0, (int64_t)0x7fffffff));
     const int32_t *cpA = cptr + (int64_t)I * pstride + t0;
     const int32_t *cpB = cptr + (int64_t)J * pstride + t0;
     const F *dW = d + t0;
