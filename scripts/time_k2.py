@@ -11,4 +11,4 @@ ts = []
 for _ in range(4):
     sm._sandwich_dev(d, None, None)
     ms = C.c_float(0); _lib.call("tm_profile_last_ms", C.byref(ms)); ts.append(ms.value)
-print(f"K2 nbdiag={os.environ.get('TM_K2_NBDIAG','even')}: {min(ts):.3f} ms")
+print(f"K2: {min(ts):.3f} ms")

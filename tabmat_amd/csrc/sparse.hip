@@ -492,6 +492,11 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[nrows]) - baseB - 1, 0);
     const F *dataA = data + min((int64_t)baseA, nnz1), *dataB = data + min((int64_t)baseB, nnz1);
     const int32_t *indA = ind + min((int64_t)baseA, nnz1), *indB = ind + min((int64_t)baseB, nnz1);
+    // The whole pipeline is instantiated twice: DIAG (I == J: one list per row, loaded once, pairs
+    // b <= a) and off-diagonal (two lists); the choice is workgroup-uniform and made once, outside
+    // the load pipeline (a branch inside it would bring the conservative s_waitcnt back).
+    auto run_tile = [&](auto diag_c) {
+    constexpr bool DIAG = decltype(diag_c)::value;
     auto load_ptrs = [&](int g) {              // g: first row of the group, relative to t0
         Ptr q;
         const int k = g + lr;
@@ -501,8 +506,12 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         q.d = *reinterpret_cast<const F *>(reinterpret_cast<const char *>(dW) + kc * (unsigned)sizeof(F));
         q.a0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb);
         q.a1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb + 4);
-        q.b0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb);
-        q.b1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb + 4);
+        if constexpr (!DIAG) {      // a diagonal tile pairs the I-list with itself: loaded once
+            q.b0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb);
+            q.b1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpB) + kb + 4);
+        } else {
+            q.b0 = q.b1 = 0;
+        }
         return q;
     };
     auto load_entries = [&](const Ptr &q) {   // slots lt and lt + 8 of both lists: 16 entries per list
@@ -512,13 +521,11 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         e.pA = q.a0;
         e.pB = q.b0;
         e.nA = on ? q.a1 - q.a0 : 0;
-        e.nB = on ? q.b1 - q.b0 : 0;
+        e.nB = DIAG ? 0 : (on ? q.b1 - q.b0 : 0);
         const unsigned rA = (unsigned)(q.a0 - baseA), rB = (unsigned)(q.b0 - baseB);
         const unsigned lA = (unsigned)max(e.nA - 1, 0), lB = (unsigned)max(e.nB - 1, 0);
         const unsigned iA = min(rA + min((unsigned)lt, lA), spanA1);
-        const unsigned iB = min(rB + min((unsigned)lt, lB), spanB1);
         const unsigned iA2 = min(rA + min((unsigned)lt + 8u, lA), spanA1);
-        const unsigned iB2 = min(rB + min((unsigned)lt + 8u, lB), spanB1);
         // 32-bit BYTE offsets (host: < 2^32 per workgroup range) -> SGPR base + VGPR offset loads
         auto ldi = [](const int32_t *base, unsigned i) {
             return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (i << 2));
@@ -529,12 +536,21 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         };
         e.ca = ldi(indA, iA);
         e.va = ldf(dataA, iA);
-        e.cb = ldi(indB, iB);
-        e.vb = ldf(dataB, iB);
         e.ca2 = ldi(indA, iA2);
         e.va2 = ldf(dataA, iA2);
-        e.cb2 = ldi(indB, iB2);
-        e.vb2 = ldf(dataB, iB2);
+        if constexpr (!DIAG) {
+            const unsigned iB = min(rB + min((unsigned)lt, lB), spanB1);
+            const unsigned iB2 = min(rB + min((unsigned)lt + 8u, lB), spanB1);
+            e.cb = ldi(indB, iB);
+            e.vb = ldf(dataB, iB);
+            e.cb2 = ldi(indB, iB2);
+            e.vb2 = ldf(dataB, iB2);
+        } else {
+            // the B side of a diagonal tile is read from the A fields in process() (no copies
+            // of values that are still in flight)
+            e.cb = e.cb2 = 0;
+            e.vb = e.vb2 = F(0);
+        }
         return e;
     };
     const int gstep = K2_WAVES * 8;
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     //            both validities and, on diagonal tiles (offmask 0), the b <= a triangle.
     constexpr int SH = sizeof(F) == 8 ? 3 : 2;
     constexpr int BIGKEY = 0x7ffffff0;
-    const int offmask = (I != J) ? 0x70000000 : 0;
+    constexpr int offmask = DIAG ? 0 : 0x70000000;
     char *const tile_bytes = reinterpret_cast<char *>(tile);
     auto a_lim = [&](int col) { return (col < 0 ? -8 : col << SH) | offmask; };
     auto a_base = [&](int col) { return (int)(((unsigned)col << (7 + SH)) | ((col & 15) << (3 + SH))); };
@@ -565,14 +581,15 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         if (kb <= la) atomic_add(reinterpret_cast<F *>(tile_bytes + (unsigned)(kb ^ ba)), prod);
     };
     auto process = [&](const Grp &cur) {
-        const int nA = cur.nA, nB = cur.nB, pA0 = cur.pA, pB0 = cur.pB;
+        const int nA = cur.nA, nB = DIAG ? cur.nA : cur.nB, pA0 = cur.pA, pB0 = DIAG ? cur.pA : cur.pB;
         const F dk = cur.d;
         // first halves (slots 0..7): every lane pairs its own A entry with the B entry of lane
         // (lane ^ s), s = 0..7, fetched with DPP moves inside the 8 lanes of its row -- 8 x 64
         // pairs = all 8 x 8 combinations of the 8 rows, no LDS scratch traffic
-        const int colA = lt < nA ? cur.ca - i0 : -1, colB = lt < nB ? cur.cb - j0 : -1;
+        const int colA = lt < nA ? cur.ca - i0 : -1;
+        const int colB = DIAG ? colA : (lt < nB ? cur.cb - j0 : -1);
         const int la = a_lim(colA), ba = a_base(colA), kb = b_key(colB);
-        const F av = cur.va * dk, vb = cur.vb;
+        const F av = cur.va * dk, vb = DIAG ? cur.va : cur.vb;
         add_pair(kb, la, ba, av * vb);
         add_pair(dpp_xor_i32<1>(kb), la, ba, av * dpp_xor<1>(vb));
         add_pair(dpp_xor_i32<2>(kb), la, ba, av * dpp_xor<2>(vb));
@@ -586,9 +603,9 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         // second halves (slots 8..15, ~19 % of the rows have one): slot 8 + k of a row is
         // broadcast to the row's 8 lanes, k = 0 .. (longest overhang of the 8 rows) - 1, ~2 steps
         const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
-        const int colB2 = lt + 8 < nB ? cur.cb2 - j0 : -1;
+        const int colB2 = lt + 8 < nB ? (DIAG ? cur.ca2 : cur.cb2) - j0 : -1;
         const int kb2 = b_key(colB2);
-        const F vb2 = cur.vb2;
+        const F vb2 = DIAG ? cur.va2 : cur.vb2;
         if (anyA2) {
             // A overhang x (B first half, B overhang)
             const int colA2 = lt + 8 < nA ? cur.ca2 - i0 : -1;
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                 }
             });
         }
-        if (anyB2 && I != J) {
+        if (!DIAG && anyB2) {
             // A first half x B overhang (empty on diagonal tiles: those columns are all > a's)
             const int kb2x = dpp_xor_i32<4>(kb2);
             const F vb2x = dpp_xor<4>(vb2);
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                         if (a < nAr && b < nBr) {
                             const int cb = ind[pBr + b] - j0;
                             const F vb = data[pBr + b];
-                            if (I != J || cb <= ca)
+                            if (!DIAG || cb <= ca)
                                 atomic_add(&tile[ca * TS + (cb ^ ((ca & 15) << 3))], va * vb);
                         }
                     }
@@ -678,6 +695,9 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         process(eb[0]);
         if (g + 3 * gstep < nrows) process(eb[1]);
     }
+    };
+    if (I == J) run_tile(std::true_type{});
+    else run_tile(std::false_type{});
     __syncthreads();
     F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
@@ -973,16 +993,16 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
     const size_t lds = sizeof(F) * (size_t)(TS * TS);   // the tile only: pairs are formed in registers
-    // workgroups per tile.  Measured: diagonal and off-diagonal tiles cost the same per row (the
-    // per-row loads dominate, not the pair count), so the split is even; the off-diagonal tiles
-    // take the workgroups left over by the integer division (25 / 26 at 512 columns: all 256 CUs).
+    // workgroups per tile.  A diagonal tile (one list per row, pairs b <= a, no B-overhang phase)
+    // costs ~0.75 of an off-diagonal one per row (measured: 22 / 28 workgroups per tile is the
+    // optimum at 512 columns, 4.74 ms against 5.10 ms for 24 / 26): split the CUs by that weight.
     const int n_off = n_parts - nchunk;
-    int nb_diag = std::max(1, NUM_CU / n_parts);
-    int nb_off = n_off > 0 ? std::max(nb_diag, (NUM_CU - nchunk * nb_diag) / n_off) : nb_diag;
-    const int cap = (int)std::max<int64_t>(1, ceil_div(n, 1024));
+    int nb_off = n_off > 0 ? std::max(1, (int)(NUM_CU / (n_off + 0.75 * nchunk))) : 0;
+    int nb_diag = std::max(1, (NUM_CU - n_off * nb_off) / nchunk);
+    if (n_off == 0) nb_off = nb_diag;
+    const int cap = (int)std::max<int64_t>(1, ceil_div(n, 1024));      // small n: fewer workgroups
     nb_diag = std::min(nb_diag, cap);
     nb_off = std::min(nb_off, cap);
-    // the kernel indexes rows and entries relative to a workgroup's range with 32 bits
     // (byte offsets: rows per workgroup * 128 entries * 8 bytes must stay below 2^32)
     {
         const int min_nb = (int)ceil_div(n, (int64_t)1 << 21);
