@@ -233,6 +233,8 @@ def cpu_baseline(workload, rows, seed):
 
 def main():
     args = parse_args()
+    # RCCL / device-memory sharing across the ranks of one node needs dmabuf IPC on this driver
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
