@@ -124,10 +124,14 @@ class SparseMatrix(MatrixBase):
             setattr(self, name, SlabEll.from_csr(self._dev(), wide=wide))
         return getattr(self, name)
 
-    def to_device(self):
+    def to_device(self, dense_width=None):
+        """Upload and build the twins now (otherwise the first product does it).  dense_width:
+        columns of the dense block this one will be crossed with (SplitMatrix.to_device passes it)
+        -- selects the interleaved-ELL geometry to pre-build; None builds none."""
         self._dev().chunk_major()
         self._slab()
-        self._ell()
+        if dense_width is not None and dense_width > 0:
+            self._ell(wide=dense_width > 64)
         return self
 
     @property

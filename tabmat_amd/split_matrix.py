@@ -164,8 +164,12 @@ class SplitMatrix(MatrixBase):
         return self._dev_indices
 
     def to_device(self):
+        dense_w = [m.shape[1] for m in self.matrices if isinstance(m, DenseMatrix)]
         for m in self.matrices:
-            m.to_device()
+            if isinstance(m, SparseMatrix):
+                m.to_device(dense_width=dense_w[0] if dense_w else None)
+            else:
+                m.to_device()
         self._full_dev_indices()
         cat_ids = [i for i, m in enumerate(self.matrices)
                    if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
