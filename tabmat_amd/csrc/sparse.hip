@@ -1779,7 +1779,10 @@ __global__ __launch_bounds__(ELLW_THREADS) void csr_dense_ellw_kernel(
                 ring[lane] = a_cur;
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int g0 = 0; g0 < 64; g0 += ELLW_SK) {
+                for (int g8 = 0; g8 < 64; g8 += 8) {
+                if (((live >> g8) & 0xFFull) == 0) continue;       // two whole columns dead
+#pragma unroll
+                for (int g0 = g8; g0 < g8 + 8; g0 += ELLW_SK) {
                     if (((live >> g0) & ((1ull << ELLW_SK) - 1)) == 0) continue;   // padding / d == 0 slots
                     pair_t x[ELLW_SK];
                     F a[ELLW_SK];
@@ -1800,6 +1803,7 @@ __global__ __launch_bounds__(ELLW_THREADS) void csr_dense_ellw_kernel(
                         A[1] = fma(a[e], x[e][1], A[1]);
                     }
                     asm volatile("" : "+v"(A));      // pin the FMAs here
+                }
                 }
                 __builtin_amdgcn_wave_barrier();     // ring is rewritten by the next chunk
             };
