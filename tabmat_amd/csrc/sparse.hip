@@ -414,8 +414,11 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
 // streams chunk I and chunk J: the lists of the 8 rows of a group are ADJACENT (one coalesced
 // ~0.5 KB region per chunk) -- with the row-major CSR they were ~300 B apart and every (row, tile)
 // pulled 4 half-used sectors (32 GB of HBM traffic for 3.2 GB of data; loads alone 4.4 ms).
-// Lane (a, b) = (lane>>3, lane&7) pairs entry a of the I-list with entry b of the J-list and
-// issues one ds_add_f64 into the LDS tile -- no ballots, no compaction.
+// A wave takes 8 rows at a time, 8 lanes per row: lane t holds slot t of the row's I-list and of
+// its J-list.  All 8 x 8 pairs of the 8 rows are formed in registers: step s = 0..7 moves the
+// J entry of lane t ^ s to lane t with DPP (quad_perm / row_half_mirror) and issues one
+// ds_add_f64 into the LDS tile; slots 8..15 are broadcast inside the row's 8 lanes (quad_perm +
+// bank_mask).  No LDS scratch, no ballots, no compaction.
 // ---------------------------------------------------------------------------------------
 constexpr int K2_ED = 2;   // groups whose entry loads are in flight
 constexpr int K2_NP = 2;   // further groups whose chunk-pointer loads are in flight
