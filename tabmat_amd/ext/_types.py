@@ -181,9 +181,12 @@ class SlabEll:
     wide: bool = False     # geometry of the wide kernel (tm_csr_dense_sandwich_ellw_*)
 
     @staticmethod
-    def from_csr(csr: CsrDev, wide: bool = False) -> "SlabEll":
+    def from_csr(csr: CsrDev, wide: bool = False, max_pad: float = None) -> "SlabEll":
         """wide=True: geometry of tm_csr_dense_sandwich_ellw_* (64-row slabs of 128 dense columns,
-        16 columns x 4 slots per iteration) instead of tm_csr_dense_sandwich_ell_*."""
+        16 columns x 4 slots per iteration) instead of tm_csr_dense_sandwich_ell_*.
+        max_pad: give up (return None) when the padded stream would exceed max_pad x nnz slots --
+        every non-empty (slab, group) costs at least 64 slots, so a very sparse block (<< 1 nonzero
+        per slab and column group) would blow up to ~0.75 bytes per matrix cell."""
         from .._lib import lib
 
         R = int(lib().tm_ellw_rows() if wide else lib().tm_slab_rows())
@@ -219,6 +222,8 @@ class SlabEll:
         if S * G:
             torch.cumsum(iters * 64, dim=0, out=gptr[1:])
         total = int(gptr[-1].item())
+        if max_pad is not None and total > max_pad * max(nnz, 1) and total > (1 << 22):
+            return None        # too sparse for padded iterations: the caller keeps the compact stream
         vals = torch.zeros(total, dtype=csr.data.dtype, device=dev)
         koff = torch.full((total,), -1, dtype=torch.int32, device=dev)      # 0xFFFFFFFF = padding
         if nnz:

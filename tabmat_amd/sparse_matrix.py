@@ -20,6 +20,11 @@ from .util import (
 )
 
 
+# The interleaved-ELL twin pads every non-empty (slab, column group) to whole 64-slot iterations
+# (x1.9 .. x2.5 at 5 % density); beyond this factor the compact slab stream is used instead.
+ELL_MAX_PAD = 8.0
+
+
 class SparseMatrix(MatrixBase):
     """Instantiated like scipy.sparse.csc_matrix (sparse_matrix.py:35-79), or from a ready
     CsrDev (device CSR twin) via SparseMatrix.from_device."""
@@ -121,8 +126,10 @@ class SparseMatrix(MatrixBase):
         wide: the 128-dense-column geometry used when B has more than 64 columns."""
         name = "_ellwblk" if wide else "_ellblk"
         if getattr(self, name, None) is None:
-            setattr(self, name, SlabEll.from_csr(self._dev(), wide=wide))
-        return getattr(self, name)
+            twin = SlabEll.from_csr(self._dev(), wide=wide, max_pad=ELL_MAX_PAD)
+            setattr(self, name, twin if twin is not None else False)
+        twin = getattr(self, name)
+        return twin if twin is not False else None      # None: too sparse, use the compact slab form
 
     def to_device(self, dense_width=None):
         """Upload and build the twins now (otherwise the first product does it).  dense_width:
@@ -246,8 +253,9 @@ class SparseMatrix(MatrixBase):
                     r64 = rows.to(torch.int64)
                     dm[r64] = d[r64]
                     d = dm
-                if xs.ell_supported(Bd):
-                    res = xs.csr_dense_sandwich_ell(self._ell(wide=Bd.m > 64), Bd, d)
+                ell = self._ell(wide=Bd.m > 64) if xs.ell_supported(Bd) else None
+                if ell is not None:
+                    res = xs.csr_dense_sandwich_ell(ell, Bd, d)
                 else:
                     res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)
                 if L_cols is not None:

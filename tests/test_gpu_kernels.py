@@ -254,6 +254,23 @@ def test_csr_dense_sandwich_wide_ell(dtype, n, m, r, dens):
     assert rel_err(sm._cross_sandwich(dm, d, rows), ref_r) < tol
 
 
+def test_very_sparse_block_keeps_the_compact_stream():
+    """Every non-empty (slab, column group) of the interleaved-ELL twin costs 64 slots; a block
+    with far less than one nonzero per slab and group falls back to the compact slab stream
+    (SparseMatrix._ell -> None) instead of a twin dozens of times its size."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(77)
+    n, m, r = 400_000, 512, 128
+    S = sps.random(n, m, density=0.0005, format="csc", random_state=rng)
+    B = rng.standard_normal((n, r))
+    d = rng.random(n)
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
+    assert sm._ell(wide=True) is None
+    ref = _orc().csr_dense_sandwich(S.tocsr(), B, d, None, None, None)
+    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < F64_TOL
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_f_ordered_dense_block_uses_row_major_twin(dtype):
     """An F-ordered dense block gets a row-major twin in HBM for the sandwich kernels
