@@ -586,6 +586,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     auto process = [&](const Grp &cur) {
         const int nA = cur.nA, nB = DIAG ? cur.nA : cur.nB, pA0 = cur.pA, pB0 = DIAG ? cur.pA : cur.pB;
         const F dk = cur.d;
+        if (!__any(nA > 0 && nB > 0)) return;       // no row of the group has a pair in this tile
         // first halves (slots 0..7): every lane pairs its own A entry with the B entry of lane
         // (lane ^ s), s = 0..7, fetched with DPP moves inside the 8 lanes of its row -- 8 x 64
         // pairs = all 8 x 8 combinations of the 8 rows, no LDS scratch traffic
