@@ -85,9 +85,9 @@ class DenseMatrix(MatrixBase):
         if twin is None:
             need = blk.buf.numel() * blk.buf.element_size()
             free = torch.cuda.mem_get_info(blk.buf.device)[0] if blk.buf.is_cuda else 0
-            if free < 2 * need + (1 << 30):
-                return blk
-            twin = DenseDev(blk.as_2d().contiguous(), blk.n, blk.m, 0)
+            # decided once (no memory queries inside a captured launch sequence later)
+            twin = blk if free < 2 * need + (1 << 30) else \
+                DenseDev(blk.as_2d().contiguous(), blk.n, blk.m, 0)
             self._devblk_c = twin
         return twin
 
