@@ -215,6 +215,28 @@ int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, con
                                    int64_t n, int64_t m, const double *B, int64_t r, const double *d,
                                    double *out, void *stream);
 
+/* Lane-group form of the same unrestricted product (ext/sparse.pyx:211-260 csr_dense_sandwich ->
+ * ext/sparse_helpers-tmpl.cpp:23-146) for a C-ordered B with 16-byte aligned rows and more than 64
+ * columns: rows in slabs of R = tm_lg_rows() = 64, columns in groups of C = tm_lg_group_cols() = 16
+ * (m a multiple of C); column w of a group belongs to wave half h = w / 8 and is the half's column
+ * j = w % 8.  A round of a (slab, group) block = 4 chunks x 32 slots, chunk c = columns j = 2c,
+ * 2c + 1 of both halves, 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th
+ * nonzero of column 8h + j of the slab; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding
+ * (value 0).  vals / koff hold round 0 of block (slab * (m / C) + group) at slot offset block * 128;
+ * slot 0 of its chunk 0 carries the number of further rounds in koff bits 24..31, which start at
+ * round xptr[block] of xvals / xkoff (128 slots per round).  unconditional = 2 or 4 positions of
+ * every column executed without a test.  out: (m, r), overwritten. */
+int tm_lg_rows(void);
+int tm_lg_group_cols(void);
+int tm_csr_dense_sandwich_lg_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,
+                                 const float *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                 const float *B, int64_t r, const float *d, int unconditional,
+                                 float *out, void *stream);
+int tm_csr_dense_sandwich_lg_f64(const double *vals, const uint32_t *koff, const int64_t *xptr,
+                                 const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                 const double *B, int64_t r, const double *d, int unconditional,
+                                 double *out, void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

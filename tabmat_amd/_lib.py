@@ -14,7 +14,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "tabmat_hip.h")
-LIB_PATH = os.path.join(_HERE, "libtabmat_hip.so")
+# TABMAT_AMD_LIB: load another build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get("TABMAT_AMD_LIB") or os.path.join(_HERE, "libtabmat_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 

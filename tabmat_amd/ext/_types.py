@@ -241,6 +241,111 @@ class SlabEll:
         return SlabEll(vals, koff, gptr, inv, n, m, mpad, wide)
 
 
+@dataclass
+class SlabLg:
+    """Lane-group twin of a sparse block for tm_csr_dense_sandwich_lg_* (csrc/sparse_lg.hip):
+    rows in slabs of R = 64, columns (sorted by density) in groups of C = 16 = one wave; column w
+    of a group belongs to wave half h = w // 8 and is the half's column j = w % 8.  A round of a
+    (slab, group) block is 4 chunks of 32 slots, chunk c = columns j = 2c, 2c + 1 of both halves
+    with 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th nonzero of column
+    8h + j as {value, koff}; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding.  Round 0 of
+    every block lies at a fixed stride; slot 0 of chunk 0 carries the number of further rounds in
+    koff bits 24..31 and xptr[block] their position (in rounds) inside xvals / xkoff.  Built once
+    per block (ingest: one device key sort)."""
+
+    vals: torch.Tensor     # F[S * G * 128]
+    koff: torch.Tensor     # int32[S * G * 128]
+    xptr: torch.Tensor     # int64[S * G + 1]  first extra round of every block
+    xvals: torch.Tensor    # F[X * 128]
+    xkoff: torch.Tensor    # int32[X * 128]
+    inv: torch.Tensor      # int64[m]  kernel row of column c of the block
+    n: int
+    m: int
+    mk: int                # kernel rows = G * C
+    unc: int               # positions per column run without a test (2 or 4)
+
+    @staticmethod
+    def from_csr(csr: CsrDev, max_pad: float = None, max_extra: float = 0.25) -> "SlabLg":
+        """Returns None when the padded stream would exceed max_pad x nnz slots (very sparse
+        blocks) or more than max_extra of the blocks need further rounds (dense blocks: a column
+        then holds more than 8 nonzeros per 64 rows) -- the caller keeps another twin."""
+        from .._lib import lib
+
+        R = int(lib().tm_lg_rows())
+        C = int(lib().tm_lg_group_cols())
+        P, W, CH, SL = 8, 128, 4, 32
+        n, m = csr.n, csr.m
+        dev = csr.data.device
+        fbytes = csr.data.element_size()
+        S = (n + R - 1) // R
+        G = max(1, (m + C - 1) // C)
+        mpad = G * C
+        nnz = int(csr.data.numel())
+        total0 = S * G * CH * SL
+        if max_pad is not None and total0 > max_pad * max(nnz, 1) and total0 > (1 << 22):
+            return None
+        idx64 = csr.indices.to(torch.int64)
+        colcnt = torch.bincount(idx64, minlength=m) if nnz else \
+            torch.zeros(m, dtype=torch.int64, device=dev)
+        order = torch.sort(colcnt, descending=True, stable=True).indices
+        inv = torch.empty(m, dtype=torch.int64, device=dev)
+        inv[order] = torch.arange(m, device=dev, dtype=torch.int64)
+        del order, colcnt
+        counts = csr.indptr[1:] - csr.indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
+        key = torch.div(rows, R, rounding_mode="floor") * mpad + (inv[idx64] if nnz else idx64)
+        del idx64
+        # CSR order is row-sorted: a STABLE sort by (slab, kernel column) keeps rows ascending
+        key_sorted, perm = torch.sort(key, stable=True)
+        del key
+        cnt64 = torch.bincount(key_sorted, minlength=S * mpad) if nnz else \
+            torch.zeros(S * mpad, dtype=torch.int64, device=dev)
+        rounds = torch.div(cnt64.view(S * G, C).max(dim=1).values + (P - 1), P, rounding_mode="floor") \
+            if S else torch.zeros(0, dtype=torch.int64, device=dev)
+        extra = torch.clamp(rounds - 1, min=0)
+        xptr = torch.zeros(S * G + 1, dtype=torch.int64, device=dev)
+        if S * G:
+            torch.cumsum(extra, dim=0, out=xptr[1:])
+        n_extra = int(xptr[-1].item())
+        if S * G and max_extra is not None and int((extra > 0).sum().item()) > max_extra * S * G \
+                and total0 > (1 << 22):
+            return None
+        vals = torch.zeros(total0, dtype=csr.data.dtype, device=dev)
+        koff = torch.zeros(total0, dtype=torch.int32, device=dev)
+        xvals = torch.zeros(max(n_extra, 1) * CH * SL, dtype=csr.data.dtype, device=dev)
+        xkoff = torch.zeros(max(n_extra, 1) * CH * SL, dtype=torch.int32, device=dev)
+        if nnz:
+            rank = torch.arange(nnz, device=dev, dtype=torch.int64) - \
+                (torch.cumsum(cnt64, dim=0) - cnt64)[key_sorted]
+            blk = torch.div(key_sorted, C, rounding_mode="floor")
+            w = torch.remainder(key_sorted, C)
+            j = torch.remainder(w, 8)
+            slot = torch.div(w, 8, rounding_mode="floor") * 16 + torch.remainder(j, 2) * P \
+                + torch.remainder(rank, P)
+            chunk = torch.div(j, 2, rounding_mode="floor")
+            rnd = torch.div(rank, P, rounding_mode="floor")
+            del rank, w, j
+            rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
+            kv = ((rloc + 1) * (W * fbytes)).to(torch.int32)
+            del rloc
+            v = csr.data[perm]
+            first = rnd == 0
+            dst0 = (blk * CH + chunk) * SL + slot
+            vals[dst0[first]] = v[first]
+            koff[dst0[first]] = kv[first]
+            if n_extra:
+                later = ~first
+                dstx = ((xptr[blk[later]] + rnd[later] - 1) * CH + chunk[later]) * SL + slot[later]
+                xvals[dstx] = v[later]
+                xkoff[dstx] = kv[later]
+            del dst0, blk, slot, chunk, rnd, v, kv, first
+        del cnt64, key_sorted, perm, rows
+        if S * G:
+            koff.view(S * G, CH * SL)[:, 0] |= (extra << 24).to(torch.int32)
+        avg = nnz / max(1, S * mpad)
+        return SlabLg(vals, koff, xptr, xvals, xkoff, inv, n, m, mpad, 4 if avg >= 2.5 else 2)
+
+
 def onehot_slab(cats, n: int, dtype: torch.dtype):
     """Slab form of the STACKED one-hot encodings of several categorical blocks: a sparse
     matrix with (at most) one unit entry per row and categorical, columns = the categoricals'

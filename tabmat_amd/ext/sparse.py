@@ -4,7 +4,7 @@ from __future__ import annotations
 
 from .. import _device as D
 from .._lib import call
-from ._types import CsrDev, DenseDev, SlabCsc, SlabEll
+from ._types import CsrDev, DenseDev, SlabCsc, SlabEll, SlabLg
 
 
 def _csr_args(A: CsrDev):
@@ -89,6 +89,19 @@ def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
     fn = "tm_csr_dense_sandwich_ellw_" if A.wide else "tm_csr_dense_sandwich_ell_"
     call(fn + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.gptr),
          A.n, A.mk, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
+    return out[A.inv]      # kernel rows are the density-sorted columns
+
+
+def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
+    """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B of
+    more than 64 columns: lane-group twin, DPP-broadcast gather (csrc/sparse_lg.hip)."""
+    assert B.n == A.n and ell_supported(B)
+    if A.m == 0 or B.m == 0 or A.n == 0:
+        return D.zeros((A.m, B.m), A.vals.dtype)
+    out = D.zeros((A.mk, B.m), A.vals.dtype)
+    call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
+         D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d),
+         int(A.unc if unc is None else unc), D.p(out), D.stream_ptr())
     return out[A.inv]      # kernel rows are the density-sorted columns
 
 

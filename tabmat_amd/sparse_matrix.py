@@ -8,7 +8,7 @@ from scipy import sparse as sps
 
 from . import _device as D
 from .ext import sparse as xs
-from .ext._types import CsrDev, SlabCsc, SlabEll
+from .ext._types import CsrDev, SlabCsc, SlabEll, SlabLg
 from .matrix_base import MatrixBase
 from .util import (
     check_indexer,
@@ -131,6 +131,14 @@ class SparseMatrix(MatrixBase):
         twin = getattr(self, name)
         return twin if twin is not False else None      # None: too sparse, use the compact slab form
 
+    def _lg(self) -> SlabLg:
+        """Lane-group twin for the DPP-broadcast sparse x dense kernel (C-ordered B with more than
+        64 columns); None when the block is too sparse or too dense for it."""
+        if getattr(self, "_lgblk", None) is None:
+            twin = SlabLg.from_csr(self._dev(), max_pad=ELL_MAX_PAD)
+            self._lgblk = twin if twin is not None else False
+        return self._lgblk if self._lgblk is not False else None
+
     def to_device(self, dense_width=None):
         """Upload and build the twins now (otherwise the first product does it).  dense_width:
         columns of the dense block this one will be crossed with (SplitMatrix.to_device passes it)
@@ -138,7 +146,8 @@ class SparseMatrix(MatrixBase):
         self._dev().chunk_major()
         self._slab()
         if dense_width is not None and dense_width > 0:
-            self._ell(wide=dense_width > 64)
+            if dense_width <= 64 or self._lg() is None:
+                self._ell(wide=dense_width > 64)
         return self
 
     @property
@@ -253,8 +262,13 @@ class SparseMatrix(MatrixBase):
                     r64 = rows.to(torch.int64)
                     dm[r64] = d[r64]
                     d = dm
-                ell = self._ell(wide=Bd.m > 64) if xs.ell_supported(Bd) else None
-                if ell is not None:
+                lg = self._lg() if (Bd.m > 64 and xs.ell_supported(Bd)) else None
+                ell = None
+                if lg is None and xs.ell_supported(Bd):
+                    ell = self._ell(wide=Bd.m > 64)
+                if lg is not None:
+                    res = xs.csr_dense_sandwich_lg(lg, Bd, d)
+                elif ell is not None:
                     res = xs.csr_dense_sandwich_ell(ell, Bd, d)
                 else:
                     res = xs.csr_dense_sandwich_slab(self._slab(), Bd, d)

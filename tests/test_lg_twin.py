@@ -1,0 +1,112 @@
+"""Lane-group twin of a sparse block (tabmat_amd/ext/_types.py::SlabLg, csrc/sparse_lg.hip).
+
+CPU part: the twin builder is plain torch, so its output is decoded here exactly the way the
+kernel walks it (blocks, rounds, chunks, slots, koff -> slab row) and compared with dense
+algebra.  GPU part: the kernel itself against the oracle's csr_dense_sandwich."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse as sps
+
+from tabmat_amd.ext._types import CsrDev, SlabLg
+
+HAS_GPU = torch.cuda.is_available()
+
+
+def _csr_cpu(S, dtype):
+    S = sps.csr_matrix(S).astype(dtype)
+    S.sort_indices()
+    return CsrDev(torch.from_numpy(S.data.copy()), torch.from_numpy(S.indices.astype(np.int32)),
+                  torch.from_numpy(S.indptr.astype(np.int64)), S.shape[0], S.shape[1])
+
+
+def _decode(tw: SlabLg, itemsize):
+    """(kernel column, row, value) triplets as the kernel reads them."""
+    R, C, CH, SL = 64, 16, 4, 32
+    rowb = 128 * itemsize
+    G = tw.mk // C
+    S = (tw.n + R - 1) // R
+    vals, koff = tw.vals.numpy(), tw.koff.numpy().view(np.uint32)
+    xvals, xkoff, xptr = tw.xvals.numpy(), tw.xkoff.numpy().view(np.uint32), tw.xptr.numpy()
+    out = []
+    for blk in range(S * G):
+        s, g = divmod(blk, G)
+        extra = int(koff[blk * CH * SL] >> 24)
+        streams = [(vals, koff, blk)] + [(xvals, xkoff, int(xptr[blk]) + m) for m in range(extra)]
+        assert xptr[blk + 1] - xptr[blk] == extra
+        for rnd, (vv, kk, base) in enumerate(streams):
+            for c in range(CH):
+                for slot in range(SL):
+                    q = (base * CH + c) * SL + slot
+                    k = int(kk[q]) & 0xFFFFF
+                    if k == 0:
+                        assert vv[q] == 0
+                        continue
+                    h, jl, it = slot // 16, (slot % 16) // 8, slot % 8
+                    assert k % rowb == 0
+                    row = s * R + k // rowb - 1
+                    out.append((g * C + 8 * h + 2 * c + jl, row, float(vv[q]), rnd * 8 + it))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,density", [(300, 40, 0.05), (64, 16, 0.5), (129, 33, 0.2),
+                                         (1000, 512, 0.02), (5, 3, 1.0)])
+def test_twin_decodes_to_the_matrix(n, m, density, dtype):
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
+    S.data += 0.5          # no explicit zeros
+    tw = SlabLg.from_csr(_csr_cpu(S, dtype), max_pad=None, max_extra=None)
+    inv = tw.inv.numpy()
+    dense = np.zeros((tw.mk, n))
+    seen = {}
+    for kc, row, v, pos in _decode(tw, np.dtype(dtype).itemsize):
+        assert dense[kc, row] == 0
+        dense[kc, row] = v
+        seen.setdefault((kc, row // 64), []).append((pos, row))
+    np.testing.assert_array_equal(dense[inv].T, S.toarray().astype(dtype))
+    for lst in seen.values():      # positions compacted, rows ascending with the position
+        lst.sort()
+        assert [p for p, _ in lst] == list(range(len(lst)))
+        assert [r for _, r in lst] == sorted(r for _, r in lst)
+    assert tw.unc in (2, 4)
+
+
+def test_twin_gives_up_outside_its_regime():
+    rng = np.random.default_rng(0)
+    S = sps.random(64 * 1200, 512, density=0.0005, format="csr", random_state=rng)
+    assert SlabLg.from_csr(_csr_cpu(S, np.float64), max_pad=8.0) is None          # too sparse
+    S = sps.random(64 * 1200, 512, density=0.3, format="csr", random_state=rng)
+    assert SlabLg.from_csr(_csr_cpu(S, np.float64), max_pad=8.0) is None          # too dense
+    assert SlabLg.from_csr(_csr_cpu(S, np.float64), max_pad=8.0, max_extra=None) is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("unc", [2, 4])
+@pytest.mark.parametrize("n,m,k,density", [(20_000, 512, 128, 0.05), (777, 40, 72, 0.1),
+                                           (64, 16, 128, 0.5), (4099, 100, 200, 0.3),
+                                           (30_000, 300, 256, 0.01), (129, 7, 68, 1.0)])
+def test_lg_kernel_matches_oracle(n, m, k, density, unc, dtype):
+    import tabmat_amd as tm
+    from oracle import oracle as orc
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(n + m + k)
+    S = sps.random(n, m, density=density, format="csc", random_state=rng, dtype=np.float64)
+    S.data -= 0.5
+    S = S.astype(dtype)
+    B = rng.standard_normal((n, k)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 7)] = 0          # d == 0 rows take the zero-row redirect
+    B[d == 0] = np.inf                           # ... and must not leak inf * 0
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
+    tw = SlabLg.from_csr(sm._dev(), max_pad=None, max_extra=None)
+    got = D.to_host(xs.csr_dense_sandwich_lg(tw, dm._dev_c(), D.to_dev(d), unc=unc))
+    Bz = B.copy()
+    Bz[d == 0] = 0
+    want = orc.csr_dense_sandwich(sps.csr_matrix(S), Bz, d, None, None, None)
+    tol = 1e-10 if dtype == np.float64 else 2e-4
+    scale = max(np.abs(want).max(), 1e-30)
+    assert np.abs(got - want).max() / scale < tol
