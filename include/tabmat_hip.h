@@ -32,9 +32,12 @@
  *     otherwise; tm_last_error() returns a message for the calling thread.
  *     (The reference's kernels return void and cannot fail; all argument
  *     validation stays in the host language, util.py:27-67.)
- *   - Scratch: kernels use a per-device workspace owned by the library
- *     (grown on demand with hipMalloc), or caller memory given with
- *     tm_set_workspace().  Calls that share a workspace must be stream-ordered.
+ *   - Scratch: kernels use a workspace owned by the library, one per (device,
+ *     stream), grown on demand with hipMalloc -- calls on different streams never
+ *     share partial-sum buffers.  Growth waits for that stream only and is refused
+ *     (TM_ENOMEM) while the stream is being captured into a HIP graph: run the op
+ *     once before capturing.  Caller memory given with tm_set_workspace() serves
+ *     every stream of its device; calls that share it must be stream-ordered.
  */
 #ifndef TABMAT_HIP_H
 #define TABMAT_HIP_H

@@ -38,6 +38,17 @@ def fsuf(t: torch.Tensor) -> str:
         raise TypeError(f"only float32/float64 are supported on the device, got {t.dtype}")
 
 
+def same_float(fn: str, *tensors) -> None:
+    """Every float tensor handed to one tm_*_{f32,f64} call must have the suffix dtype: the C ABI
+    takes bare pointers, so a float32 operand behind a _f64 entry point would be read out of
+    bounds.  The reference raises TypeError for mixed dtypes (util.py:62-67,
+    sparse_matrix.py:218-223)."""
+    dts = {t.dtype for t in tensors if t is not None and t.is_floating_point()}
+    if len(dts) > 1:
+        raise TypeError(f"{fn}: all floating-point operands need the same dtype, either "
+                        f"np.float64 or np.float32; got {sorted(str(d) for d in dts)}")
+
+
 def torch_dtype(np_dtype) -> torch.dtype:
     try:
         return _NP2T[np.dtype(np_dtype)]

@@ -127,9 +127,11 @@ class CategoricalMatrix(MatrixBase):
         self._dev()
         return self
 
-    def _onehot(self):
-        """(slab form of the one-hot encoding, row permutation) for the gather kernel; cached."""
-        tdt = D.torch_dtype(self.dtype)
+    def _onehot(self, tdt=None):
+        """(slab form of the one-hot encoding, row permutation) for the gather kernel; cached.
+        tdt: dtype of the operand it will be multiplied with (the reference's cat x dense kernel
+        is templated on d / mat_j only, ext/split.pyx:32-80); default the block's own dtype."""
+        tdt = D.torch_dtype(self.dtype) if tdt is None else tdt
         cache = getattr(self, "_onehot_cache", None)
         if cache is None or cache[0] != tdt:   # astype() changes the nominal dtype in place
             from .ext._types import onehot_slab
@@ -324,7 +326,7 @@ class CategoricalMatrix(MatrixBase):
                         and xsplit.multi_cat_dense_wide_ok(cats, other._dev_c())):
                     res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev_c())
                 else:
-                    oh, inv = self._onehot()
+                    oh, inv = self._onehot(other._dev_c().buf.dtype)
                     res = xs.csr_dense_sandwich_slab(oh, other._dev_c(), d)[inv]
                 return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_dense(self._dev(), self.shape[1], d, other._dev(), rows,

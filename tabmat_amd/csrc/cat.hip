@@ -169,7 +169,7 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     const int64_t rows_per_block = ceil_div(ceil_div(n_iter, nblk), 4) * 4;   // keeps t0 % 4 == 0
     nblk = ceil_div(n_iter, rows_per_block);
     void *wsv = nullptr;
-    int rc = get_workspace(sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+    int rc = get_workspace(sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv, st);
     if (rc) return rc;
     F *ws = reinterpret_cast<F *>(wsv);
     if (lds > 48 * 1024) {
@@ -386,7 +386,7 @@ static int run_cat_dense(const int32_t *codes, int64_t n, int64_t i_ncol, int dr
         return TM_EUNSUPPORTED;
     }
     void *wsv = nullptr;
-    int rc = get_workspace(sizeof(F) * (size_t)(p.n_parts * p.nblk * p.stride) + 256, &wsv);
+    int rc = get_workspace(sizeof(F) * (size_t)(p.n_parts * p.nblk * p.stride) + 256, &wsv, st);
     if (rc) return rc;
     F *ws = reinterpret_cast<F *>(wsv);
     auto kern = order_f ? &cat_dense_kernel<F, true> : &cat_dense_kernel<F, false>;
@@ -423,7 +423,7 @@ static int run_cat_sparse(const int32_t *codes, int64_t n, int64_t i_ncol, int d
     const size_t map_bytes = cols ? ((sizeof(int32_t) * (size_t)s_ncol + 255) / 256) * 256 : 0;
     void *wsv = nullptr;
     int rc = get_workspace(map_bytes + sizeof(F) * (size_t)(p.n_parts * p.nblk * p.stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     int32_t *col_map = nullptr;
     if (cols) {
@@ -460,7 +460,7 @@ static int run_cat_tmv(const int32_t *codes, int64_t n, int64_t n_cols, int drop
         void *wsv = nullptr;
         const size_t map_bytes = ((sizeof(int32_t) * (size_t)n_cols + 255) / 256) * 256;
         const size_t part_bytes = sizeof(F) * (size_t)(2 * NUM_CU) * (size_t)n_cols + 4096;
-        int rc = get_workspace(part_bytes + map_bytes, &wsv);
+        int rc = get_workspace(part_bytes + map_bytes, &wsv, st);
         if (rc) return rc;
         col_map = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wsv) + part_bytes);
         rc = build_col_map(col_map, n_cols, cols, n_cols_sel, st);
@@ -479,7 +479,7 @@ static int run_cat_matvec(const int32_t *codes, int64_t n, int64_t n_cols, int d
     int32_t *col_map = nullptr;
     if (cols) {
         void *wsv = nullptr;
-        int rc = get_workspace(sizeof(int32_t) * (size_t)n_cols + 256, &wsv);
+        int rc = get_workspace(sizeof(int32_t) * (size_t)n_cols + 256, &wsv, st);
         if (rc) return rc;
         col_map = reinterpret_cast<int32_t *>(wsv);
         rc = build_col_map(col_map, n_cols, cols, n_cols_sel, st);
@@ -962,7 +962,7 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
             nblk = ceil_div(n, rpb);
             const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_parts * stride) + 255) / 256) * 256;
             void *wsv = nullptr;
-            rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+            rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv, st);
             if (rc) return rc;
             F *tmp = reinterpret_cast<F *>(wsv);
             F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
@@ -1006,7 +1006,7 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     nblk = ceil_div(n, rpb);
     const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_parts * stride) + 255) / 256) * 256;
     void *wsv = nullptr;
-    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv);
+    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
@@ -1084,7 +1084,7 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_groups * stride) + 255) / 256) * 256;
     void *wsv = nullptr;
     rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_groups * nblk * stride) + 256,
-                       &wsv);
+                       &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);

@@ -34,9 +34,14 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                     \
     } while (0)
 
-// Per-device scratch.  get_workspace() returns at least `bytes` of device memory that
-// stays valid until the next get_workspace() call on the same device asks for more.
-int get_workspace(size_t bytes, void **ptr);
+// Scratch per (device, stream): get_workspace() returns at least `bytes` of device memory that
+// stays valid until the next get_workspace() call for the same device and stream asks for more.
+// Ops in flight on different streams therefore never share partial-sum buffers.  Growing waits
+// for that stream only and is refused while the stream is being captured into a graph (the
+// pointer baked into the graph would dangle): warm the op up once before capturing.  A
+// caller-provided workspace (tm_set_workspace) serves every stream of its device -- single-stream
+// use is then the caller's contract.
+int get_workspace(size_t bytes, void **ptr, hipStream_t st);
 
 // Optional in-library kernel timing (tm_profile_enable): HIP events recorded on the launch
 // stream immediately around the MAIN kernel of an op, so bench.py can quote the dominant

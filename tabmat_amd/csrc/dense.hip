@@ -494,7 +494,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     const int direct_max = sizeof(F) == 4 ? 256 : 128;
     if (n_cols <= direct_max) {
         const int W = n_cols <= 16 ? 16 : n_cols <= 32 ? 32 : n_cols <= 64 ? 64 : n_cols <= 128 ? 128 : 256;
-        int rc = get_workspace(syrk_ws_bytes<F>(W), &wsv);
+        int rc = get_workspace(syrk_ws_bytes<F>(W), &wsv, st);
         if (rc) return rc;
         return syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, cols, (int)n_cols, nullptr, out,
                                 n_cols, reinterpret_cast<char *>(wsv), 0, st);
@@ -504,7 +504,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     const int PW = 128;
     const int np = (int)ceil_div(n_cols, PW);
     const size_t idx_bytes = 4096;  // 2 x 256 int32 (virtual cols, positions) + slack
-    int rc = get_workspace(idx_bytes + syrk_ws_bytes<F>(256), &wsv);
+    int rc = get_workspace(idx_bytes + syrk_ws_bytes<F>(256), &wsv, st);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(wsv);
     int32_t *vcols = reinterpret_cast<int32_t *>(base);

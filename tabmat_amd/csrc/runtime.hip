@@ -4,7 +4,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "common.hpp"
 
@@ -29,11 +31,12 @@ struct Workspace {
     size_t bytes = 0;
     bool external = false;
 };
-static Workspace g_ws[64];
+static Workspace g_ws_ext[64];                              // tm_set_workspace, per device
+static std::map<std::pair<int, hipStream_t>, Workspace> g_ws;   // library-owned, per (device, stream)
 static std::mutex g_ws_mu;
 static int64_t g_ws_generation = 0;   // bumped whenever a workspace pointer changes
 
-int get_workspace(size_t bytes, void **ptr) {
+int get_workspace(size_t bytes, void **ptr, hipStream_t st) {
     int dev = 0;
     TM_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) {
@@ -41,15 +44,25 @@ int get_workspace(size_t bytes, void **ptr) {
         return TM_EINVAL;
     }
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace &w = g_ws[dev];
-    if (bytes > w.bytes) {
-        if (w.external) {
+    if (g_ws_ext[dev].external) {
+        if (bytes > g_ws_ext[dev].bytes) {
             set_error("caller-provided workspace too small: need %zu bytes, have %zu", bytes,
-                      w.bytes);
+                      g_ws_ext[dev].bytes);
+            return TM_ENOMEM;
+        }
+        *ptr = g_ws_ext[dev].ptr;
+        return TM_OK;
+    }
+    Workspace &w = g_ws[std::make_pair(dev, st)];
+    if (bytes > w.bytes) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("workspace of %zu bytes needed while the stream is being captured "
+                      "(have %zu): run the op once before the capture", bytes, w.bytes);
             return TM_ENOMEM;
         }
         if (w.ptr) {
-            TM_HIP(hipDeviceSynchronize());
+            TM_HIP(hipStreamSynchronize(st));
             TM_HIP(hipFree(w.ptr));
             w.ptr = nullptr;
             w.bytes = 0;
@@ -153,21 +166,23 @@ int tm_set_workspace(void *ptr, size_t bytes) {
     TM_HIP(hipGetDevice(&dev));
     TM_REQUIRE(dev >= 0 && dev < 64, "device id out of range");
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace &w = g_ws[dev];
-    if (!w.external && w.ptr) {
-        TM_HIP(hipDeviceSynchronize());
-        TM_HIP(hipFree(w.ptr));
+    // library-owned workspaces of this device are released (their streams drained first)
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        if (it->first.first == dev) {
+            if (it->second.ptr) {
+                TM_HIP(hipStreamSynchronize(it->first.second));
+                TM_HIP(hipFree(it->second.ptr));
+            }
+            it = g_ws.erase(it);
+        } else {
+            ++it;
+        }
     }
     ++g_ws_generation;
-    if (ptr) {
-        w.ptr = ptr;
-        w.bytes = bytes;
-        w.external = true;
-    } else {
-        w.ptr = nullptr;
-        w.bytes = 0;
-        w.external = false;
-    }
+    Workspace &w = g_ws_ext[dev];
+    w.ptr = ptr;
+    w.bytes = ptr ? bytes : 0;
+    w.external = ptr != nullptr;
     return TM_OK;
 }
 

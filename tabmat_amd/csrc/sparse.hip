@@ -763,7 +763,7 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     int32_t *col_map = nullptr;
     if (cols) {
         void *wsv = nullptr;
-        int rc = get_workspace(align256(sizeof(int32_t) * (size_t)m), &wsv);
+        int rc = get_workspace(align256(sizeof(int32_t) * (size_t)m), &wsv, st);
         if (rc) return rc;
         col_map = reinterpret_cast<int32_t *>(wsv);
         rc = build_col_map(col_map, m, cols, n_cols, st);
@@ -798,7 +798,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
         const int64_t cpb = ceil_div(nchunk, nblk);
         nblk = ceil_div(nchunk, cpb);
         void *wsv = nullptr;
-        int rc = get_workspace(sizeof(F) * (size_t)(nblk * m) + 256, &wsv);
+        int rc = get_workspace(sizeof(F) * (size_t)(nblk * m) + 256, &wsv, st);
         if (rc) return rc;
         F *ws = reinterpret_cast<F *>(wsv);
         prof_begin(st);
@@ -815,7 +815,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     nblk = ceil_div(n_iter, rpb);
     void *wsv = nullptr;
     int rc = get_workspace(map_bytes + (use_lds ? sizeof(F) * (size_t)(nblk * n_out) : 0) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     int32_t *col_map = nullptr;
     if (cols) {
@@ -877,7 +877,7 @@ static int run_csr_dense(const F *data, const int32_t *ind, const int64_t *ptr, 
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
     void *wsv = nullptr;
     int rc = get_workspace(map_bytes + tmp_bytes + sizeof(F) * (size_t)(n_parts * nblk * stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(wsv);
     int32_t *a_map = nullptr;
@@ -954,7 +954,7 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
     void *wsv = nullptr;
     int rc = get_workspace(map_bytes + ij_bytes + tmp_bytes +
                                sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     char *base = reinterpret_cast<char *>(wsv);
     int32_t *col_map = nullptr;
@@ -1018,7 +1018,7 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)n_parts * TS * TS);
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
@@ -1866,7 +1866,7 @@ static int run_csr_dense_gather(const F *vals, const unsigned *koff, const unsig
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
@@ -1925,7 +1925,7 @@ static int run_csr_dense_ell(const F *vals, const unsigned *koff, const int64_t 
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
@@ -1977,7 +1977,7 @@ static int run_csr_dense_ellw(const F *vals, const unsigned *koff, const int64_t
     const size_t tmp_bytes = align256(sizeof(F) * (size_t)(n_parts * stride));
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);

@@ -397,7 +397,7 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     const size_t tmp_bytes = (sizeof(F) * (size_t)(n_parts * stride) + 255) / 256 * 256;
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 256,
-                           &wsv);
+                           &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);

@@ -342,8 +342,9 @@ class SlabLg:
         del cnt64, key_sorted, perm, rows
         if S * G:
             koff.view(S * G, CH * SL)[:, 0] |= (extra << 24).to(torch.int32)
-        avg = nnz / max(1, S * mpad)
-        return SlabLg(vals, koff, xptr, xvals, xkoff, inv, n, m, mpad, 4 if avg >= 2.5 else 2)
+        # 4 unconditional positions only pay with registers to spare (f32); measured at cfg4:
+        # f64 unc=2 6.1 ms / unc=4 7.6 ms (spills), f32 5.3 / 5.3 ms
+        return SlabLg(vals, koff, xptr, xvals, xkoff, inv, n, m, mpad, 2)
 
 
 def onehot_slab(cats, n: int, dtype: torch.dtype):

@@ -16,6 +16,7 @@ def transpose_matvec(indices, other, n_cols, rows, cols, out, drop_first=False):
         rows = None
     if cols is not None and D.nlen(cols) == n_cols:
         cols = None
+    D.same_float("transpose_matvec", other, out)
     call(f"tm_cat_transpose_matvec_{D.fsuf(out)}", D.p(indices), n, n_cols, int(drop_first),
          D.p(other), D.p(rows), D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
 
@@ -24,6 +25,7 @@ def matvec(indices, other, n_rows, cols, n_cols, out_vec, drop_first=False):
     """ext/categorical.pyx:128-180 (matvec_fast/_complex): out_vec[i] += other[col(i)]."""
     if cols is not None and D.nlen(cols) == 0:
         return
+    D.same_float("matvec", other, out_vec)
     call(f"tm_cat_matvec_{D.fsuf(out_vec)}", D.p(indices), n_rows, n_cols, int(drop_first),
          D.p(other), D.p(cols), D.nlen(cols), D.p(out_vec), D.stream_ptr())
 

@@ -13,6 +13,7 @@ def dense_sandwich(X: DenseDev, d, rows, cols):
     out = D.zeros((out_m, out_m), X.dtype)
     if in_n == 0 or out_m == 0:  # ext/dense.pyx:26-27
         return out
+    D.same_float("dense_sandwich", X.buf, d)
     call(f"tm_dense_sandwich_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(d), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -26,6 +27,7 @@ def dense_rmatvec(X: DenseDev, v, rows, cols, out=None):
         out = D.zeros((n_cols,), X.dtype)
     if n_rows == 0 or n_cols == 0:
         return out
+    D.same_float("dense_rmatvec", X.buf, v, out)
     call(f"tm_dense_rmatvec_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(v), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -39,6 +41,7 @@ def dense_matvec(X: DenseDev, v, rows, cols, out=None):
         out = D.zeros((n_rows,), X.dtype)
     if n_rows == 0 or n_cols == 0:
         return out
+    D.same_float("dense_matvec", X.buf, v, out)
     call(f"tm_dense_matvec_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(v), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -49,6 +52,7 @@ def transpose_square_dot_weights(X: DenseDev, weights, shift):
     out = D.zeros((X.m,), X.dtype)
     if X.n == 0 or X.m == 0:
         return out
+    D.same_float("transpose_square_dot_weights", X.buf, weights, shift)
     call(f"tm_dense_col_sq_dev_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(weights),
          D.p(shift), D.p(out), D.stream_ptr())
     return out

@@ -17,6 +17,7 @@ def sparse_sandwich(A: CsrDev, d, rows, cols):
     out = D.zeros((m, m), A.dtype)
     if m == 0 or (rows is not None and D.nlen(rows) == 0):
         return out
+    D.same_float("sparse_sandwich", A.data, d)
     call(f"tm_sparse_sandwich_{D.fsuf(A.data)}", *_csr_args(A), D.p(d), D.p(rows), D.nlen(rows),
          D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -30,6 +31,7 @@ def csr_dense_sandwich(A: CsrDev, B: DenseDev, d, rows, A_cols, B_cols):
     out = D.zeros((nA, nB), A.dtype)
     if nr == 0 or nA == 0 or nB == 0 or A.data.numel() == 0:  # ext/sparse.pyx:236-237
         return out
+    D.same_float("csr_dense_sandwich", A.data, B.buf, d)
     call(f"tm_csr_dense_sandwich_{D.fsuf(A.data)}", *_csr_args(A), D.p(B.buf), B.m, B.order_f,
          D.p(d), D.p(rows), D.nlen(rows), D.p(A_cols), D.nlen(A_cols), D.p(B_cols),
          D.nlen(B_cols), D.p(out), D.stream_ptr())
@@ -43,6 +45,7 @@ def csr_matvec(X: CsrDev, v, rows, cols, out=None):
         out = D.zeros((n_rows,), X.dtype)
     if n_rows == 0 or (cols is not None and D.nlen(cols) == 0):
         return out
+    D.same_float("csr_matvec", X.data, v, out)
     call(f"tm_csr_matvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
          D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -56,6 +59,7 @@ def csc_rmatvec(X: CsrDev, v, rows, cols, out=None):
         out = D.zeros((n_cols,), X.dtype)
     if n_cols == 0 or (rows is not None and D.nlen(rows) == 0):
         return out
+    D.same_float("csc_rmatvec", X.data, v, out)
     call(f"tm_csr_rmatvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
          D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -68,6 +72,7 @@ def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
     out = D.zeros((A.m, B.m), A.vals.dtype)
     if A.m == 0 or B.m == 0 or A.n == 0:
         return out
+    D.same_float("csr_dense_sandwich_slab", A.vals, B.buf, d)
     call(f"tm_csr_dense_sandwich_slab_{D.fsuf(A.vals)}", D.p(A.vals), D.p(A.koff), D.p(A.cnt),
          D.p(A.gptr), A.n, A.m, D.p(B.buf), B.m, B.order_f, D.p(d), D.p(out), D.stream_ptr())
     return out
@@ -86,6 +91,7 @@ def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
     if A.m == 0 or B.m == 0 or A.n == 0:
         return D.zeros((A.m, B.m), A.vals.dtype)
     out = D.zeros((A.mk, B.m), A.vals.dtype)
+    D.same_float("csr_dense_sandwich_ell", A.vals, B.buf, d)
     fn = "tm_csr_dense_sandwich_ellw_" if A.wide else "tm_csr_dense_sandwich_ell_"
     call(fn + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.gptr),
          A.n, A.mk, D.p(B.buf), B.m, D.p(d), D.p(out), D.stream_ptr())
@@ -99,6 +105,7 @@ def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
     if A.m == 0 or B.m == 0 or A.n == 0:
         return D.zeros((A.m, B.m), A.vals.dtype)
     out = D.zeros((A.mk, B.m), A.vals.dtype)
+    D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
     call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
          D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d),
          int(A.unc if unc is None else unc), D.p(out), D.stream_ptr())
@@ -110,6 +117,7 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     out = D.zeros((A.m, A.m), A.dtype)
     if A.m == 0 or A.n == 0:
         return out
+    D.same_float("sparse_sandwich_chunked", A.data, d)
     cm_data, cm_ind, cptr = A.chunk_major()
     call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr),
          A.n, A.m, int(cm_data.numel()), D.p(d), D.p(out), D.stream_ptr())
@@ -121,6 +129,7 @@ def transpose_square_dot_weights(A: CsrDev, weights):
     out = D.zeros((A.m,), A.dtype)
     if A.n == 0 or A.m == 0 or A.data.numel() == 0:
         return out
+    D.same_float("transpose_square_dot_weights", A.data, weights)
     call(f"tm_csr_col_sq_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n, A.m,
          D.p(weights), D.p(out), D.stream_ptr())
     return out

@@ -17,6 +17,7 @@ def sandwich_cat_dense(i_indices, i_ncol, d, mat_j: DenseDev, rows, j_cols, drop
     n_rows = i_indices.numel() if rows is None else D.nlen(rows)
     if d.numel() == 0 or n_rows == 0 or n_j == 0 or i_ncol == 0:  # ext/split.pyx:51-52
         return res
+    D.same_float("sandwich_cat_dense", mat_j.buf, d)
     call(f"tm_cat_dense_sandwich_{D.fsuf(mat_j.buf)}", D.p(i_indices), i_indices.numel(), i_ncol,
          int(drop_first), D.p(d), D.p(rows), D.nlen(rows), D.p(mat_j.buf), mat_j.m, mat_j.order_f,
          D.p(j_cols), D.nlen(j_cols), D.p(res), D.stream_ptr())
@@ -42,6 +43,7 @@ def sandwich_cat_sparse(i_indices, i_ncol, d, S: CsrDev, rows, cols, drop_first=
     res = D.zeros((i_ncol, n_cols), S.dtype)
     if i_ncol == 0 or n_cols == 0 or (rows is not None and D.nlen(rows) == 0):
         return res
+    D.same_float("sandwich_cat_sparse", S.data, d)
     call(f"tm_cat_sparse_sandwich_{D.fsuf(S.data)}", D.p(i_indices), i_indices.numel(), i_ncol,
          int(drop_first), D.p(S.data), D.p(S.indices), D.p(S.indptr), S.m, D.p(d), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(res), D.stream_ptr())
@@ -128,6 +130,7 @@ def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev):
     if total == 0 or mat_j.m == 0 or mat_j.n == 0:
         return res
     codes, ncols, drop, n = _cat_args(cats)
+    D.same_float("multi_cat_dense_sandwich", mat_j.buf, d)
     call(f"tm_multi_cat_dense_sandwich_{D.fsuf(mat_j.buf)}", codes, ncols, drop, n, mat_j.n,
          D.p(d), D.p(mat_j.buf), mat_j.m, mat_j.order_f, D.p(res), D.stream_ptr())
     return res
@@ -141,6 +144,7 @@ def multi_cat_sparse_sandwich(cats, d, S: SlabCsc):
     if total == 0 or S.m == 0 or S.n == 0:
         return res
     codes, ncols, drop, n = _cat_args(cats)
+    D.same_float("multi_cat_sparse_sandwich", S.vals, d)
     call(f"tm_multi_cat_sparse_sandwich_slab_{D.fsuf(S.vals)}", codes, ncols, drop, n, S.n, D.p(d),
          D.p(S.vals), D.p(S.koff), D.p(S.ecol), D.p(S.gptr), S.m, D.p(res), D.stream_ptr())
     return res
