@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-op kernel times to stderr")
     ap.add_argument("--out", default=None, help="also write the JSON (+breakdown) to this file")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE passes over the dominant kernel")
+    ap.add_argument("--traffic-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -77,14 +80,10 @@ def build_workload(name, n, seed):
     raise ValueError(name)
 
 
-def kernel_breakdown(mat, d, reps=3):
-    """Main-kernel time of every block / block-pair op of one sandwich, via tm_profile_*."""
-    import ctypes as C
-
+def kernel_ops(mat, d):
+    """[(name, thunk)] of every block / block-pair op that one sandwich launches."""
     import tabmat_amd as tm
-    from tabmat_amd import _lib
 
-    lib = _lib.lib()
     mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
     ops = []
     for i, mi in enumerate(mats):
@@ -122,6 +121,17 @@ def kernel_breakdown(mat, d, reps=3):
             # the fused kernels replace the per-pair categorical cross terms
             ops = [o for o in ops if not (("categorical" in o[0]) and ("dense" in o[0] or "sparse" in o[0])
                                           and "x" in o[0])] + fused
+    return ops
+
+
+def kernel_breakdown(mat, d, reps=3):
+    """Main-kernel time of every block / block-pair op of one sandwich, via tm_profile_*
+    (HIP events on the launch stream around the op's main kernel)."""
+    import ctypes as C
+
+    from tabmat_amd import _lib
+
+    ops = kernel_ops(mat, d)
     out = {}
     _lib.call("tm_profile_enable", 1)
     try:
@@ -231,10 +241,85 @@ def cpu_baseline(workload, rows, seed):
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's
+    JSON line through."""
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < args.gpus and os.environ.get("TABMAT_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(TABMAT_BENCH_BACKEND=gloo lets ranks share devices for a dry run)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def measure_traffic(args, dom):
+    """HBM bytes per launch of the dominant kernel from the L2's memory-side counters: two
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) over a child
+    run of this script that launches that op a few times.  FETCH_SIZE is doubled (gfx950 counts
+    wide coalesced reads at half, MI355X_MICROARCH.md "HBM"); WRITE_SIZE is taken as reported (KiB).
+    Returns bytes or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    total = 0.0
+    try:
+        for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+            tmp = tempfile.mkdtemp(prefix="tm_traffic_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "-d", tmp, "-o", "t", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", dom,
+                   "--workload", args.workload, "--rows", str(args.rows)]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            best = {}
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == counter and "tmh::" in r["Kernel_Name"]:
+                    best.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            # the op's main kernel is the one with the largest counter value per dispatch
+            val = max(sum(v) / len(v) for v in best.values())
+            total += val * scale
+            shutil.rmtree(tmp, ignore_errors=True)
+        return int(total)
+    except Exception:
+        return None
+
+
+def traffic_child(args):
+    """Child of measure_traffic: build the workload, launch the named op three times."""
+    mat, tdt = build_workload(args.workload, args.rows, 3)
+    d = torch.rand(mat.shape[0], dtype=tdt, device="cuda")
+    import tabmat_amd as tm
+
+    ops = dict(kernel_ops(mat, d))
+    for _ in range(3):
+        ops[args.traffic_child]()
+    torch.cuda.synchronize()
+
+
 def main():
     args = parse_args()
     # RCCL / device-memory sharing across the ranks of one node needs dmabuf IPC on this driver
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.traffic_child:
+        return traffic_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -254,7 +339,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from tabmat_amd import synth
     from tabmat_amd.distributed import RowShardedMatrix
@@ -265,14 +350,20 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(100 + rank)
     d = torch.rand(n_local, dtype=tdt, device="cuda", generator=g)
-    sharded = RowShardedMatrix(mat)
+    # every rank owns its own 10M-row shard (weak scaling); the wrapper adds the one collective
+    # of the path: an all-reduce of the p x p result over RCCL
+    sharded = RowShardedMatrix(mat, bounds=(rank * n_local, (rank + 1) * n_local),
+                               n_global=world * n_local)
 
     import tabmat_amd as tm
 
     def product(dd):
+        # the PUBLIC entry point, device vector in -> device result out (no host traffic):
+        # SplitMatrix.sandwich / DenseMatrix.sandwich; a CategoricalMatrix returns a scipy
+        # dia_matrix from its public method, so its device diagonal is timed instead
         if isinstance(mat, tm.CategoricalMatrix):
             return mat._sandwich_diag_dev(dd, None, None)
-        return mat._sandwich_dev(dd, None, None)
+        return mat.sandwich(dd)
 
     # One step = one pass of the hot path over the shard, launched eagerly.  --graph replays the
     # same launch sequence (same kernels, order, arguments) from a HIP graph, the form a GLM solver
@@ -284,13 +375,13 @@ def main():
     else:
         from tabmat_amd.graph import CapturedProduct
 
-        run = CapturedProduct(product, d)
+        run = CapturedProduct(lambda dd: mat._sandwich_dev(dd, None, None), d)
         d = run._static_in
 
     def step():
         out = run(d)
         if world > 1:
-            dist.all_reduce(out)  # RCCL over xGMI: p x p float64 (8 MB at p = 1024)
+            out = sharded._all_reduce(out)  # RCCL over xGMI: p x p float64 (8 MB at p = 1024)
         return out
 
     for _ in range(args.warmup):
@@ -310,6 +401,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # min over individually timed steps next to the mean (the reference harness reports the
+    # minimum, benchmark/main.py:108-128); outside the timed region above
+    per_step = []
+    for _ in range(min(args.steps, 10)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        e1.synchronize()
+        per_step.append(e0.elapsed_time(e1))
+    ms_min = min(per_step)
 
     alg_bytes = synth.algorithmic_bytes(mat)
     flops = synth.algorithmic_flops(mat) if isinstance(mat, tm.SplitMatrix) else (
@@ -336,15 +438,17 @@ def main():
             roof = {"bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (a profiler cannot be
-        # attached from inside this process); null when no measurement exists for this kernel
+        # HBM bytes per launch of that kernel, measured NOW: rocprofv3 --pmc passes over a child
+        # run that launches the same op (null when rocprofv3 is unavailable or N > 1)
         roof["traffic"] = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if n_local == 10_000_000:
-                roof["traffic"] = tr.get(args.workload, {}).get(dom)
-        except Exception:
-            pass
+        if world == 1 and not args.no_traffic:
+            roof["traffic"] = measure_traffic(args, dom)
+        # the dense self-sandwich (MFMA syrk) against the matrix spec of its dtype
+        mfma_frac = None
+        for name, ms in bd.items():
+            fl = op_flops(mat, name)
+            if fl:
+                mfma_frac = round(fl / (ms * 1e-3) / (peak_tf * 1e12), 4)
         roof["kernel"] = dom
         roof["kernel_ms"] = round(dom_ms, 4)
         roof["algorithmic_bytes_per_launch"] = int(dom_bytes)
@@ -372,7 +476,12 @@ def main():
                        "sharding": "rows" if world > 1 else "none",
                        "collective": "all_reduce(p*p f64)" if world > 1 else "none"},
             "roofline": roof,
+            "ms_per_step_min": round(ms_min, 4),
             "hbm_frac_whole_job": round(alg_bytes / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # whole step against max(HBM, MFMA): bytes / 8 TB/s vs flops / dense matrix peak of the dtype
+            "mixed_roofline_ms": round(max(alg_bytes / world / (HBM_PEAK_GBS * 1e9),
+                                           flops / world / (peak_tf * 1e12)) * 1e3, 4),
+            "mfma_frac_of_spec": mfma_frac,
             "sum_kernel_ms": round(sum(bd.values()), 4),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only

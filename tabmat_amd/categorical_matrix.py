@@ -23,6 +23,7 @@ from .util import (
     check_sandwich_compatible,
     check_transpose_matvec_out_shape,
     normalize_index,
+    device_row_index,
 )
 
 
@@ -47,7 +48,8 @@ class CategoricalMatrix(MatrixBase):
     def __init__(self, cat_vec, categories: Optional[np.ndarray] = None, drop_first: bool = False,
                  dtype=np.float64, column_name: Optional[str] = None,
                  term_name: Optional[str] = None, column_name_format: str = "{name}[{category}]",
-                 cat_missing_method: str = "fail", cat_missing_name: str = "(MISSING)"):
+                 cat_missing_method: str = "fail", cat_missing_name: str = "(MISSING)",
+                 _validated: bool = False):
         if cat_missing_method not in {"fail", "zero", "convert"}:
             raise ValueError(
                 "cat_missing_method must be one of 'fail' 'zero' or 'convert'; "
@@ -64,10 +66,36 @@ class CategoricalMatrix(MatrixBase):
             self._host_codes = None
             n = int(cat_vec.numel())
             self._has_missings = cat_missing_method == "zero"
+            if n and not _validated:
+                # the kernels index bins / vectors with the codes: check the range once (the
+                # host path does the same, categorical_matrix.py:238-247)
+                lo, hi = int(self._dev_codes.min().item()), int(self._dev_codes.max().item())
+                if hi >= len(self.categories):
+                    raise ValueError("Indices exceed length of categories.")
+                if lo < -1:
+                    raise ValueError("Indices must be non-negative (or -1 for missing).")
+                if lo == -1 and cat_missing_method == "fail":
+                    raise ValueError(
+                        "Categorical data can't have missing values "
+                        "if cat_missing_method='fail'.")
+                if lo == -1 and cat_missing_method == "convert":
+                    if cat_missing_name in self.categories:
+                        raise ValueError(f"Missing category {cat_missing_name} already exists.")
+                    self.categories = np.hstack([self.categories.astype(object),
+                                                 [cat_missing_name]])
+                    self._dev_codes = torch.where(self._dev_codes < 0,
+                                                  len(self.categories) - 1, self._dev_codes).to(torch.int32)
+                self._has_missings = lo == -1 and cat_missing_method == "zero"
         else:
-            if hasattr(cat_vec, "cat") and hasattr(cat_vec.cat, "codes"):  # pandas categorical
+            if hasattr(cat_vec, "cat") and hasattr(cat_vec.cat, "codes"):  # pandas categorical Series
                 categories_ = np.asarray(cat_vec.cat.categories)
                 indices = np.asarray(cat_vec.cat.codes)
+                self.categories = categories_ if categories is None else np.asarray(categories)
+            elif hasattr(cat_vec, "codes") and hasattr(cat_vec, "categories"):
+                # a bare pd.Categorical: keep its declared categories and their order
+                # (categorical_matrix.py:232-236 uses cat_vec.categories / .codes)
+                categories_ = np.asarray(cat_vec.categories)
+                indices = np.asarray(cat_vec.codes)
                 self.categories = categories_ if categories is None else np.asarray(categories)
             elif categories is not None:
                 self.categories = np.asarray(categories)
@@ -175,6 +203,15 @@ class CategoricalMatrix(MatrixBase):
         row, col = check_indexer(item)
         full = (isinstance(col, slice) and len(range(*col.indices(self.shape[1]))) == self.shape[1]) or (
             isinstance(col, np.ndarray) and np.array_equal(col.ravel(), np.arange(self.shape[1])))
+        if full and self._dev_codes is not None:
+            # row indexing of codes that live in HBM stays in HBM
+            kind, *arg = device_row_index(row, self.shape[0])
+            codes = self._dev_codes[arg[0]:arg[1]] if kind == "slice" else \
+                self._dev_codes[D.idx_dev(arg[0], torch.int64)]
+            return CategoricalMatrix(codes.contiguous(), categories=self.categories,
+                                     drop_first=self.drop_first, dtype=self.dtype,
+                                     column_name=self._colname,
+                                     cat_missing_method=self._missing_method, _validated=True)
         if full:
             if isinstance(row, np.ndarray):
                 row = row.ravel()

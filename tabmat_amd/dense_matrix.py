@@ -21,6 +21,8 @@ from .util import (
     check_transpose_matvec_out_shape,
     normalize_index,
     np_dtype_of,
+    device_row_index,
+    selects_all_columns,
 )
 
 
@@ -133,6 +135,12 @@ class DenseMatrix(MatrixBase):
 
     def __getitem__(self, key):
         row, col = check_indexer(key)
+        if self._devblk is not None and selects_all_columns(col, self.shape[1]):
+            # row indexing of a block that lives in HBM stays in HBM (no host round trip)
+            kind, *arg = device_row_index(row, self.shape[0])
+            t = self._devblk.as_2d()
+            sub = t[arg[0]:arg[1]] if kind == "slice" else t[D.idx_dev(arg[0], torch.int64)]
+            return type(self)(sub, column_names=self._colnames, term_names=self._terms)
         names = np.array(self._colnames, dtype=object)[col].ravel().tolist()
         terms = np.array(self._terms, dtype=object)[col].ravel().tolist()
         return type(self)(self.toarray()[row, col], column_names=names, term_names=terms)

@@ -33,6 +33,21 @@ def bucket_rows(rows: Optional[np.ndarray], lo: int, hi: int) -> Optional[np.nda
     return sel.astype(np.int32)
 
 
+def shard(mat, world_size: Optional[int] = None, rank: Optional[int] = None, group=None):
+    """Row shard of `mat` (any MatrixBase, e.g. a SplitMatrix) for this rank: every block is cut
+    to the rank's contiguous row range (shard_bounds) -- on the device when the block already
+    lives in HBM (DenseMatrix / SparseMatrix / CategoricalMatrix.__getitem__), so a matrix built
+    once can be re-partitioned without a host round trip -- and wrapped in a RowShardedMatrix.
+    SURVEY.md 8e: "partitioning at construction"."""
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = mat.shape[0]
+    lo, hi = shard_bounds(n, world_size, rank)
+    return RowShardedMatrix(mat[lo:hi], group, bounds=(lo, hi), n_global=n)
+
+
 class RowShardedMatrix:
     """Wraps the LOCAL row shard (any MatrixBase) of a matrix that is row-partitioned over the
     ranks of `group`.  d / v passed to the products are the local slices (length = local rows);
@@ -40,9 +55,12 @@ class RowShardedMatrix:
 
     def __init__(self, local, group=None,
                  local_sandwich: Optional[Callable] = None,
-                 local_transpose_matvec: Optional[Callable] = None):
+                 local_transpose_matvec: Optional[Callable] = None,
+                 bounds: Optional[tuple] = None, n_global: Optional[int] = None):
         self.local = local
         self.group = group
+        self.bounds = bounds            # (lo, hi) of this shard in the global row numbering
+        self.n_global = n_global
         # injection points so the N>1 host logic can be exercised on CPU (gloo) in tests
         self._sandwich = local_sandwich or (lambda d, rows, cols: local.sandwich(d, rows, cols))
         self._tmv = local_transpose_matvec or (
@@ -74,3 +92,18 @@ class RowShardedMatrix:
     def matvec(self, v, cols=None, out=None):
         """Row-partitioned output: the local rows of X v; no collective."""
         return self.local.matvec(v, cols, out)
+
+    # ---- the same products addressed in GLOBAL row numbering (needs bounds, see shard()) ----
+    def local_slice(self, x):
+        """The rows of a global length-n vector (numpy or torch) that belong to this shard."""
+        lo, hi = self.bounds
+        return x[lo:hi]
+
+    def sandwich_global(self, d, rows=None, cols=None):
+        """d: global length-n vector; rows: global row ids or None."""
+        lo, hi = self.bounds
+        return self.sandwich(self.local_slice(d), bucket_rows(rows, lo, hi), cols)
+
+    def transpose_matvec_global(self, v, rows=None, cols=None):
+        lo, hi = self.bounds
+        return self.transpose_matvec(self.local_slice(v), bucket_rows(rows, lo, hi), cols)

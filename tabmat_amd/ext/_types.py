@@ -96,6 +96,24 @@ class CsrDev:
             self._cm = cm
         return cm
 
+    def take_rows(self, kind, *arg) -> "CsrDev":
+        """Row-indexed copy built on the device: kind "slice" (lo, hi) or "index" (row ids)."""
+        dev = self.data.device
+        if kind == "slice":
+            lo, hi = arg
+            a, b = int(self.indptr[lo].item()), int(self.indptr[hi].item())
+            return CsrDev(self.data[a:b].contiguous(), self.indices[a:b].contiguous(),
+                          (self.indptr[lo:hi + 1] - a).contiguous(), hi - lo, self.m)
+        r = D.idx_dev(arg[0], torch.int64)
+        starts = self.indptr[r]
+        counts = self.indptr[r + 1] - starts
+        indptr = torch.zeros(r.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, dim=0, out=indptr[1:])
+        nnz = int(indptr[-1].item())
+        pos = torch.repeat_interleave(starts - indptr[:-1], counts) + \
+            torch.arange(nnz, device=dev, dtype=torch.int64)
+        return CsrDev(self.data[pos], self.indices[pos], indptr, int(r.numel()), self.m)
+
     @staticmethod
     def from_scipy(csr) -> "CsrDev":
         n, m = csr.shape

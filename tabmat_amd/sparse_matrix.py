@@ -17,6 +17,8 @@ from .util import (
     check_sandwich_compatible,
     check_transpose_matvec_out_shape,
     normalize_index,
+    device_row_index,
+    selects_all_columns,
 )
 
 
@@ -202,6 +204,11 @@ class SparseMatrix(MatrixBase):
 
     def __getitem__(self, key):
         row, col = check_indexer(key)
+        if self._devblk is not None and selects_all_columns(col, self.shape[1]):
+            # row indexing of the CSR twin in HBM (no host round trip)
+            sub = type(self).from_device(self._devblk.take_rows(*device_row_index(row, self.shape[0])))
+            sub._colnames, sub._terms = list(self._colnames), list(self._terms)
+            return sub
         names = np.array(self._colnames, dtype=object)[col].ravel().tolist()
         terms = np.array(self._terms, dtype=object)[col].ravel().tolist()
         return type(self)(self._host()[row, col], column_names=names, term_names=terms)

@@ -84,6 +84,30 @@ def check_sandwich_compatible(mat, d) -> None:
         )
 
 
+def selects_all_columns(col, m: int) -> bool:
+    """True when the canonical column indexer keeps every column in order."""
+    if isinstance(col, slice):
+        return col.indices(m) == (0, m, 1) or (m == 0)
+    col = np.asarray(col).ravel()
+    return len(col) == m and bool(np.array_equal(col, np.arange(m)))
+
+
+def device_row_index(row, n: int):
+    """Canonical row indexer -> ("slice", lo, hi) for a unit-step slice, else ("index", int64
+    numpy array of non-negative row ids).  Used by the device form of row indexing
+    (split_matrix.py:462-477: train / validation splits without a host round trip)."""
+    if isinstance(row, slice):
+        lo, hi, step = row.indices(n)
+        if step == 1:
+            return ("slice", lo, max(lo, hi))
+        return ("index", np.arange(lo, hi, step, dtype=np.int64))
+    r = np.asarray(row).ravel()
+    if r.dtype == bool:
+        r = np.flatnonzero(r)
+    r = r.astype(np.int64)
+    return ("index", np.where(r < 0, r + n, r))
+
+
 def check_indexer(indexer):
     """Canonical (row_indexer, col_indexer) pair (util.py:70-115)."""
     if not isinstance(indexer, tuple):

@@ -174,3 +174,13 @@ def mixed_specs(n, k_dense, k_sparse, cats, seed, dtype=np.float64, density=0.05
         idx.append(np.arange(cur, cur + w, dtype=np.int64))
         cur += w
     return specs, idx
+
+
+def take_rows(spec, rows):
+    """Row-indexed copy of a neutral block spec (rows: integer array, repeats allowed)."""
+    rows = np.asarray(rows)
+    if spec[0] == "dense":
+        return ("dense", np.ascontiguousarray(spec[1][rows]))
+    if spec[0] == "sparse":
+        return ("sparse", spec[1].tocsr()[rows].tocsc())
+    return ("cat", spec[1][rows], spec[2], spec[3])

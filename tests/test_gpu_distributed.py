@@ -1,0 +1,93 @@
+"""Row-sharded products with the REAL HIP blocks: world_size 2 on one GPU (gloo process group,
+both ranks on cuda:0), shards cut by tabmat_amd.distributed.shard(); the all-reduced results
+must equal the single-rank HIP result and the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q, device_resident):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _cases as cs
+        from _gpu_util import to_tm_split
+        from oracle import oracle as orc
+        from tabmat_amd.distributed import shard
+
+        n = 30_011
+        specs, idx = cs.mixed_specs(n, 24, 70, (11, 5, 3), seed=11)
+        full = to_tm_split(specs, idx)
+        if device_resident:
+            full.to_device()          # shards are then cut in HBM
+        blocks = [cs.to_oracle_block(s) for s in specs]
+        rng = np.random.default_rng(5)
+        d = rng.random(n)
+        w = rng.standard_normal(n)
+        v = rng.standard_normal(full.shape[1])
+        rows_g = np.sort(rng.choice(n, n // 3, replace=False))
+        sh = shard(full)
+        lo, hi = sh.bounds
+        assert sh.local.shape[0] == hi - lo
+        got = sh.sandwich_global(d)
+        got_rows = sh.sandwich_global(d, rows_g)
+        got_dev = sh.sandwich(torch.from_numpy(d[lo:hi]).cuda())        # device in -> device out
+        got_tmv = sh.transpose_matvec_global(w)
+        got_mv = sh.matvec(v)
+        want = orc.split_sandwich(blocks, idx, d)
+        want_rows = orc.split_sandwich(blocks, idx, d, rows_g)
+        want_tmv = orc.split_transpose_matvec(blocks, idx, w)
+        want_mv = orc.split_matvec(blocks, idx, v)[lo:hi]
+        single = full.sandwich(d)
+
+        def rel(a, b):
+            return float(np.abs(np.asarray(a) - b).max() / max(np.abs(b).max(), 1e-300))
+
+        errs = dict(sand=rel(got, want), rows=rel(got_rows, want_rows),
+                    dev=rel(got_dev.cpu().numpy(), want), tmv=rel(got_tmv, want_tmv),
+                    mv=rel(got_mv, want_mv), single=rel(got, single))
+        q.put((rank, errs, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_world2_hip_shards_match_single_rank_and_oracle(device_resident):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, device_resident)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bounds = sorted(r[2] for r in res)
+    assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == 30_011
+    for rank, errs, _ in res:
+        for k, e in errs.items():
+            assert e < 1e-10, (rank, k, e)
