@@ -383,6 +383,22 @@ int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_
                          const int64_t *ci, double *out, int64_t p, int mirror, int diag,
                          void *stream);
 
+/* =====================================================================================
+ * StandardizedMatrix on device blocks (standardized_mat.py:123-230).
+ * tm_vec_sum_*: out[0] = sum_i v[rows[i]] (rows == NULL: v[0..n)), accumulated in double in a
+ *   fixed order (the np.sum(d[rows]) / other.sum(0) of standardized_mat.py:159,215).
+ * tm_standardize_sandwich_f64: the rank-one corrections of standardized_mat.py:148-171 in place:
+ *   inout[i, j] = inout[i, j] mult[i] mult[j] + m[i] shift[j] + shift[i] m[j] + shift[i] shift[j] S,
+ *   m = mult * xtd (xtd = mat' d), S = sum_d[0]; mult == NULL: ones; inner_diag != NULL: the inner
+ *   sandwich is diagonal (a categorical block) and given as that length-k vector, inout is
+ *   overwritten.  All pointers are device pointers.
+ * ===================================================================================== */
+int tm_vec_sum_f32(const float *v, const int32_t *rows, int64_t n, double *out, void *stream);
+int tm_vec_sum_f64(const double *v, const int32_t *rows, int64_t n, double *out, void *stream);
+int tm_standardize_sandwich_f64(double *inout, const double *inner_diag, const double *xtd,
+                                const double *shift, const double *mult, const double *sum_d,
+                                int64_t k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,9 +250,37 @@ class SplitMatrix(MatrixBase):
         sub_d = [None if sc is None else D.idx_dev(sc) for sc in sub_cols]
         return pos_d, sub_d, n_cols
 
-    def _sandwich_dev(self, d, rows, cols_host, plan=None):
+    def _sandwich_xtd_dev(self, d, rows, cols_host):
+        """(X' diag(d) X, X' d) restricted to rows / cols, both float64 on the device, from ONE
+        pass over the blocks where the algebra allows it (what StandardizedMatrix.sandwich needs,
+        standardized_mat.py:148-150, which makes two passes): the column sums of a categorical
+        block are the diagonal of its own sandwich, and for any other block B they are the sums
+        over the levels of its cross term with a COMPLETE categorical C (no dropped level, no
+        missing codes: every row of C has exactly one 1, so C 1 = 1 and B' D 1 = (B' D C) 1).
+        Blocks without such a partner get their own transpose_matvec launch."""
+        colsum = [None] * len(self.matrices)
+        out = self._sandwich_dev(d, rows, cols_host, colsum=colsum)
+        pos_d, sub_d, n_cols = self._sandwich_plan(cols_host)
+        xtd = D.zeros((n_cols,), torch.float64)
+        for i, (mi, pd, sd) in enumerate(zip(self.matrices, pos_d, sub_d)):
+            if sd is not None and D.nlen(sd) == 0:
+                continue
+            cs = colsum[i]
+            if cs is None:
+                if isinstance(mi, CategoricalMatrix):
+                    full = D.zeros((mi.shape[1],), d.dtype)
+                    mi._transpose_matvec_dev(d, rows, sd, full)
+                    cs = full if sd is None else full[sd.to(torch.int64)]
+                else:
+                    cs = mi._matvec_dev(d, rows, sd, None, True)
+            xtd[pd] = cs.to(torch.float64)
+        return out, xtd
+
+    def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None):
         """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
-        Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356)."""
+        Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
+        colsum: optional list (one slot per block) that receives X_block' d[rows] (restricted to
+        the block's columns) wherever it falls out of the sandwich for free."""
         pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
         out = D.zeros((n_cols, n_cols), torch.float64)
         mats = self.matrices
@@ -294,6 +322,10 @@ class SplitMatrix(MatrixBase):
                     continue
                 for ci, i in enumerate(cat_ids):
                     res = stacked[int(offs[ci]):int(offs[ci + 1])]
+                    if (colsum is not None and colsum[w] is None and not mats[i].drop_first
+                            and not mats[i]._has_missings):
+                        cs = res.sum(dim=0)           # all levels of a complete categorical
+                        colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
                     res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
                     xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                     done.add((min(i, w), max(i, w)))
@@ -302,6 +334,8 @@ class SplitMatrix(MatrixBase):
                 continue
             if isinstance(mi, CategoricalMatrix):
                 diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
+                if colsum is not None:
+                    colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
                 xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
             else:
                 res = mi._sandwich_dev(d, rows, sub_d[i])

@@ -1,19 +1,37 @@
 """StandardizedMatrix: lazily centred / scaled view  self[i, j] = mult[j] * mat[i, j] + shift[j]
-(reference: /root/reference/src/tabmat/standardized_mat.py).  Everything heavy is delegated to
-the wrapped matrix' device products; the corrections are O(p^2) host arithmetic."""
+(reference: /root/reference/src/tabmat/standardized_mat.py) over device-resident blocks.
+
+Everything stays on the device: shift / mult are kept in HBM next to their host copies, the
+per-call vector may be a numpy array (numpy result) or a torch cuda tensor (device result, no
+host traffic), the O(p^2) rank-one corrections of the sandwich run in
+tm_standardize_sandwich_f64 and the sums over the per-call vector in tm_vec_sum_*.  The sandwich
+gets X' d out of the SAME pass over the blocks as the inner sandwich wherever the algebra allows
+it (SplitMatrix._sandwich_xtd_dev); the reference makes two passes (standardized_mat.py:148-150)."""
 from __future__ import annotations
 
 import numpy as np
-from scipy import sparse as sps
+import torch
 
+from . import _device as D
+from ._lib import call
 from .matrix_base import MatrixBase
 from .util import (
     check_matvec_dimensions,
     check_sandwich_compatible,
     check_transpose_matvec_out_shape,
+    normalize_index,
     set_up_rows_or_cols,
     setup_restrictions,
 )
+
+
+def _vec_sum(v_dev, rows_d):
+    """sum(v[rows]) as a float64 device scalar (tm_vec_sum_*)."""
+    out = D.zeros((1,), torch.float64)
+    n = v_dev.numel() if rows_d is None else D.nlen(rows_d)
+    if n:
+        call(f"tm_vec_sum_{D.fsuf(v_dev)}", D.p(v_dev), D.p(rows_d), n, D.p(out), D.stream_ptr())
+    return out
 
 
 class StandardizedMatrix:
@@ -22,6 +40,10 @@ class StandardizedMatrix:
     def __init__(self, mat: MatrixBase, shift, mult=None):
         if not isinstance(mat, MatrixBase):
             raise TypeError("mat should be an instance of a MatrixBase subclass.")
+        if isinstance(shift, torch.Tensor):
+            shift = D.to_host(shift)
+        if isinstance(mult, torch.Tensor):
+            mult = D.to_host(mult)
         shift_arr = np.atleast_1d(np.squeeze(shift))
         want = (mat.shape[1],)
         if shift_arr.shape != want:
@@ -35,11 +57,44 @@ class StandardizedMatrix:
                                  f"but it has shape {np.asarray(mult).shape}")
         self.shift, self.mult, self.mat = shift_arr, mult_arr, mat
         self.shape, self.ndim, self.dtype = mat.shape, mat.ndim, mat.dtype
+        self._dev_cache = {}
 
+    # ---- device copies of the p-sized vectors ---------------------------------------------
+    def _shift_dev(self, cols_n=None, dtype=torch.float64):
+        return self._pvec("shift", self.shift, cols_n, dtype)
+
+    def _mult_dev(self, cols_n=None, dtype=torch.float64):
+        return None if self.mult is None else self._pvec("mult", self.mult, cols_n, dtype)
+
+    def _pvec(self, name, arr, cols_n, dtype):
+        key = (name, dtype)
+        if key not in self._dev_cache:
+            self._dev_cache[key] = D.to_dev(np.asarray(arr, dtype=np.float64), dtype)
+        t = self._dev_cache[key]
+        return t if cols_n is None else t[D.idx_dev(cols_n, torch.int64)]
+
+    # ---- products -------------------------------------------------------------------------
     def matvec(self, other_mat, cols=None, out=None):
-        """standardized_mat.py:69-97."""
+        """standardized_mat.py:69-97: mat.matvec(mult * v, cols) + shift[cols] . v[cols]."""
+        on_dev = D.is_dev(other_mat)
+        if on_dev and other_mat.ndim == 1:
+            v = other_mat
+            check_matvec_dimensions(self, v, transpose=False)
+            cols_n = normalize_index(cols, self.shape[1])
+            tdt = D.torch_dtype(self.dtype)
+            v = D.to_dev(v, tdt)
+            scaled = v if self.mult is None else v * self._mult_dev(None, tdt)
+            sh = self._shift_dev(cols_n, tdt)
+            vc = v if cols_n is None else v[D.idx_dev(cols_n, torch.int64)]
+            # the scalar shift . v is the start value of the accumulating block kernels
+            res = (sh * vc).sum().expand(self.shape[0]).contiguous()
+            res = self.mat.matvec(scaled, cols, out=res)
+            if out is None:
+                return res
+            out += res
+            return out
         cols = set_up_rows_or_cols(cols, self.shape[1])
-        other_mat = np.asarray(other_mat)
+        other_mat = np.asarray(D.to_host(other_mat) if on_dev else other_mat)
         check_matvec_dimensions(self, other_mat, transpose=False)
         scaled = other_mat
         if self.mult is not None:
@@ -52,42 +107,77 @@ class StandardizedMatrix:
         mult = None if self.mult is None else [self.mult[i]]
         return StandardizedMatrix(self.mat.getcol(i), [self.shift[i]], mult)
 
+    def _inner_xtd_dev(self, d, rows_d, cols_n):
+        """(inner sandwich or None, its diagonal or None, mat' d) as float64 device tensors."""
+        from .categorical_matrix import CategoricalMatrix
+        from .split_matrix import SplitMatrix
+
+        mat = self.mat
+        if isinstance(mat, SplitMatrix):
+            inner, xtd = mat._sandwich_xtd_dev(d, rows_d, cols_n)
+            return inner, None, xtd
+        cols_d = D.idx_dev(cols_n)
+        if isinstance(mat, CategoricalMatrix):
+            diag = mat._sandwich_diag_dev(d, rows_d, cols_d).to(torch.float64)
+            return None, diag, diag           # one-hot entries are 0 / 1: C' d = diag(C' D C)
+        inner = mat._sandwich_dev(d, rows_d, cols_d).to(torch.float64)
+        xtd = mat._matvec_dev(d, rows_d, cols_d, None, True).to(torch.float64)
+        return inner, None, xtd
+
     def sandwich(self, d, rows=None, cols=None):
-        """Inner sandwich + rank-one corrections (standardized_mat.py:123-172)."""
-        if not hasattr(d, "dtype"):
+        """Inner sandwich + rank-one corrections (standardized_mat.py:123-172), float64.
+        d: numpy array (numpy result) or torch cuda tensor (device result)."""
+        on_dev = D.is_dev(d)
+        if not on_dev and not hasattr(d, "dtype"):
             d = np.asarray(d)
         check_sandwich_compatible(self, d)
-        if rows is not None or cols is not None:
-            r_, c_ = setup_restrictions(self.shape, rows, cols)
-            rows = r_ if rows is not None else None
-            cols = c_ if cols is not None else None
-        inner = self.mat.sandwich(d, rows, cols)
-        d_mat = self.mat.transpose_matvec(d, rows, cols)
-        lim_mult = None
-        if self.mult is not None:
-            lim_mult = self.mult[cols] if cols is not None else self.mult
-            d_mat = d_mat * lim_mult
-        lim_shift = self.shift[cols] if cols is not None else self.shift
-        lim_d = d[rows] if rows is not None else d
-        res = (np.outer(d_mat, lim_shift) + np.outer(lim_shift, d_mat)
-               + np.outer(lim_shift, lim_shift) * np.sum(lim_d))
-        if sps.issparse(inner):
-            diag = np.asarray(inner.diagonal(), dtype=float)
-            if lim_mult is not None:
-                diag = diag * lim_mult**2
-            k = np.arange(res.shape[0])
-            res[k, k] += diag
-        else:
-            res += inner * np.outer(lim_mult, lim_mult) if lim_mult is not None else inner
-        return res
+        rows_n = normalize_index(rows, self.shape[0])
+        cols_n = normalize_index(cols, self.shape[1])
+        d_dev = D.to_dev(d)
+        rows_d = D.idx_dev(rows_n)
+        k = self.shape[1] if cols_n is None else len(cols_n)
+        if rows_n is not None and len(rows_n) == 0:
+            res = D.zeros((k, k), torch.float64)
+            return res if on_dev else D.to_host(res)
+        inner, diag, xtd = self._inner_xtd_dev(d_dev, rows_d, cols_n)
+        res = inner.contiguous() if inner is not None else D.empty((k, k), torch.float64)
+        sum_d = _vec_sum(d_dev, rows_d)
+        # (operands held in locals until the launch is queued: a temporary whose pointer has been
+        # taken would hand its memory to the next temporary)
+        xtd_c = xtd.contiguous()
+        shift_c = self._shift_dev(cols_n).contiguous()
+        mult_c = None if self.mult is None else self._mult_dev(cols_n).contiguous()
+        call("tm_standardize_sandwich_f64", D.p(res), D.p(diag), D.p(xtd_c), D.p(shift_c),
+             D.p(mult_c), D.p(sum_d), k, D.stream_ptr())
+        return res if on_dev else D.to_host(res)
 
     def unstandardize(self) -> MatrixBase:
         return self.mat
 
     def transpose_matvec(self, other, rows=None, cols=None, out=None):
-        """standardized_mat.py:178-230."""
+        """standardized_mat.py:178-230: mult[cols] * mat.T[cols, rows] other[rows]
+        + shift[cols] * sum(other[rows])."""
         check_transpose_matvec_out_shape(self, out)
-        other = np.asarray(other)
+        on_dev = D.is_dev(other)
+        if on_dev and other.ndim == 1:
+            check_matvec_dimensions(self, other, transpose=True)
+            rows_n = normalize_index(rows, self.shape[0])
+            cols_n = normalize_index(cols, self.shape[1])
+            tdt = D.torch_dtype(self.dtype)
+            v = D.to_dev(other, tdt)
+            res = self.mat.transpose_matvec(v, rows, cols)
+            s = _vec_sum(v, D.idx_dev(rows_n)).to(tdt)
+            if self.mult is not None:
+                res = res * self._mult_dev(cols_n, tdt)
+            res = res + self._shift_dev(cols_n, tdt) * s
+            if out is None:
+                return res
+            if cols_n is None:
+                out += res
+            else:
+                out[D.idx_dev(cols_n, torch.int64)] += res
+            return out
+        other = np.asarray(D.to_host(other) if on_dev else other)
         check_matvec_dimensions(self, other, transpose=True)
         res = self.mat.transpose_matvec(other, rows, cols)
         rows_a, cols_a = setup_restrictions(self.shape, rows, cols)
