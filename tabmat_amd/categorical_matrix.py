@@ -173,6 +173,10 @@ class CategoricalMatrix(MatrixBase):
         if self._has_missings:
             orig = orig.view(np.ma.MaskedArray)
             orig.mask = self.indices == -1
+        elif self._missing_method == "convert" and self._missing_category in self.categories:
+            # categorical_matrix.py:463-468: the converted level reads back as missing
+            orig = orig.view(np.ma.MaskedArray)
+            orig.mask = self.indices == len(self.categories) - 1
         return orig
 
     def tocsr(self) -> sps.csr_matrix:

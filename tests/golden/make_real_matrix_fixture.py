@@ -23,6 +23,18 @@ DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "real_matrix_bloc
 
 
 def main():
+    build(DST, cat_threshold=4, sparse_threshold=0.1)
+    # Variant that FORCES a sparse block (the default thresholds yield [cat, dense, cat, cat, cat]):
+    # cat_threshold above every level count one-hot expands all categoricals and
+    # sparse_threshold = 0.3 sends their low-density columns to the sparse block
+    # (constructor.py:128-153 allows both), so K2 / K3 / categorical-free cross terms see
+    # reference-held data too.  The tests also load the sparse block with int64 CSC indices.
+    build(DST.replace(".npz", "_sparse.npz"), cat_threshold=10**6, sparse_threshold=0.3)
+    # ... and one with all three kinds side by side: [sparse, dense, cat, cat]
+    build(DST.replace(".npz", "_mixed.npz"), cat_threshold=8, sparse_threshold=0.3)
+
+
+def build(dst, cat_threshold, sparse_threshold):
     df = pd.read_pickle(SRC)
     n = df.shape[0]
     out = {}
@@ -38,10 +50,10 @@ def main():
             ncat = len(s.cat.categories)
             onehot = np.zeros((n, ncat))
             onehot[np.arange(n), codes] = 1.0
-            if ncat < 4:   # constructor.py:128-153 -> _split_sparse_and_dense_parts
+            if ncat < cat_threshold:   # constructor.py:128-153 -> _split_sparse_and_dense_parts
                 dens = (onehot != 0).mean(0)
-                d_loc = np.where(dens > 0.1)[0]
-                s_loc = np.where(dens <= 0.1)[0]
+                d_loc = np.where(dens > sparse_threshold)[0]
+                s_loc = np.where(dens <= sparse_threshold)[0]
                 if len(d_loc):
                     blocks.append(("dense", np.asfortranarray(onehot[:, d_loc]), col + d_loc))
                 if len(s_loc):
@@ -52,7 +64,7 @@ def main():
             col += ncat
         else:
             x = s.to_numpy().astype(np.float64)
-            if (x != 0).mean() <= 0.1:
+            if (x != 0).mean() <= sparse_threshold:
                 sparse_cols.append(x); sparse_idx.append(col)
             else:
                 dense_cols.append(x); dense_idx.append(col)
@@ -104,8 +116,8 @@ def main():
     out["rows"] = rows
     out["cols"] = cols
     out["sandwich_rows_cols"] = ((Xs.T * d[rows].astype(np.longdouble)) @ Xs).astype(np.float64)
-    np.savez_compressed(DST, **out)
-    print("wrote", DST, "blocks:", kinds, "p =", col)
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, "blocks:", kinds, "p =", col)
 
 
 if __name__ == "__main__":

@@ -219,11 +219,16 @@ def test_many_types(missing):
         np.testing.assert_almost_equal(mat.matvec(v), M.dot(v))
 
 
-def test_real_matrix_golden():
-    """The reference's only data fixture (tests/test_real_matrix.py), standardized as there."""
+@pytest.mark.parametrize("idx64", [False, True])
+@pytest.mark.parametrize("name", ["real_matrix_blocks.npz", "real_matrix_blocks_sparse.npz",
+                                  "real_matrix_blocks_mixed.npz"])
+def test_real_matrix_golden(name, idx64):
+    """The reference's only data fixture (tests/test_real_matrix.py), standardized as there; the
+    _sparse / _mixed variants split it with other thresholds so that a sparse block exists
+    (tests/golden/make_real_matrix_fixture.py), loaded with int32 and int64 CSC indices."""
     import tabmat_amd as tm
 
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_matrix_blocks.npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
     blocks, idx = [], []
     for b, kind in enumerate(z["kinds"]):
         idx.append(z[f"b{b}_indices"])
@@ -233,7 +238,11 @@ def test_real_matrix_golden():
         elif kind == "dense":
             blocks.append(tm.DenseMatrix(z[f"b{b}_array"]))
         else:
-            blocks.append(tm.SparseMatrix(sps.csc_matrix(z[f"b{b}_array"])))
+            S = sps.csc_matrix(z[f"b{b}_array"])
+            if idx64:
+                S = sps.csc_matrix((S.data, S.indices.astype(np.int64), S.indptr.astype(np.int64)),
+                                   shape=S.shape)
+            blocks.append(tm.SparseMatrix(S))
     X = tm.SplitMatrix(blocks, idx)
     np.testing.assert_array_equal(X.toarray(), z["design"])
     np.testing.assert_allclose(X.sandwich(z["d"]), z["sandwich"], rtol=1e-12, atol=1e-12)
@@ -248,4 +257,4 @@ def test_real_matrix_golden():
     X_std = X.standardize(wts, True, True)[0]
     r = np.random.rand(n)
     dense = X_std.toarray()
-    np.testing.assert_almost_equal(X_std.sandwich(r), (dense.T * r) @ dense, 10)
+    np.testing.assert_almost_equal(X_std.sandwich(r), (dense.T * r) @ dense, 12)

@@ -205,8 +205,11 @@ def test_categorical_counts_bit_exact(dtype):
 
 
 # ---- the reference's only data fixture (tests/test_real_matrix.py) ----------
-def _load_real():
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_matrix_blocks.npz"))
+REAL_FIXTURES = ["real_matrix_blocks.npz", "real_matrix_blocks_sparse.npz", "real_matrix_blocks_mixed.npz"]
+
+
+def _load_real(name="real_matrix_blocks.npz", idx64=False):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
     blocks, idx = [], []
     for b, kind in enumerate(z["kinds"]):
         idx.append(z[f"b{b}_indices"])
@@ -215,12 +218,18 @@ def _load_real():
         elif kind == "dense":
             blocks.append(orc.Dense(z[f"b{b}_array"]))
         else:
-            blocks.append(orc.Sparse(sps.csc_matrix(z[f"b{b}_array"])))
+            S = sps.csc_matrix(z[f"b{b}_array"])
+            if idx64:       # ext/sparse.pyx:13-15 win_integral: int32 or int64 index arrays
+                S = sps.csc_matrix((S.data, S.indices.astype(np.int64), S.indptr.astype(np.int64)),
+                                   shape=S.shape)
+            blocks.append(orc.Sparse(S))
     return z, blocks, idx
 
 
-def test_real_matrix_golden():
-    z, blocks, idx = _load_real()
+@pytest.mark.parametrize("idx64", [False, True])
+@pytest.mark.parametrize("name", REAL_FIXTURES)
+def test_real_matrix_golden(name, idx64):
+    z, blocks, idx = _load_real(name, idx64)
     np.testing.assert_array_equal(orc.split_toarray(blocks, idx), z["design"])
     np.testing.assert_allclose(orc.split_sandwich(blocks, idx, z["d"]), z["sandwich"],
                                rtol=1e-12, atol=1e-12)
