@@ -384,6 +384,42 @@ int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_
                          void *stream);
 
 /* =====================================================================================
+ * Multi-right-hand-side matvec / transpose-matvec (2-D `vec`).  The reference hands these to
+ * scipy.sparse (sparse_matrix.py:252-254, 266-268) and NumPy BLAS (dense_matrix.py:212-217 with
+ * a 2-D operand).  V: (m, K) for matvec, (n, K) for rmatvec, row-major; out: (n_rows, K) resp.
+ * (n_cols, K) row-major, ACCUMULATED into.  rows / cols as in the 1-D entry points
+ * (NULL = all); for the matvec forms `cols` masks the columns that take part (V keeps m rows).
+ * ===================================================================================== */
+int tm_csr_matvec_multi_f32(const float *csr_data, const int32_t *csr_indices,
+                            const int64_t *csr_indptr, int64_t n, int64_t m, const float *V,
+                            int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                            int64_t n_cols, float *out, void *stream);
+int tm_csr_rmatvec_multi_f32(const float *csr_data, const int32_t *csr_indices,
+                             const int64_t *csr_indptr, int64_t n, int64_t m, const float *V,
+                             int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                             int64_t n_cols, float *out, void *stream);
+int tm_dense_matvec_multi_f32(const float *X, int64_t n, int64_t m, int order_f, const float *V,
+                              int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                              int64_t n_cols, float *out, void *stream);
+int tm_dense_rmatvec_multi_f32(const float *X, int64_t n, int64_t m, int order_f, const float *V,
+                               int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, float *out, void *stream);
+int tm_csr_matvec_multi_f64(const double *csr_data, const int32_t *csr_indices,
+                            const int64_t *csr_indptr, int64_t n, int64_t m, const double *V,
+                            int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                            int64_t n_cols, double *out, void *stream);
+int tm_csr_rmatvec_multi_f64(const double *csr_data, const int32_t *csr_indices,
+                             const int64_t *csr_indptr, int64_t n, int64_t m, const double *V,
+                             int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                             int64_t n_cols, double *out, void *stream);
+int tm_dense_matvec_multi_f64(const double *X, int64_t n, int64_t m, int order_f, const double *V,
+                              int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                              int64_t n_cols, double *out, void *stream);
+int tm_dense_rmatvec_multi_f64(const double *X, int64_t n, int64_t m, int order_f, const double *V,
+                               int64_t K, const int32_t *rows, int64_t n_rows, const int32_t *cols,
+                               int64_t n_cols, double *out, void *stream);
+
+/* =====================================================================================
  * StandardizedMatrix on device blocks (standardized_mat.py:123-230).
  * tm_vec_sum_*: out[0] = sum_i v[rows[i]] (rows == NULL: v[0..n)), accumulated in double in a
  *   fixed order (the np.sum(d[rows]) / other.sum(0) of standardized_mat.py:159,215).

@@ -224,10 +224,7 @@ class DenseMatrix(MatrixBase):
         if v_dev.ndim == 1:
             res = self._matvec_dev(v_dev, rd, cd, None, transpose)
         else:
-            cols_out = [self._matvec_dev(v_dev[:, j].contiguous(), rd, cd, None, transpose)
-                        for j in range(v_dev.shape[1])]
-            res = torch.stack(cols_out, dim=1) if cols_out else D.zeros(
-                (m if transpose else n, 0), tdt)
+            res = xd.dense_matvec_multi(self._dev(), v_dev, rd, cd, transpose)
         if not on_dev:
             res = D.to_host(res)
             if np.issubdtype(vec.dtype, np.floating) and vec.dtype != self.dtype:

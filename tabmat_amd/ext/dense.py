@@ -47,6 +47,23 @@ def dense_matvec(X: DenseDev, v, rows, cols, out=None):
     return out
 
 
+def dense_matvec_multi(X: DenseDev, V, rows, cols, transpose):
+    """2-D operand: X[rows, cols] @ V[cols] (n_rows, K) or X[rows, cols].T @ V[rows] (n_cols, K);
+    the reference leaves these to NumPy BLAS (dense_matrix.py:212-217)."""
+    K = int(V.shape[1])
+    n_cols = X.m if cols is None else D.nlen(cols)
+    n_rows = X.n if rows is None else D.nlen(rows)
+    out = D.zeros((n_cols if transpose else n_rows, K), X.dtype)
+    if K == 0 or n_rows == 0 or n_cols == 0:
+        return out
+    D.same_float("dense_matvec_multi", X.buf, V)
+    Vc = V.contiguous()
+    fn = "tm_dense_rmatvec_multi_" if transpose else "tm_dense_matvec_multi_"
+    call(fn + D.fsuf(X.buf), D.p(X.buf), X.n, X.m, X.order_f, D.p(Vc), K, D.p(rows), D.nlen(rows),
+         D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
 def transpose_square_dot_weights(X: DenseDev, weights, shift):
     """ext/dense.pyx:103-122: out[j] = sum_i w[i] * (X[i, j] - shift[j])**2."""
     out = D.zeros((X.m,), X.dtype)

@@ -65,6 +65,23 @@ def csc_rmatvec(X: CsrDev, v, rows, cols, out=None):
     return out
 
 
+def csr_matvec_multi(X: CsrDev, V, rows, cols, transpose):
+    """2-D operand (scipy.sparse products in the reference, sparse_matrix.py:252-254, 266-268):
+    X[rows, cols] @ V[cols] -> (n_rows, K), or X[rows, cols].T @ V[rows] -> (n_cols, K)."""
+    K = int(V.shape[1])
+    n_cols = X.m if cols is None else D.nlen(cols)
+    n_rows = X.n if rows is None else D.nlen(rows)
+    out = D.zeros((n_cols if transpose else n_rows, K), X.dtype)
+    if K == 0 or n_rows == 0 or n_cols == 0:
+        return out
+    D.same_float("csr_matvec_multi", X.data, V)
+    Vc = V.contiguous()
+    fn = "tm_csr_rmatvec_multi_" if transpose else "tm_csr_matvec_multi_"
+    call(fn + D.fsuf(X.data), *_csr_args(X), D.p(Vc), K, D.p(rows), D.nlen(rows), D.p(cols),
+         D.nlen(cols), D.p(out), D.stream_ptr())
+    return out
+
+
 def csr_dense_sandwich_slab(A: SlabCsc, B: DenseDev, d):
     """Fast path of ext/sparse.pyx:211-260 for an unrestricted product (B C- or F-ordered):
     slab-blocked gather kernel with static register accumulators (csrc/sparse.hip, K3)."""

@@ -38,7 +38,13 @@ class CapturedProduct:
         self._capture()
 
     def _capture(self):
-        side = torch.cuda.Stream()
+        # Warm-up and capture run on ONE private stream: the library keeps a workspace per
+        # (device, stream) and refuses to grow it during a capture, so the stream that is captured
+        # must be the one that was warmed up.  The captured launches then use that stream's
+        # workspace only -- eager products on other streams never share scratch with a replay.
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):          # builds lazy twins, grows workspace / caches
@@ -47,7 +53,7 @@ class CapturedProduct:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime meanwhile
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             out = self._fn(self._static_in)
         self._graph, self._static_out, self._gen = g, out, _ws_generation()
 

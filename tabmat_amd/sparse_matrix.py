@@ -330,9 +330,7 @@ class SparseMatrix(MatrixBase):
         if v_dev.ndim == 1:
             res = self._matvec_dev(v_dev, rd, cd, None, transpose)
         else:
-            parts = [self._matvec_dev(v_dev[:, j].contiguous(), rd, cd, None, transpose)
-                     for j in range(v_dev.shape[1])]
-            res = torch.stack(parts, dim=1) if parts else D.zeros((m if transpose else n, 0), tdt)
+            res = xs.csr_matvec_multi(self._dev(), v_dev, rd, cd, transpose)
         if not on_dev:
             res = D.to_host(res)
         if out is None:

@@ -402,8 +402,22 @@ class SplitMatrix(MatrixBase):
                         scd = None
                     mat._matvec_dev(vb, None, scd, res, False)
         else:
-            parts = [self.matvec(v_dev[:, j].contiguous(), cols) for j in range(v_dev.shape[1])]
-            res = torch.stack(parts, dim=1)
+            # 2-D operand (no categorical block here): one multi-right-hand-side launch per block
+            from .ext import dense as xd
+            from .ext import sparse as xs
+
+            res = D.zeros((self.shape[0], v_dev.shape[1]), tdt)
+            for mat, idx, sc in zip(self.matrices, idx_d, sub_cols):
+                if sc is not None and len(sc) == 0:
+                    continue
+                scd = D.idx_dev(sc)
+                if scd is not None and D.nlen(scd) == mat.shape[1]:
+                    scd = None
+                vb = v_dev[idx]
+                if isinstance(mat, DenseMatrix):
+                    res += xd.dense_matvec_multi(mat._dev(), vb, None, scd, False)
+                else:
+                    res += xs.csr_matvec_multi(mat._dev(), vb, None, scd, False)
         if not on_dev:
             res = D.to_host(res)
             if np.issubdtype(v.dtype, np.floating):
@@ -449,9 +463,22 @@ class SplitMatrix(MatrixBase):
                     part = mat._matvec_dev(v_dev, rd, scd, None, True)
                 res[pd] += part
         else:
-            parts = [self.transpose_matvec(v_dev[:, j].contiguous(), rows, cols)
-                     for j in range(v_dev.shape[1])]
-            res = torch.stack(parts, dim=1)
+            from .ext import dense as xd
+            from .ext import sparse as xs
+
+            res = D.zeros((n_cols, v_dev.shape[1]), tdt)
+            pos_d = self._full_dev_indices() if cols_n is None else self._dev_idx(pos)
+            empty_rows = rows_n is not None and len(rows_n) == 0
+            for mat, pd, sc in zip(self.matrices, pos_d, sub_cols):
+                if empty_rows or (sc is not None and len(sc) == 0):
+                    continue
+                scd = D.idx_dev(sc)
+                if scd is not None and D.nlen(scd) == mat.shape[1]:
+                    scd = None
+                if isinstance(mat, DenseMatrix):
+                    res[pd] += xd.dense_matvec_multi(mat._dev(), v_dev, rd, scd, True)
+                else:
+                    res[pd] += xs.csr_matvec_multi(mat._dev(), v_dev, rd, scd, True)
         if not on_dev:
             res = D.to_host(res)
             if np.issubdtype(v.dtype, np.floating):
