@@ -225,10 +225,13 @@ int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, con
  * j = w % 8.  A round of a (slab, group) block = 4 chunks x 32 slots, chunk c = columns j = 2c,
  * 2c + 1 of both halves, 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th
  * nonzero of column 8h + j of the slab; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding
- * (value 0).  vals / koff hold round 0 of block (slab * (m / C) + group) at slot offset block * 128;
- * slot 0 of its chunk 0 carries the number of further rounds in koff bits 24..31, which start at
- * round xptr[block] of xvals / xkoff (128 slots per round).  unconditional = 2 or 4 positions of
- * every column executed without a test.  out: (m, r), overwritten. */
+ * (value 0).  vals / koff hold round 0 of block (slab * (m / C) + group) at slot offset block * 128.
+ * Entries beyond a column's 8th of a slab are overflow ENTRIES in xkoff (16 bytes each, 16-byte
+ * aligned: value (8 bytes; float32 in the first 4), koff, column w = 8h + j of the group), block
+ * by block; the block header sits in round 0, chunk 0: koff bits 20..31 of slot 0 = number of
+ * entries of the block, bits 20..31 of slots 1..3 = 3 x 12 bits of the index of its first entry.
+ * xptr and xvals are not read by the kernel (kept in the signature).  unconditional = 2 or 4
+ * positions of every column executed without a test.  out: (m, r), overwritten. */
 int tm_lg_rows(void);
 int tm_lg_group_cols(void);
 int tm_csr_dense_sandwich_lg_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,

@@ -21,15 +21,16 @@
 //     slot  h * 16 + (j & 1) * 8 + it   =  the (8 * round + it)-th nonzero of column 8h + j
 // as {value F, koff u32}; koff = (1 + row in slab) * row bytes, 0 = padding (value 0).  Row 0 of
 // an LDS slab buffer is all zero and d[0] of its d-vector is 0, so padding needs no select.
-// Round 0 of every block sits at a fixed stride (no pointer chase in the common case); slot 0 of
-// chunk 0 carries the number of further rounds in koff bits 24..31, those live in a second pair
-// of arrays addressed through xptr (columns with more than 8 nonzeros in a slab: 0.4 % at 5 %).
+// Round 0 of every block sits at a fixed stride (no pointer chase).  A column's 9th, 10th ...
+// nonzero of a slab (0.4 % of the columns at 5 %) is an overflow ENTRY of 16 bytes {value, koff,
+// column} in a separate array; the block header -- number of entries in koff bits 20..31 of slot
+// 0 of chunk 0, index of the first in bits 20..31 of slots 1..3 -- travels with round 0, the
+// entries come in through SCALAR loads and run through the chunk code as one-entry chunks.
 // Positions of a column are compacted (nonzeros first), so "position `it` of column j is used by
 // either half" is monotone in `it`; the first LG_UNC positions run unconditionally, the rest in
 // pairs behind one scalar bit test.
 #include "common.hpp"
 #include "reduce.hpp"
-#include <stdlib.h>
 
 namespace tmh {
 
@@ -51,6 +52,34 @@ struct LgLds {
     static constexpr int TOTAL = DL_OFF + 2 * DLN * (int)sizeof(F);
 };
 
+// Buffer descriptor over [base, base + bytes): loads beyond the range return 0 (the ragged last
+// slab needs no per-lane clamping).  Device pass only; the host pass sees empty stand-ins (it only
+// needs the kernel's stub).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t lg_rsrc_t;
+__device__ __forceinline__ lg_rsrc_t lg_rsrc(const void *base, int64_t bytes) {
+    const unsigned nb = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ void lg_buf_to_lds16(lg_rsrc_t rs, void *lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff,
+                                             soff, 0, 0);
+}
+template <typename F>
+__device__ __forceinline__ F lg_buf_load(lg_rsrc_t rs, int voff) {
+    if constexpr (sizeof(F) == 8)
+        return __builtin_bit_cast(F, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+    else
+        return __builtin_bit_cast(F, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+}
+#else
+struct lg_rsrc_t {};
+inline lg_rsrc_t lg_rsrc(const void *, int64_t) { return {}; }
+inline void lg_buf_to_lds16(lg_rsrc_t, void *, int, int) {}
+template <typename F>
+inline F lg_buf_load(lg_rsrc_t, int) { return F(0); }
+#endif
+
 template <int SEL>
 __device__ __forceinline__ unsigned lg_bcast_add(unsigned k, unsigned off) {
     unsigned r;
@@ -59,23 +88,11 @@ __device__ __forceinline__ unsigned lg_bcast_add(unsigned k, unsigned off) {
         : "v"(k), "v"(off), "n"(SEL));
     return r;
 }
-#ifndef LG_ABL
-#define LG_ABL 0
-#endif
-#ifndef LG_SPREAD
-#define LG_SPREAD 1
-#endif
 template <int SEL>
 __device__ __forceinline__ void lg_fmac(double &acc, double a, double x) {
-#if LG_ABL == 1
-    asm("v_fmac_f64_e32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(x));
-#elif LG_ABL == 2
-    asm volatile("" ::"v"(x));
-#else
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
         : "+v"(acc)
         : "v"(a), "v"(x), "n"(SEL));
-#endif
 }
 template <int SEL>
 __device__ __forceinline__ void lg_fmac(float &acc, float a, float x) {
@@ -84,31 +101,31 @@ __device__ __forceinline__ void lg_fmac(float &acc, float a, float x) {
         : "v"(a), "v"(x), "n"(SEL));
 }
 
-#ifdef LG_PROF
-__device__ long long lg_prof[256 * 16 * 8];
-#define LG_T(x) const long long x = clock64()
-#define LG_ACC(i, v) pacc[i] += (v)
-#else
-#define LG_T(x)
-#define LG_ACC(i, v)
-#endif
-
+// Addressing: everything a wave touches per slab advances by a CONSTANT stride, so the kernel
+// keeps running pointers (one 64-bit add per stream and slab) and per-lane byte offsets computed
+// once.  The first version recomputed `B + min(s * 64 + row, n - 1) * r + c` and the stream index
+// with 64-bit multiplies for every 1 KiB piece and every chunk: ~300 scalar / address
+// instructions per wave and slab, 3.3 ms of the kernel's 6.1 ms with all arithmetic and all LDS
+// traffic removed (profiles/r2_k3_ablation.txt).  Only the LAST slab of the matrix can hold rows
+// beyond n; it uses clamped offsets (tail_*).
 template <typename F, int UNC>
 __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ xptr,
     const F *__restrict__ xvals, const unsigned *__restrict__ xkoff, int n_groups, int64_t n_slabs,
     int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r, int nB,
-    const F *__restrict__ d, F *__restrict__ ws, int dbg) {
+    const F *__restrict__ d, F *__restrict__ ws) {
+    const uint4 *__restrict__ xent = reinterpret_cast<const uint4 *>(xkoff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using L = LgLds<F>;
     constexpr int VEC = 16 / (int)sizeof(F);             // dense columns per 16-byte read
     constexpr int NRD = L::ROWB / 512;                    // reads per nonzero and lane (2 / 1)
     constexpr int ROWB = L::ROWB;
     constexpr int SLABB = LG_R * ROWB;
-    constexpr int NV = SLABB / 16 / LG_THREADS;           // 16-byte pieces staged per thread
+    constexpr int NV = SLABB / 16 / LG_THREADS;           // 1 KiB pieces copied per wave (4 / 2)
     constexpr int RPP = 1024 / ROWB;                       // slab rows per 1 KiB wave piece
     constexpr int LOGROW = ROWB == 1024 ? 10 : 9;
     typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,11 +133,10 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
     const bool active = group < n_groups;
     const int j0 = blockIdx.y * LG_W;
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
-    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    const int ns = (int)(min(s0 + slabs_per_block, n_slabs) - s0);   // slabs of this workgroup
     const unsigned lane_off = (unsigned)(lane & 31) * 16u;
     const int lane32 = (lane >> 5) * 16 + (lane & 15);     // the slot this lane loads
     F *dl_all = reinterpret_cast<F *>(smem_raw + L::DL_OFF);
-    typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_byte *)smem_raw;
 
     F acc[8][NRD][VEC];
@@ -136,28 +152,49 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
         reinterpret_cast<F *>(smem_raw + b * L::BUFB)[c] = F(0);
     }
     if (tid < 2) dl_all[tid * L::DLN] = F(0);
+    if (ns <= 0) return;
+
+    // ---- per-lane constants of the slab copy: piece i of this wave = 1 KiB = RPP slab rows ----
+    // B and d are read through buffer descriptors rebuilt per slab (base = the slab's first
+    // byte, range = what is left of the array): rows beyond n - 1 in the ragged last slab are out
+    // of range and read as 0 without any per-lane clamping.
+    const int cc = min(j0 + ((lane * 16) % ROWB) / (int)sizeof(F), nB - VEC);
+    // byte offset of this lane's 16 bytes inside a slab of B for piece 0; piece i lies RPP rows
+    // further (a uniform stride, added to the scalar base)
+    const int row0 = wave * NV * RPP + (lane * 16) / ROWB;
+    const unsigned boff0 = (unsigned)((row0 * r + cc) * (int64_t)sizeof(F));
+    const int64_t pstride = (int64_t)RPP * r * (int64_t)sizeof(F);
+    const int64_t bstride = (int64_t)LG_R * r * (int64_t)sizeof(F);
+    const char *bnext = reinterpret_cast<const char *>(B) + s0 * bstride;        // slab to copy next
+    int64_t bleft = n * r * (int64_t)sizeof(F) - s0 * bstride;                     // bytes from there on
+    // (uniform bases + small per-lane offsets: scalar-base addressing, no 64-bit VGPR pointers)
+    const F *dnext = d + s0 * LG_R;                                                // its d
+    int64_t dleft = (n - s0 * LG_R) * (int64_t)sizeof(F);
+    const int64_t sstride = (int64_t)n_groups * (LG_CHUNKS * LG_SLOTS);
+    const F *vnext = vals + (s0 * n_groups + group) * (int64_t)(LG_CHUNKS * LG_SLOTS);
+    const unsigned *knext = koff + (s0 * n_groups + group) * (int64_t)(LG_CHUNKS * LG_SLOTS);
 
     F dsc = F(0);
-    // async copy of B[slab rows, j0 .. j0 + 128): piece i of this wave's NV 1 KiB pieces
-    auto issue_piece = [&](int64_t s, int buf, int i) {
-        if (dbg & 1) return;
-        const int piece = wave * NV + i;
-        const int row = piece * RPP + (lane * 16) / ROWB;
-        const int c = ((lane * 16) % ROWB) / (int)sizeof(F);
-        const int64_t k = min(s * LG_R + row, n - 1);
-        const int cc = min(j0 + c, nB - VEC);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(B + k * r + cc),
-            (__attribute__((address_space(3))) void *)(smem_raw + buf * L::BUFB + ROWB + piece * 1024),
-            16, 0, 0);
+    // `which` = index of the slab inside the workgroup's range (0 .. ns - 1)
+    auto issue_piece = [&](int buf, int i) {
+        lg_buf_to_lds16(lg_rsrc(bnext, bleft), smem_raw + buf * L::BUFB + ROWB + (wave * NV + i) * 1024,
+                        (int)boff0, (int)(i * pstride));
     };
-    auto issue_slab = [&](int64_t s, int buf) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) issue_piece(s, buf, i);
-        if (tid < LG_R) dsc = d[min(s * LG_R + tid, n - 1)];
+    auto load_d = [&]() {
+        if (tid < LG_R) {
+            dsc = lg_buf_load<F>(lg_rsrc(dnext, dleft), tid * (int)sizeof(F));
+        }
     };
-    auto finish_slab = [&](int64_t s, int buf) {
-        if (tid < LG_R) dl_all[buf * L::DLN + 1 + tid] = (s * LG_R + tid < n) ? dsc : F(0);
+    auto finish_slab = [&](int buf) {
+        if (tid < LG_R) dl_all[buf * L::DLN + 1 + tid] = dsc;
+    };
+    auto advance = [&]() {                       // the "next" pointers move one slab on
+        bnext += bstride;
+        bleft -= bstride;
+        dnext += LG_R;
+        dleft -= LG_R * (int64_t)sizeof(F);
+        vnext += sstride;
+        knext += sstride;
     };
 
     // the four chunks of round 0 of the NEXT slab, requested while the current one is worked on
@@ -165,66 +202,46 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
     unsigned pk[LG_CHUNKS];
 #pragma unroll
     for (int c = 0; c < LG_CHUNKS; ++c) { pv[c] = F(0); pk[c] = 0u; }
-    auto load_chunk = [&](int64_t s, int c) {
-        if (!active || s >= s1) return;
-        if ((dbg & 2) && s > s0) return;
-        const int64_t q = ((s * n_groups + group) * LG_CHUNKS + c) * LG_SLOTS + lane32;
-        pv[c] = vals[q];
-        pk[c] = koff[q];
-    };
-    auto load_round0 = [&](int64_t s) {
-#pragma unroll
-        for (int c = 0; c < LG_CHUNKS; ++c) load_chunk(s, c);
+    auto load_chunk = [&](int c) {
+        pv[c] = vnext[c * LG_SLOTS + lane32];
+        pk[c] = knext[c * LG_SLOTS + lane32];
     };
 
-    if (s0 < s1) {
-        load_round0(s0);
-        issue_slab(s0, 0);
-        finish_slab(s0, 0);
+    // prologue: slab 0 of the range into buffer 0
+#pragma unroll
+    for (int i = 0; i < NV; ++i) issue_piece(0, i);
+    load_d();
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < LG_CHUNKS; ++c) load_chunk(c);
     }
+    advance();
+    finish_slab(0);
     __syncthreads();
-#ifdef LG_PROF
-    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    for (int64_t s = s0; s < s1; ++s) {
-        LG_T(t_top);
-        const int buf = (int)((s - s0) & 1);
-        const bool more = s + 1 < s1;
-#if LG_SPREAD == 0
-        F cv[LG_CHUNKS];
-        unsigned ck[LG_CHUNKS];
+
+    unsigned slab_base = lds_base;                // LDS address of the current buffer
+    unsigned next_base = lds_base + (unsigned)L::BUFB;
+    const F *dl = dl_all;
+    const F *dl_next = dl_all + L::DLN;
+    for (int w = 0; w < ns; ++w) {
+        const int buf = w & 1;
+        const bool more = w + 1 < ns;
+        if (more) load_d();
+        if (!active) {                  // a wave without columns still copies its share
+            if (more) {
 #pragma unroll
-        for (int c = 0; c < LG_CHUNKS; ++c) { cv[c] = pv[c]; ck[c] = pk[c]; }
-        if (more) {
-            issue_slab(s + 1, buf ^ 1);
-            load_round0(s + 1);
-        }
-#else
-        if (more && tid < LG_R) dsc = d[min((s + 1) * LG_R + tid, n - 1)];
-        if (more && !(active && !(dbg & 4))) {      // a wave without columns still copies its share
-#pragma unroll
-            for (int i = 0; i < NV; ++i) issue_piece(s + 1, buf ^ 1, i);
-        }
-#endif
-        LG_T(t_issue);
-        LG_ACC(0, t_issue - t_top);
-        if (active && !(dbg & 4)) {
-            const F *dl = dl_all + buf * L::DLN;
-            const unsigned slab_base = lds_base + (unsigned)(buf * L::BUFB);
+                for (int i = 0; i < NV; ++i) issue_piece(buf ^ 1, i);
+            }
+        } else {
             // one chunk: fold d into the values, redirect d == 0 rows to the zero row, then the
             // positions of columns j = 2c, 2c + 1 of both halves
-            auto do_chunk = [&](auto cc, F v, unsigned kraw) {
-                constexpr int c = decltype(cc)::value;
+            auto do_chunk = [&](auto cc_, F v, unsigned kraw) {
+                constexpr int c = decltype(cc_)::value;
                 const unsigned kk = kraw & LG_KMASK;
                 const unsigned long long real = __builtin_amdgcn_ballot_w64(kk != 0u);
                 const unsigned comb = ((unsigned)real | (unsigned)(real >> 32)) & 0xFFFFu;
                 if (comb == 0u) return;
-#if LG_ABL == 4
-                F dk = F(1);
-                asm volatile("" : "+v"(dk));
-#else
                 const F dk = dl[kk >> LOGROW];
-#endif
                 F a = v * dk;
                 unsigned kq = slab_base + (dk != F(0) ? kk : 0u);      // absolute LDS address
                 // DPP reads of a VGPR need two wait states after the VALU write
@@ -239,24 +256,9 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
                         const unsigned addr = lg_bcast_add<SEL>(kq, lane_off);
 #pragma unroll
                         for (int u = 0; u < NRD; ++u)
-#if LG_ABL == 3
-                        {
-                            vec_t t;
-                            asm volatile("" : "=v"(t) : "v"(addr));
-                            x[decltype(e)::value][u] = t;
-                        }
-#elif LG_ABL == 5
-                        {
-                            if (u == 0) x[decltype(e)::value][u] = *reinterpret_cast<
-                                const __attribute__((address_space(3))) vec_t *>(
-                                (lds_byte *)(uintptr_t)(addr + u * 512));
-                            else { vec_t t; asm volatile("" : "=v"(t) : "v"(addr)); x[decltype(e)::value][u] = t; }
-                        }
-#else
                             x[decltype(e)::value][u] = *reinterpret_cast<
                                 const __attribute__((address_space(3))) vec_t *>(
                                 (lds_byte *)(uintptr_t)(addr + u * 512));
-#endif
                     });
                     static_for<cnt>([&](auto e) {
                         constexpr int SEL = jl * 8 + it + decltype(e)::value;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
                 };
                 static_for<2>([&](auto jlc) {
                     constexpr int jl = decltype(jlc)::value;
+                    if (!(comb & (1u << (jl * 8)))) return;      // neither half has a nonzero here
                     positions(jlc, std::integral_constant<int, 0>{}, std::integral_constant<int, UNC>{});
                     if constexpr (UNC <= 2) {
                         if (comb & (1u << (jl * 8 + 2))) {
@@ -288,55 +291,65 @@ __global__ __launch_bounds__(LG_THREADS) void csr_dense_lg_kernel(
                     }
                 });
             };
-#if LG_SPREAD == 0
-            const int extra = __builtin_amdgcn_readfirstlane((int)(ck[0] >> 24));
-            static_for<LG_CHUNKS>([&](auto cc) { do_chunk(cc, cv[decltype(cc)::value], ck[decltype(cc)::value]); });
-#else
-            // the copy of the next slab and the loads of its chunks are issued BETWEEN the chunks
-            // of this one: issued in one burst at the top of the iteration the 16 waves queue up
-            // behind the vector-memory pipe for ~2000 cycles before any of them computes
-            const int extra = __builtin_amdgcn_readfirstlane((int)(pk[0] >> 24));
-            static_for<LG_CHUNKS>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                if (more) {
+            // Pass 0: the four chunks of round 0.  The copy of the next slab and the loads of its
+            // chunks are issued BETWEEN the chunks: issued in one burst at the top of the iteration
+            // the 16 waves queue up behind the vector-memory pipe for ~2000 cycles before any of
+            // them computes.
+            // Passes 1 .. nrec: one overflow entry each (a column's 9th, 10th ... nonzero of the
+            // slab), turned into a chunk that holds just that entry and sent through the same code.
+            // The block header travels with round 0 and the entries are fetched with SCALAR loads
+            // (first one here, at the top): a vector load at the point of use would make its
+            // s_waitcnt vmcnt(0) wait for the slab copy issued a moment earlier -- one full memory
+            // round trip in the middle of the iteration of 63 % of the workgroups (6.0 -> 4.9 ms).
+            const int nrec = __builtin_amdgcn_readlane((int)pk[0], 0) >> 20 & 0xFFF;
+            int64_t rec0 = 0;
+            uint4 e = uint4{0u, 0u, 0u, 0u};
+            if (nrec > 0) {
+                rec0 = (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[0], 1) >> 20) |
+                       (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[0], 2) >> 20) << 12 |
+                       (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[0], 3) >> 20) << 24;
+                e = xent[rec0];
+            }
+            for (int pass = 0; pass <= nrec; ++pass) {
+                if (pass > 1) e = xent[rec0 + pass - 1];     // a second entry in a block is rare
+                const int wcol = (int)(e.w & 15u);            // column 8h + j of the group
+                const int ec = (wcol & 7) >> 1;
+                const int eslot = (wcol >> 3) * 16 + (wcol & 1) * 8;   // position 0 of that column
+                F eval;
+                if constexpr (sizeof(F) == 8)
+                    eval = __builtin_bit_cast(F, ((unsigned long long)e.y << 32) | e.x);
+                else
+                    eval = __builtin_bit_cast(F, e.x);
+                static_for<LG_CHUNKS>([&](auto cc_) {
+                    constexpr int c = decltype(cc_)::value;
+                    F v;
+                    unsigned k;
+                    if (pass == 0) {
+                        if (more) {
 #pragma unroll
-                    for (int i = c * NV / LG_CHUNKS; i < (c + 1) * NV / LG_CHUNKS; ++i)
-                        issue_piece(s + 1, buf ^ 1, i);
-                }
-                const F v = pv[c];
-                const unsigned k = pk[c];
-                if (more) load_chunk(s + 1, c);
-                do_chunk(cc, v, k);
-            });
-#endif
-            if (extra > 0) {        // columns with more than 8 nonzeros in this slab: rare
-                const int64_t xb = xptr[s * n_groups + group];
-                for (int m = 0; m < extra; ++m) {
-                    const int64_t q = ((xb + m) * LG_CHUNKS) * LG_SLOTS + lane32;
-                    static_for<LG_CHUNKS>([&](auto cc) {
-                        constexpr int c = decltype(cc)::value;
-                        do_chunk(cc, xvals[q + c * LG_SLOTS], xkoff[q + c * LG_SLOTS]);
-                    });
-                }
+                            for (int i = c * NV / LG_CHUNKS; i < (c + 1) * NV / LG_CHUNKS; ++i)
+                                issue_piece(buf ^ 1, i);
+                        }
+                        v = pv[c];
+                        k = pk[c];
+                        if (more) load_chunk(c);
+                    } else {
+                        const bool hit = ec == c && lane32 == eslot;
+                        v = hit ? eval : F(0);
+                        k = hit ? e.z : 0u;
+                    }
+                    if (pass == 0 || ec == c) do_chunk(cc_, v, k);
+                });
             }
         }
-        LG_T(t_comp);
-        LG_ACC(1, t_comp - t_issue);
-        if (s + 1 < s1) finish_slab(s + 1, buf ^ 1);
-#ifdef LG_PROF
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
-#endif
-        LG_T(t_mem);
-        LG_ACC(2, t_mem - t_comp);
+        if (more) {
+            advance();
+            finish_slab(buf ^ 1);
+        }
         __syncthreads();
-        LG_T(t_bar);
-        LG_ACC(3, t_bar - t_mem);
-        LG_ACC(4, 1);
+        const unsigned tb = slab_base; slab_base = next_base; next_base = tb;
+        const F *td = dl; dl = dl_next; dl_next = td;
     }
-#ifdef LG_PROF
-    if (lane == 0 && blockIdx.x < 128 && blockIdx.z < 2)
-        for (int i = 0; i < 8; ++i) lg_prof[((blockIdx.z * 128 + blockIdx.x) * 16 + wave) * 8 + i] = pacc[i];
-#endif
     if (active) {
         // ws layout: [part][block][n_groups * LG_C kernel columns][128]
         const int h = lane >> 5;
@@ -408,7 +421,7 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(LG_THREADS),
                        lds, st, vals, koff, xptr, xvals, xkoff, n_groups, n_slabs, spb, B, n, r,
-                       (int)nB, d, ws, getenv("TM_LG_DBG") ? atoi(getenv("TM_LG_DBG")) : 0);
+                       (int)nB, d, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
@@ -422,12 +435,6 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
 }  // namespace tmh
 
 extern "C" {
-#ifdef LG_PROF
-int tm_lg_prof_fetch(long long *host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tmh::lg_prof), sizeof(long long) * 256 * 16 * 8);
-}
-#endif
-
 int tm_lg_rows(void) { return tmh::LG_R; }
 int tm_lg_group_cols(void) { return tmh::LG_C; }
 

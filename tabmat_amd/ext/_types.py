@@ -267,15 +267,20 @@ class SlabLg:
     (slab, group) block is 4 chunks of 32 slots, chunk c = columns j = 2c, 2c + 1 of both halves
     with 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th nonzero of column
     8h + j as {value, koff}; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding.  Round 0 of
-    every block lies at a fixed stride; slot 0 of chunk 0 carries the number of further rounds in
-    koff bits 24..31 and xptr[block] their position (in rounds) inside xvals / xkoff.  Built once
-    per block (ingest: one device key sort)."""
+    every block lies at a fixed stride.  Entries beyond a column's 8th of a slab (0.4 % of the
+    columns at 5 % density) are overflow ENTRIES in xkoff: 16 bytes {value (8 bytes; float32 in
+    the first 4), koff, column w = 8h + j of the group}, block by block.  The block header --
+    number of entries in koff bits 20..31 of slot 0 of chunk 0, index of the first one in bits
+    20..31 of slots 1..3 (3 x 12 bits) -- travels with round 0, so the kernel fetches the entries
+    with SCALAR loads at the top of a slab and never waits for the vector-memory pipeline (the
+    copy of the next slab) in the middle of its work.  xptr[block] (host-side view of the same
+    index) is kept for tests.  Built once per block (ingest: one device key sort)."""
 
     vals: torch.Tensor     # F[S * G * 128]
     koff: torch.Tensor     # int32[S * G * 128]
-    xptr: torch.Tensor     # int64[S * G + 1]  first extra round of every block
-    xvals: torch.Tensor    # F[X * 128]
-    xkoff: torch.Tensor    # int32[X * 128]
+    xptr: torch.Tensor     # int64[S * G + 1]  first overflow entry of every block
+    xvals: torch.Tensor    # F[1]  (unused)
+    xkoff: torch.Tensor    # int32[X * 4]  overflow entries
     inv: torch.Tensor      # int64[m]  kernel row of column c of the block
     n: int
     m: int
@@ -320,18 +325,15 @@ class SlabLg:
             torch.zeros(S * mpad, dtype=torch.int64, device=dev)
         rounds = torch.div(cnt64.view(S * G, C).max(dim=1).values + (P - 1), P, rounding_mode="floor") \
             if S else torch.zeros(0, dtype=torch.int64, device=dev)
-        extra = torch.clamp(rounds - 1, min=0)
-        xptr = torch.zeros(S * G + 1, dtype=torch.int64, device=dev)
-        if S * G:
-            torch.cumsum(extra, dim=0, out=xptr[1:])
-        n_extra = int(xptr[-1].item())
-        if S * G and max_extra is not None and int((extra > 0).sum().item()) > max_extra * S * G \
+        if S * G and max_extra is not None and int((rounds > 1).sum().item()) > max_extra * S * G \
                 and total0 > (1 << 22):
             return None
+        del rounds
         vals = torch.zeros(total0, dtype=csr.data.dtype, device=dev)
         koff = torch.zeros(total0, dtype=torch.int32, device=dev)
-        xvals = torch.zeros(max(n_extra, 1) * CH * SL, dtype=csr.data.dtype, device=dev)
-        xkoff = torch.zeros(max(n_extra, 1) * CH * SL, dtype=torch.int32, device=dev)
+        xptr = torch.zeros(S * G + 1, dtype=torch.int64, device=dev)
+        xvals = torch.zeros(1, dtype=csr.data.dtype, device=dev)       # (unused, kept for the ABI)
+        xkoff = torch.zeros(4, dtype=torch.int32, device=dev)           # overflow entries, 4 words each
         if nnz:
             rank = torch.arange(nnz, device=dev, dtype=torch.int64) - \
                 (torch.cumsum(cnt64, dim=0) - cnt64)[key_sorted]
@@ -351,15 +353,33 @@ class SlabLg:
             dst0 = (blk * CH + chunk) * SL + slot
             vals[dst0[first]] = v[first]
             koff[dst0[first]] = kv[first]
-            if n_extra:
-                later = ~first
-                dstx = ((xptr[blk[later]] + rnd[later] - 1) * CH + chunk[later]) * SL + slot[later]
-                xvals[dstx] = v[later]
-                xkoff[dstx] = kv[later]
-            del dst0, blk, slot, chunk, rnd, v, kv, first
+            later = ~first
+            if bool(later.any().item()):
+                # overflow ENTRIES: {value, koff, column} records of 16 bytes, block by block
+                # (the entries are already sorted by block)
+                nrec = torch.bincount(blk[later], minlength=S * G)
+                torch.cumsum(nrec, dim=0, out=xptr[1:])
+                ne = int(later.sum().item())
+                xent = torch.zeros((ne, 4), dtype=torch.int32, device=dev)
+                vl = v[later].contiguous()
+                if fbytes == 8:
+                    xent[:, 0:2] = vl.view(torch.int32).view(ne, 2)
+                else:
+                    xent[:, 0] = vl.view(torch.int32)
+                xent[:, 2] = kv[later]
+                xent[:, 3] = torch.remainder(key_sorted[later], C).to(torch.int32)   # (h << 3) | j
+                xkoff = xent.reshape(-1).contiguous()
+                # block header in round 0, chunk 0: slot 0 bits 20..31 = number of entries (<= 896),
+                # slots 1..3 bits 20..31 = 3 x 12 bits of the first entry's index
+                hdr = koff.view(S * G, CH * SL)
+                hdr[:, 0] |= (nrec << 20).to(torch.int32)
+                start = xptr[:-1]
+                for t in range(3):
+                    part = torch.bitwise_and(torch.bitwise_right_shift(start, 12 * t), 0xFFF)
+                    hdr[:, 1 + t] |= torch.where(nrec > 0, part << 20, torch.zeros_like(part)).to(torch.int32)
+                del nrec, xent, vl, hdr, start
+            del dst0, blk, slot, chunk, rnd, v, kv, first, later
         del cnt64, key_sorted, perm, rows
-        if S * G:
-            koff.view(S * G, CH * SL)[:, 0] |= (extra << 24).to(torch.int32)
         # 4 unconditional positions only pay with registers to spare (f32); measured at cfg4:
         # f64 unc=2 6.1 ms / unc=4 7.6 ms (spills), f32 5.3 / 5.3 ms
         return SlabLg(vals, koff, xptr, xvals, xkoff, inv, n, m, mpad, 2)

@@ -31,21 +31,32 @@ def _decode(tw: SlabLg, itemsize):
     out = []
     for blk in range(S * G):
         s, g = divmod(blk, G)
-        extra = int(koff[blk * CH * SL] >> 24)
-        streams = [(vals, koff, blk)] + [(xvals, xkoff, int(xptr[blk]) + m) for m in range(extra)]
-        assert xptr[blk + 1] - xptr[blk] == extra
-        for rnd, (vv, kk, base) in enumerate(streams):
-            for c in range(CH):
-                for slot in range(SL):
-                    q = (base * CH + c) * SL + slot
-                    k = int(kk[q]) & 0xFFFFF
-                    if k == 0:
-                        assert vv[q] == 0
-                        continue
-                    h, jl, it = slot // 16, (slot % 16) // 8, slot % 8
-                    assert k % rowb == 0
-                    row = s * R + k // rowb - 1
-                    out.append((g * C + 8 * h + 2 * c + jl, row, float(vv[q]), rnd * 8 + it))
+        base = blk * CH * SL
+        nrec = int(koff[base] >> 20)
+        assert xptr[blk + 1] - xptr[blk] == nrec
+        if nrec:
+            rec0 = int(koff[base + 1] >> 20) | int(koff[base + 2] >> 20) << 12 | int(koff[base + 3] >> 20) << 24
+            assert rec0 == xptr[blk]
+        for c in range(CH):         # round 0: four chunks at the fixed stride
+            for slot in range(SL):
+                q = (blk * CH + c) * SL + slot
+                k = int(koff[q]) & 0xFFFFF
+                if k == 0:
+                    assert vals[q] == 0
+                    continue
+                h, jl, it = slot // 16, (slot % 16) // 8, slot % 8
+                assert k % rowb == 0
+                out.append((g * C + 8 * h + 2 * c + jl, s * R + k // rowb - 1, float(vals[q]), it))
+        seen = {}
+        for t in range(nrec):       # overflow entries of the block: {value, koff, column}
+            e = xkoff[(int(xptr[blk]) + t) * 4:(int(xptr[blk]) + t) * 4 + 4]
+            val = e[:2].view(np.float64)[0] if itemsize == 8 else e[:1].view(np.float32)[0]
+            k = int(e[2]) & 0xFFFFF
+            assert k and k % rowb == 0
+            w = int(e[3]) & 15
+            pos = 8 + seen.get(w, 0)
+            seen[w] = seen.get(w, 0) + 1
+            out.append((g * C + w, s * R + k // rowb - 1, float(val), pos))
     return out
 
 
