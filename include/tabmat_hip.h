@@ -387,6 +387,23 @@ int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_
                          void *stream);
 
 /* =====================================================================================
+ * Deterministic categorical transpose_matvec / sandwich diagonal (ext/categorical.pyx:23-42 with
+ * the thread-ordered reduction of ext/cat_split_helpers-tmpl.cpp:33-38: the reference's K4a is
+ * bitwise reproducible).  perm: the rows that fall into a column, grouped by column (stable by
+ * row); every column's run is cut into blocks of tm_cat_det_block_rows() rows: bstart[n_blocks + 1]
+ * = block limits inside perm, cat_bptr[n_cols + 1] = first block of every column.
+ * out[c] (+)= sum over the column's rows of v[row], each block summed in a fixed order in double,
+ * the block sums added in order.  A row restriction is expressed through v (0 outside).
+ * ===================================================================================== */
+int tm_cat_det_block_rows(void);
+int tm_cat_transpose_matvec_det_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                    const int64_t *cat_bptr, int64_t n_cols, const float *v,
+                                    float *out, int accumulate, void *stream);
+int tm_cat_transpose_matvec_det_f64(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                    const int64_t *cat_bptr, int64_t n_cols, const double *v,
+                                    double *out, int accumulate, void *stream);
+
+/* =====================================================================================
  * Multi-right-hand-side matvec / transpose-matvec (2-D `vec`).  The reference hands these to
  * scipy.sparse (sparse_matrix.py:252-254, 266-268) and NumPy BLAS (dense_matrix.py:212-217 with
  * a 2-D operand).  V: (m, K) for matvec, (n, K) for rmatvec, row-major; out: (n_rows, K) resp.

@@ -21,6 +21,14 @@ def transpose_matvec(indices, other, n_cols, rows, cols, out, drop_first=False):
          D.p(other), D.p(rows), D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
 
 
+def transpose_matvec_det(perm, bstart, n_blocks, cat_bptr, n_cols, other, out, accumulate=True):
+    """Deterministic form of transpose_matvec_fast/_complex (ext/categorical.pyx:23-117): fixed
+    summation order per column (tm_cat_transpose_matvec_det_*)."""
+    D.same_float("transpose_matvec_det", other, out)
+    call(f"tm_cat_transpose_matvec_det_{D.fsuf(out)}", D.p(perm), D.p(bstart), int(n_blocks),
+         D.p(cat_bptr), int(n_cols), D.p(other), D.p(out), int(bool(accumulate)), D.stream_ptr())
+
+
 def matvec(indices, other, n_rows, cols, n_cols, out_vec, drop_first=False):
     """ext/categorical.pyx:128-180 (matvec_fast/_complex): out_vec[i] += other[col(i)]."""
     if cols is not None and D.nlen(cols) == 0:

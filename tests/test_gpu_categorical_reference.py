@@ -193,3 +193,48 @@ def test_cross_dense_does_not_crash(drop_first):
     assert res is not None
     want = np.bincount(indices, weights=w, minlength=K_BIG)[int(drop_first):]
     np.testing.assert_allclose(res, np.repeat(want[:, None], 10, axis=1), rtol=1e-10)
+
+
+# ---- deterministic K4a (ext/cat_split_helpers-tmpl.cpp:33-38, CHANGELOG.rst) -------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("drop_first,missing", [(False, False), (True, True)])
+def test_deterministic_transpose_matvec_is_bitwise_reproducible(dtype, drop_first, missing, monkeypatch):
+    import tabmat_amd as tm
+    import tabmat_amd.categorical_matrix as cm
+
+    rng = np.random.default_rng(3)
+    n, k = 300_000, 37
+    codes = rng.zipf(1.3, n) % k                      # skewed: long runs of one category
+    if missing:
+        codes[rng.random(n) < 0.05] = -1
+    v = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)).astype(dtype)   # order-sensitive sums
+    mat = tm.CategoricalMatrix(codes, categories=np.arange(k), drop_first=drop_first, dtype=dtype,
+                               cat_missing_method="zero" if missing else "fail")
+    want = np.zeros(k)
+    np.add.at(want, codes[codes >= 0], v[codes >= 0].astype(np.float64))
+    want = want[int(drop_first):]
+    monkeypatch.setattr(cm, "DETERMINISTIC", True)
+    runs = [mat.transpose_matvec(v) for _ in range(4)]
+    for r in runs[1:]:
+        np.testing.assert_array_equal(r, runs[0])               # bit for bit
+    tol = 1e-10 if dtype == np.float64 else 1e-3
+    assert np.abs(runs[0] - want).max() / np.abs(want).max() < tol
+    # row / column restrictions and the sandwich diagonal go through the same kernel
+    rows = np.sort(rng.choice(n, n // 3, replace=False))
+    cols = np.sort(rng.choice(mat.shape[1], 11, replace=False))
+    sel = np.zeros(n, bool)
+    sel[rows] = True
+    w2 = np.zeros(k)
+    ok = (codes >= 0) & sel
+    np.add.at(w2, codes[ok], v[ok].astype(np.float64))
+    w2 = w2[int(drop_first):][cols]
+    got = mat.transpose_matvec(v, rows, cols)
+    assert np.abs(got - w2).max() / np.abs(w2).max() < tol
+    d1 = mat.sandwich(np.abs(v)).diagonal()
+    d2 = mat.sandwich(np.abs(v)).diagonal()
+    np.testing.assert_array_equal(d1, d2)
+    # counts stay exact
+    monkeypatch.setattr(cm, "DETERMINISTIC", True)
+    ones = np.ones(n, dtype=dtype)
+    cnt = np.bincount(codes[codes >= 0], minlength=k)[int(drop_first):]
+    np.testing.assert_array_equal(mat.transpose_matvec(ones), cnt)
