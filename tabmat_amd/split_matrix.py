@@ -5,6 +5,7 @@ the block results are scattered into the float64 p x p (or length-p / length-n) 
 by tm_scatter_block -- no host round trip inside a call."""
 from __future__ import annotations
 
+import os
 import warnings
 from collections.abc import Sequence
 from typing import Optional, Union
@@ -28,6 +29,49 @@ from .util import (
     normalize_index,
     set_up_rows_or_cols,
 )
+
+
+# TABMAT_AMD_STREAMS=k (k > 1): the independent block products of one sandwich are issued on k HIP
+# streams (every stream has its own library workspace) and joined before the result is returned.
+# Measured at cfg4 (profiles/r2_microbench.txt): 17.5 ms with one stream, 18.7 / 19.2 / 18.3 ms with
+# 2 / 4 / 8 -- the big kernels cannot share a CU (each takes the whole LDS or register file), so
+# nothing overlaps but their tails, and interleaved workgroups of different kernels break the L2
+# pairing the kernels are laid out for.  Off by default; kept as the evidence for that choice.
+N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
+
+
+class _StreamFan:
+    """Round-robin side streams for independent launches; join() makes the current stream wait."""
+
+    def __init__(self, k):
+        self.k = k
+        self.i = 0
+        if k > 1:
+            self.main = torch.cuda.current_stream()
+            self.start = torch.cuda.Event()
+            self.start.record(self.main)
+            pool = getattr(_StreamFan, "_pool", None)
+            if pool is None or len(pool) < k:
+                pool = _StreamFan._pool = [torch.cuda.Stream() for _ in range(k)]
+            self.streams = pool[:k]
+            self.used = set()
+
+    def lane(self):
+        if self.k <= 1:
+            import contextlib
+
+            return contextlib.nullcontext()
+        s = self.streams[self.i % self.k]
+        self.i += 1
+        if s not in self.used:
+            s.wait_event(self.start)
+            self.used.add(s)
+        return torch.cuda.stream(s)
+
+    def join(self):
+        if self.k > 1:
+            for s in self.used:
+                self.main.wait_stream(s)
 
 
 def as_tabmat(a):
@@ -276,6 +320,25 @@ class SplitMatrix(MatrixBase):
             xtd[pd] = cs.to(torch.float64)
         return out, xtd
 
+    def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget):
+        """All categorical x `mw` cross blocks from ONE pass over `mw` (tm_multi_cat_*), stacked
+        [sum of levels, mw columns], or None when no fused kernel applies."""
+        if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_wide_ok(cats, mw._dev_c()):
+            # few enough levels for one LDS tile: one pass of 16-byte loads over the dense
+            # block, one LDS atomic per (row, categorical, 16 columns)
+            return xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
+        if isinstance(mw, DenseMatrix):
+            # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
+            # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
+            from .ext import sparse as xs
+
+            oh, inv = self._onehot_slab(cat_ids)
+            return xs.csr_dense_sandwich_slab(oh, mw._dev_c(), d_eff)[inv]
+        if (isinstance(mw, SparseMatrix) and total * 33 <= budget
+                and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
+            return xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
+        return None
+
     def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None):
         """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
         Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
@@ -286,6 +349,7 @@ class SplitMatrix(MatrixBase):
         mats = self.matrices
         empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
         done = set()
+        fan = _StreamFan(N_STREAMS)
         # ---- fused categorical cross terms: one pass over the dense / sparse block serves
         #      every categorical block (tm_multi_cat_*), instead of one pass per pair
         cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
@@ -303,48 +367,38 @@ class SplitMatrix(MatrixBase):
             for w, mw in enumerate(mats):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
-                stacked = None
-                if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_wide_ok(cats, mw._dev_c()):
-                    # few enough levels for one LDS tile: one pass of 16-byte loads over the dense
-                    # block, one LDS atomic per (row, categorical, 16 columns)
-                    stacked = xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
-                elif isinstance(mw, DenseMatrix):
-                    # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
-                    # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
-                    from .ext import sparse as xs
-
-                    oh, inv = self._onehot_slab(cat_ids)
-                    stacked = xs.csr_dense_sandwich_slab(oh, mw._dev_c(), d_eff)[inv]
-                elif (isinstance(mw, SparseMatrix) and total * 33 <= budget
-                      and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
-                    stacked = xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
-                if stacked is None:
-                    continue
-                for ci, i in enumerate(cat_ids):
-                    res = stacked[int(offs[ci]):int(offs[ci + 1])]
-                    if (colsum is not None and colsum[w] is None and not mats[i].drop_first
-                            and not mats[i]._has_missings):
-                        cs = res.sum(dim=0)           # all levels of a complete categorical
-                        colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
-                    res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
-                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
-                    done.add((min(i, w), max(i, w)))
+                with fan.lane():
+                    stacked = self._fused_cats(mw, cats, cat_ids, d_eff, rows, total, budget)
+                    if stacked is None:
+                        continue
+                    for ci, i in enumerate(cat_ids):
+                        res = stacked[int(offs[ci]):int(offs[ci + 1])]
+                        if (colsum is not None and colsum[w] is None and not mats[i].drop_first
+                                and not mats[i]._has_missings):
+                            cs = res.sum(dim=0)           # all levels of a complete categorical
+                            colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
+                        res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
+                        xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
+                        done.add((min(i, w), max(i, w)))
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
-            if isinstance(mi, CategoricalMatrix):
-                diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
-                if colsum is not None:
-                    colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
-                xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
-            else:
-                res = mi._sandwich_dev(d, rows, sub_d[i])
-                xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+            with fan.lane():
+                if isinstance(mi, CategoricalMatrix):
+                    diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
+                    if colsum is not None:
+                        colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
+                    xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
+                else:
+                    res = mi._sandwich_dev(d, rows, sub_d[i])
+                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
             for j in range(i + 1, len(mats)):
                 if empty[j] or (i, j) in done:
                     continue
-                res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
-                xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
+                with fan.lane():
+                    res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
+                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
+        fan.join()
         return out
 
     def sandwich_graph(self, d, rows=None, cols=None):
