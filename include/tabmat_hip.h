@@ -361,6 +361,19 @@ int tm_multi_cat_dense_sandwich_f64(const void *const *h_codes, const int64_t *h
                                     const int32_t *h_drop_first, int n_cats, int64_t n,
                                     const double *d, const double *M, int64_t M_ncol, int order_f,
                                     double *out, void *stream);
+/* The same with a row list (C-ordered M with 16-byte aligned rows, <= 4 categoricals, levels
+ * within one LDS tile -- else TM_EUNSUPPORTED): only rows[0 .. n_rows) of M, d and the codes are
+ * read, cost proportional to n_rows (the `for k in rows` of ext/split.pyx:32-80). */
+int tm_multi_cat_dense_sandwich_rows_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n,
+                                         const float *d, const float *M, int64_t M_ncol,
+                                         const int32_t *rows, int64_t n_rows, float *out,
+                                         void *stream);
+int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n,
+                                         const double *d, const double *M, int64_t M_ncol,
+                                         const int32_t *rows, int64_t n_rows, double *out,
+                                         void *stream);
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,
@@ -385,6 +398,31 @@ int tm_scatter_block_f32(const float *src, int64_t nr, int64_t nc, const int64_t
 int tm_scatter_block_f64(const double *src, int64_t nr, int64_t nc, const int64_t *ri,
                          const int64_t *ci, double *out, int64_t p, int mirror, int diag,
                          void *stream);
+
+/* =====================================================================================
+ * Row-restricted fast paths at a cost proportional to the number of selected rows (the reference's
+ * `for k in rows` loops: ext/sparse.pyx:46-48, ext/sparse_helpers-tmpl.cpp:67-131).  Both work on
+ * the chunk-major twin of tm_sparse_sandwich_chunked_* plus a table row_ranges[n_chunks][n_sel][2]
+ * = {start, end} of every SELECTED row (ascending row order) inside every 128-column chunk, and
+ * d_sel[n_sel] = d of those rows; rows[n_sel] = their row numbers (for the dense operand).
+ *   tm_sparse_sandwich_chunked_rows_*: out (m, m)  = A[rows]' diag(d[rows]) A[rows]
+ *   tm_csr_dense_sandwich_rows_*:      out (m, r)  = A[rows]' diag(d[rows]) B[rows]   (B C- or F-ordered)
+ * Results overwrite out.
+ * ===================================================================================== */
+int tm_sparse_sandwich_chunked_rows_f32(const float *cm_data, const int32_t *cm_indices,
+                                        const int32_t *row_ranges, int64_t n_sel, int64_t m,
+                                        int64_t nnz, const float *d_sel, float *out, void *stream);
+int tm_sparse_sandwich_chunked_rows_f64(const double *cm_data, const int32_t *cm_indices,
+                                        const int32_t *row_ranges, int64_t n_sel, int64_t m,
+                                        int64_t nnz, const double *d_sel, double *out, void *stream);
+int tm_csr_dense_sandwich_rows_f32(const float *cm_data, const int32_t *cm_indices,
+                                   const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                   const float *d_sel, int64_t n, int64_t m, const float *B, int64_t r,
+                                   int order_f, float *out, void *stream);
+int tm_csr_dense_sandwich_rows_f64(const double *cm_data, const int32_t *cm_indices,
+                                   const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                   const double *d_sel, int64_t n, int64_t m, const double *B, int64_t r,
+                                   int order_f, double *out, void *stream);
 
 /* =====================================================================================
  * Deterministic categorical transpose_matvec / sandwich diagonal (ext/categorical.pyx:23-42 with

@@ -587,7 +587,9 @@ constexpr int MCW_RS = 32;
 template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
-    int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
+    int64_t rows_per_block, F *__restrict__ ws, int64_t stride, const int32_t *__restrict__ rows) {
+    // rows != NULL: `n` is the length of the row list and every position is mapped through it
+    // (cost proportional to the list; the reference's `for k in rows`, ext/split.pyx:32-80)
     constexpr int VEC = 16 / (int)sizeof(F);
     constexpr int TJ = 16 * VEC;
     constexpr int NI = MCW_RS / 4;               // load instructions per step
@@ -617,11 +619,13 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     auto load = [&](int64_t k0, Regs &R) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int64_t k = min(k0 + 4 * i + q, n - 1);
+            const int64_t p = min(k0 + 4 * i + q, n - 1);
+            const int64_t k = rows ? (int64_t)rows[p] : p;
             R.x[i] = *reinterpret_cast<const vec_t *>(M + k * m + jc);
         }
         const int64_t k = k0 + lr;
-        const int64_t kc = min(k, n - 1);
+        const int64_t kp = min(k, n - 1);
+        const int64_t kc = rows ? (int64_t)rows[kp] : kp;
         R.dk = d[kc];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -937,13 +941,15 @@ static int make_catset(const void *const *h_codes, const int64_t *h_ncols, const
 template <typename F>
 static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncols,
                                const int32_t *h_drop, int n_cats, int64_t n, const F *d, const F *M,
-                               int64_t m, int order_f, F *out, hipStream_t st) {
+                               int64_t m, int order_f, F *out, hipStream_t st,
+                               const int32_t *rows = nullptr, int64_t n_rows = 0) {
     CatSet cs;
     int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
     if (rc) return rc;
     const int64_t total = (int64_t)cs.total * m;
     if (total == 0) return TM_OK;
     TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+    if (rows != nullptr) n = n_rows;          // positions of the row list from here on
     if (n == 0) return TM_OK;
     {
         // wide-load path: C-ordered, 16-byte aligned rows, <= 4 categoricals, tile + scratch in LDS
@@ -971,7 +977,7 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
                 prof_begin(st);
                 hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(1024), lds_w, st,
-                                   cs, d, M, n, m, rpb, ws, stride);
+                                   cs, d, M, n, m, rpb, ws, stride, rows);
                 prof_end(st);
                 TM_LAUNCH_CHECK();
                 return TM_OK;
@@ -989,6 +995,10 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
             TM_LAUNCH_CHECK();
             return TM_OK;
         }
+    }
+    if (rows != nullptr) {
+        set_error("multi_cat_dense: the row-list form needs the wide-load path");
+        return TM_EUNSUPPORTED;
     }
     int TJ = 64;
     while (TJ > 1 && sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) TJ >>= 1;
@@ -1231,6 +1241,22 @@ int tm_multi_cat_dense_sandwich_f64(const void *const *h_codes, const int64_t *h
                                     double *out, void *stream) {
     return run_multi_cat_dense<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol,
                                        order_f, out, as_stream(stream));
+}
+int tm_multi_cat_dense_sandwich_rows_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n,
+                                         const float *d, const float *M, int64_t M_ncol,
+                                         const int32_t *rows, int64_t n_rows, float *out,
+                                         void *stream) {
+    return run_multi_cat_dense<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol, 0, out,
+                                      as_stream(stream), rows, n_rows);
+}
+int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n,
+                                         const double *d, const double *M, int64_t M_ncol,
+                                         const int32_t *rows, int64_t n_rows, double *out,
+                                         void *stream) {
+    return run_multi_cat_dense<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol, 0, out,
+                                       as_stream(stream), rows, n_rows);
 }
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

@@ -427,7 +427,11 @@ template <typename F, int TS>
 __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
-    int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws) {
+    int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws, int pairs) {
+    // pairs = 1: row-restricted form.  `cptr` is then a table [nch][n][2] of {start, end} of the
+    // SELECTED rows (ascending) in every chunk, d the selected weights, n their number: the same
+    // pipeline walks a row list at a cost proportional to its length (the reference's
+    // `for k in rows`, ext/sparse.pyx:46-48) -- the host gathers the table from the chunk pointers.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
     // 1-D grid: the nch diagonal tiles come first with nb_diag workgroups each, then the
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const int lr = lane >> 3, lt = lane & 7;       // load phase: row-in-group, entry slot
     const int64_t t0 = (int64_t)blk * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
-    const int64_t pstride = n + 1;          // cptr is [nch][n + 1] (chunk-major twin)
+    const int64_t pstride = pairs ? 2 * n : n + 1;   // cptr is [nch][n + 1] (chunk-major twin)
 
     // A wave owns GROUPS of 8 consecutive rows (8 lanes per row).  Software pipeline over the
     // groups: the entry loads of a group need its chunk pointers (two dependent memory round
@@ -486,13 +490,14 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     struct Grp { int pA, nA, pB, nB; F d; F va, vb, va2, vb2; int ca, cb, ca2, cb2; };
     const int nrows = (int)(t1 - t0);                       // < 2^31 (host: rows_per_block)
     const int kmax = (int)max((int64_t)0, min(n - 1 - t0, (int64_t)0x7fffffff));
-    const int32_t *cpA = cptr + (int64_t)I * pstride + t0;
-    const int32_t *cpB = cptr + (int64_t)J * pstride + t0;
+    const int32_t *cpA = cptr + (int64_t)I * pstride + (t0 << pairs);
+    const int32_t *cpB = cptr + (int64_t)J * pstride + (t0 << pairs);
+    const int last = pairs ? 2 * nrows - 1 : nrows;          // where the range's last row ends
     const F *dW = d + t0;
     const int baseA = __builtin_amdgcn_readfirstlane(cpA[0]);
     const int baseB = __builtin_amdgcn_readfirstlane(cpB[0]);
-    const unsigned spanA1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpA[nrows]) - baseA - 1, 0);
-    const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[nrows]) - baseB - 1, 0);
+    const unsigned spanA1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpA[last]) - baseA - 1, 0);
+    const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[last]) - baseB - 1, 0);
     const F *dataA = data + min((int64_t)baseA, nnz1), *dataB = data + min((int64_t)baseB, nnz1);
     const int32_t *indA = ind + min((int64_t)baseA, nnz1), *indB = ind + min((int64_t)baseB, nnz1);
     // The whole pipeline is instantiated twice: DIAG (I == J: one list per row, loaded once, pairs
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         const int k = g + lr;
         q.valid = k < nrows;
         const unsigned kc = (unsigned)min(k, kmax);
-        const unsigned kb = kc << 2;
+        const unsigned kb = kc << (2 + pairs);
         q.d = *reinterpret_cast<const F *>(reinterpret_cast<const char *>(dW) + kc * (unsigned)sizeof(F));
         q.a0 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb);
         q.a1 = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(cpA) + kb + 4);
@@ -986,7 +991,7 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
 template <typename F>
 static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const int32_t *cptr,
                                        int64_t n, int64_t m, int64_t nnz, const F *d, F *out,
-                                       hipStream_t st) {
+                                       hipStream_t st, int pairs = 0) {
     if (m == 0) return TM_OK;
     if (n == 0 || nnz == 0) {
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(m * m), st));
@@ -1031,7 +1036,7 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nchunk * nb_diag + n_off * nb_off)),
                        dim3(K2_WAVES * 64), lds, st, data, ind, cptr, nchunk, d, n, nnz - 1, nb_diag,
-                       nb_off, (int)nblk, ws);
+                       nb_off, (int)nblk, ws, pairs);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,
@@ -2014,6 +2019,19 @@ int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_in
                                    const double *d, double *out, void *stream) {
     return tmh::run_sparse_sandwich_chunked<double>(csr_data, csr_indices, cptr, n, m, nnz, d, out,
                                                     tmh::as_stream(stream));
+}
+
+int tm_sparse_sandwich_chunked_rows_f32(const float *cm_data, const int32_t *cm_indices,
+                                        const int32_t *row_ranges, int64_t n_sel, int64_t m,
+                                        int64_t nnz, const float *d_sel, float *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<float>(cm_data, cm_indices, row_ranges, n_sel, m, nnz, d_sel,
+                                                   out, tmh::as_stream(stream), 1);
+}
+int tm_sparse_sandwich_chunked_rows_f64(const double *cm_data, const int32_t *cm_indices,
+                                        const int32_t *row_ranges, int64_t n_sel, int64_t m,
+                                        int64_t nnz, const double *d_sel, double *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<double>(cm_data, cm_indices, row_ranges, n_sel, m, nnz, d_sel,
+                                                    out, tmh::as_stream(stream), 1);
 }
 
 int tm_ellw_rows(void) { return tmh::ELLW_R; }

@@ -129,6 +129,61 @@ def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
     return out[A.inv]      # kernel rows are the density-sorted columns
 
 
+def _row_table(A: CsrDev, rows, d, as_set: bool):
+    """(cm_data, cm_ind, ranges int32 [n_chunks, n_sel, 2], rows_sorted int32, d_sel): the
+    {start, end} of every selected row in every column chunk, rows ascending (the sums do not
+    depend on the order).  as_set: a repeated row counts once -- the reference's sparse_sandwich
+    turns `rows` into a mask (ext/sparse.pyx:46-48) while its csr_dense_sandwich loops over the
+    list and counts a repeated row twice (ext/sparse_helpers-tmpl.cpp:67-131)."""
+    import weakref
+
+    import torch
+
+    cm_data, cm_ind, cptr = A.chunk_major()
+    # the table depends on `rows` only: the self sandwich and the cross term of one call share it
+    cached = getattr(A, "_row_table", None)
+    if cached is not None and cached[0]() is rows:
+        _, r64, dup, tabs = cached
+    else:
+        r64 = torch.sort(rows.to(torch.int64)).values
+        dup = bool((r64[1:] == r64[:-1]).any().item()) if r64.numel() > 1 else False
+        tabs = {}
+        A._row_table = (weakref.ref(rows), r64, dup, tabs)
+    key = bool(as_set and dup)
+    if key not in tabs:
+        rr = torch.unique_consecutive(r64) if key else r64
+        tabs[key] = (rr, torch.stack([cptr[:, rr], cptr[:, rr + 1]], dim=2).contiguous())
+    rr, ranges = tabs[key]
+    return cm_data, cm_ind, ranges, rr.to(torch.int32).contiguous(), d[rr].contiguous()
+
+
+def sparse_sandwich_rows(A: CsrDev, d, rows):
+    """A[rows]' diag(d[rows]) A[rows] at a cost proportional to len(rows) (ext/sparse.pyx:17-77
+    with its `for k in rows` loop): the chunk-major K2 pipeline on the row table."""
+    out = D.zeros((A.m, A.m), A.dtype)
+    if A.m == 0 or D.nlen(rows) == 0 or A.data.numel() == 0:
+        return out
+    D.same_float("sparse_sandwich_rows", A.data, d)
+    cm_data, cm_ind, ranges, r32, d_sel = _row_table(A, rows, d, True)
+    call(f"tm_sparse_sandwich_chunked_rows_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(ranges),
+         int(r32.numel()), A.m, int(cm_data.numel()), D.p(d_sel), D.p(out), D.stream_ptr())
+    return out
+
+
+def csr_dense_sandwich_rows(A: CsrDev, B: DenseDev, d, rows):
+    """A[rows]' diag(d[rows]) B[rows] at a cost proportional to len(rows) (ext/sparse.pyx:211-260,
+    ext/sparse_helpers-tmpl.cpp:67-131): row-list kernel with an LDS tile per column chunk."""
+    out = D.zeros((A.m, B.m), A.dtype)
+    if A.m == 0 or B.m == 0 or D.nlen(rows) == 0 or A.data.numel() == 0:
+        return out
+    D.same_float("csr_dense_sandwich_rows", A.data, B.buf, d)
+    cm_data, cm_ind, ranges, r32, d_sel = _row_table(A, rows, d, False)
+    call(f"tm_csr_dense_sandwich_rows_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(ranges),
+         int(r32.numel()), D.p(r32), D.p(d_sel), A.n, A.m, D.p(B.buf), B.m, B.order_f, D.p(out),
+         D.stream_ptr())
+    return out
+
+
 def sparse_sandwich_chunked(A: CsrDev, d):
     """Unrestricted fast path of ext/sparse.pyx:17-77 on the chunk-major twin (K2)."""
     out = D.zeros((A.m, A.m), A.dtype)

@@ -122,14 +122,21 @@ def multi_cat_dense_wide_ok(cats, mat_j: DenseDev) -> bool:
             and mat_j.buf.data_ptr() % 16 == 0 and lds <= 150 * 1024)
 
 
-def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev):
+def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev, rows=None):
     """All categorical x dense cross blocks in one pass over the dense block:
-    returns the stacked [sum(n_cols) x mat_j.m] result (ext/split.pyx:32-80, fused over cats)."""
+    returns the stacked [sum(n_cols) x mat_j.m] result (ext/split.pyx:32-80, fused over cats).
+    rows (int32 device tensor): only those rows are read (wide-load path only, see
+    multi_cat_dense_wide_ok)."""
     total = sum(int(c[1]) for c in cats)
     res = D.zeros((total, mat_j.m), mat_j.dtype)
-    if total == 0 or mat_j.m == 0 or mat_j.n == 0:
+    if total == 0 or mat_j.m == 0 or mat_j.n == 0 or (rows is not None and D.nlen(rows) == 0):
         return res
     codes, ncols, drop, n = _cat_args(cats)
+    if rows is not None:
+        D.same_float("multi_cat_dense_sandwich", mat_j.buf, d)
+        call(f"tm_multi_cat_dense_sandwich_rows_{D.fsuf(mat_j.buf)}", codes, ncols, drop, n, mat_j.n,
+             D.p(d), D.p(mat_j.buf), mat_j.m, D.p(rows), D.nlen(rows), D.p(res), D.stream_ptr())
+        return res
     D.same_float("multi_cat_dense_sandwich", mat_j.buf, d)
     call(f"tm_multi_cat_dense_sandwich_{D.fsuf(mat_j.buf)}", codes, ncols, drop, n, mat_j.n,
          D.p(d), D.p(mat_j.buf), mat_j.m, mat_j.order_f, D.p(res), D.stream_ptr())

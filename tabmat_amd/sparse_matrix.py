@@ -25,6 +25,12 @@ from .util import (
 # The interleaved-ELL twin pads every non-empty (slab, column group) to whole 64-slot iterations
 # (x1.9 .. x2.5 at 5 % density); beyond this factor the compact slab stream is used instead.
 ELL_MAX_PAD = 8.0
+# A row restriction with at most this fraction of the rows runs the row-list kernels (cost
+# proportional to len(rows)); above it the full-pass kernels with a masked d are cheaper
+# (scripts/dev/time_rows.py: break-even near one half for the self sandwich, one quarter for the
+# sparse x dense term whose row-list form pays two LDS atomics per nonzero).
+ROW_LIST_FRACTION = 0.5
+ROW_LIST_FRACTION_K3 = 0.25
 
 
 class SparseMatrix(MatrixBase):
@@ -225,6 +231,13 @@ class SparseMatrix(MatrixBase):
     def _sandwich_dev(self, d, rows, cols):
         A = self._dev()
         if A.data.numel() > 0 and A.data.numel() < 2**31 and self.shape[1] <= 128 * 32:
+            if rows is not None and 0 < D.nlen(rows) <= ROW_LIST_FRACTION * self.shape[0]:
+                # short row list: the same pipeline over the selected rows only
+                res = xs.sparse_sandwich_rows(A, d, rows)
+                if cols is not None:
+                    c64 = cols.to(torch.int64)
+                    res = res[c64][:, c64].contiguous()
+                return res
             # fast path: unrestricted chunk-pointer kernel; row restriction = masked d,
             # column restriction = sub-selection of the small result
             if rows is not None:
@@ -260,6 +273,16 @@ class SparseMatrix(MatrixBase):
                     f"np.float32. This matrix is of type {self.dtype}, B is of type "
                     f"{other.dtype}.")
             Bd = other._dev_c()
+            A = self._dev()
+            if (rows is not None and 0 < D.nlen(rows) <= ROW_LIST_FRACTION_K3 * self.shape[0]
+                    and 0 < A.data.numel() < 2**31 and self.shape[1] <= 128 * 32):
+                # short row list: row-list kernel on the chunk-major twin (cost ~ len(rows))
+                res = xs.csr_dense_sandwich_rows(A, Bd, d, rows)
+                if L_cols is not None:
+                    res = res[L_cols.to(torch.int64)]
+                if R_cols is not None:
+                    res = res[:, R_cols.to(torch.int64)]
+                return res
             if self.shape[0] > 0 and self._dev().data.numel() > 0 and (
                     rows is None or self._values_finite()):
                 # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded

@@ -320,12 +320,15 @@ class SplitMatrix(MatrixBase):
             xtd[pd] = cs.to(torch.float64)
         return out, xtd
 
-    def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget):
+    def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget, d_rows=None):
         """All categorical x `mw` cross blocks from ONE pass over `mw` (tm_multi_cat_*), stacked
         [sum of levels, mw columns], or None when no fused kernel applies."""
         if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_wide_ok(cats, mw._dev_c()):
             # few enough levels for one LDS tile: one pass of 16-byte loads over the dense
             # block, one LDS atomic per (row, categorical, 16 columns)
+            if rows is not None and D.nlen(rows) <= 0.5 * self.shape[0]:
+                # short row list: only those rows of the dense block are read
+                return xsplit.multi_cat_dense_sandwich(cats, d_rows, mw._dev_c(), rows)
             return xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
         if isinstance(mw, DenseMatrix):
             # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
@@ -368,7 +371,7 @@ class SplitMatrix(MatrixBase):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
                 with fan.lane():
-                    stacked = self._fused_cats(mw, cats, cat_ids, d_eff, rows, total, budget)
+                    stacked = self._fused_cats(mw, cats, cat_ids, d_eff, rows, total, budget, d)
                     if stacked is None:
                         continue
                     for ci, i in enumerate(cat_ids):
