@@ -108,3 +108,43 @@ def test_row_restriction_costs_what_its_rows_cost():
     ref = X._sandwich_dev(dm, None, None)
     got = X._sandwich_dev(d, rows, None)
     assert float((got - ref).abs().max() / ref.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("frac", [0.7, 0.1])
+def test_excluded_rows_may_hold_inf_and_nan(frac):
+    """A row restriction never touches the excluded rows in the reference; here the full-pass
+    kernels see them with d = 0 (masked d) and must contribute exactly 0, not inf * 0 = NaN --
+    in every block kind, for the masked paths (frac 0.7) and the row-list paths (frac 0.1)."""
+    import tabmat_amd as tm
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(8)
+    n = 30_000
+    rows = np.sort(rng.choice(n, int(n * frac), replace=False))
+    excl = np.setdiff1d(np.arange(n), rows)
+    bad = excl[rng.integers(0, len(excl), 500)]
+    X = rng.standard_normal((n, 70))
+    X[bad[:250], rng.integers(0, 70, 250)] = np.inf
+    X[bad[250:], rng.integers(0, 70, 250)] = np.nan
+    S = sps.random(n, 140, density=0.06, format="csr", random_state=rng, dtype=np.float64)
+    S.data -= 0.5
+    lo = S.indptr[bad[::2]]
+    has = S.indptr[bad[::2] + 1] > lo
+    S.data[lo[has]] = np.inf                     # stored inf / nan in excluded rows of the sparse block
+    lo = S.indptr[bad[1::2]]
+    has = S.indptr[bad[1::2] + 1] > lo
+    S.data[lo[has]] = np.nan
+    codes = rng.integers(0, 9, n)
+    mat = tm.SplitMatrix([tm.DenseMatrix(X), tm.SparseMatrix(S.tocsc()), tm.CategoricalMatrix(codes)])
+    d = rng.random(n)
+    got = mat.sandwich(d, rows)
+    assert np.isfinite(got).all()
+    Xc, Sc = X.copy(), S.copy()
+    Xc[excl] = 0.0
+    Sc.data[~np.isfinite(Sc.data)] = 0.0
+    ref = tm.SplitMatrix([tm.DenseMatrix(Xc), tm.SparseMatrix(Sc.tocsc()), tm.CategoricalMatrix(codes)])
+    want = ref.sandwich(d, rows)
+    assert rel_err(got, want) < 1e-10
+    w = rng.standard_normal(n)
+    gt = mat.transpose_matvec(w, rows)
+    assert np.isfinite(gt).all() and rel_err(gt, ref.transpose_matvec(w, rows)) < 1e-10
