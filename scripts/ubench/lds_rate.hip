@@ -9,7 +9,7 @@
 #include <stdio.h>
 #include <vector>
 
-template <int WB, int PAT, int K>
+template <int WB, int PAT, int K, int HALF = 0>
 __global__ __launch_bounds__(1024) void krate(unsigned *out, int reps, long long *cyc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,7 +33,16 @@ __global__ __launch_bounds__(1024) void krate(unsigned *out, int reps, long long
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             u4 x[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(x[k]) : "v"(a[k]));
+            for (int k = 0; k < K; ++k) {
+                // HALF 1: only lanes 0-31 execute the read; HALF 2: halves alternate
+                if constexpr (HALF == 0) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(x[k]) : "v"(a[k]));
+                } else {
+                    const unsigned long long m = (HALF == 2 && (k & 1)) ? 0xFFFFFFFF00000000ull : 0xFFFFFFFFull;
+                    asm volatile("s_mov_b64 exec, %2\n\tds_read_b128 %0, %1\n\ts_mov_b64 exec, -1"
+                                 : "=v"(x[k]) : "v"(a[k]), "s"(m));
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)");
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" ::"v"(x[k]));
@@ -62,12 +71,12 @@ __global__ __launch_bounds__(1024) void krate(unsigned *out, int reps, long long
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int WB, int PAT, int K>
+template <int WB, int PAT, int K, int HALF = 0>
 void run(const char *name, int nw, unsigned *out, long long *cyc) {
     const int reps = 20000 / K;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    auto kern = krate<WB, PAT, K>;
+    auto kern = krate<WB, PAT, K, HALF>;
     hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
     hipLaunchKernelGGL(kern, dim3(256), dim3(nw * 64), 66 * 1024, 0, out, 10, cyc);
     hipEventRecord(a);
@@ -97,5 +106,8 @@ int main() {
     run<16, 0, 4>("b128 one row / wave", 16, out, cyc);
     run<16, 0, 16>("b128 one row / wave", 16, out, cyc);
     run<16, 1, 4>("b128 two rows (halves)", 16, out, cyc);
+    run<16, 1, 8, 1>("b128 halves, exec = lanes 0-31", 16, out, cyc);
+    run<16, 1, 8, 2>("b128 halves, exec alternates", 16, out, cyc);
+    run<16, 1, 8, 1>("b128 halves, exec = lanes 0-31", 8, out, cyc);
     return 0;
 }
