@@ -224,8 +224,8 @@ int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, con
  * (m a multiple of C); column w of a group belongs to wave half h = w / 8 and is the half's column
  * j = w % 8.  A round of a (slab, group) block = 4 chunks x 32 slots, chunk c = columns j = 2c,
  * 2c + 1 of both halves, 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th
- * nonzero of column 8h + j of the slab; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding
- * (value 0).  vals / koff hold round 0 of block (slab * (m / C) + group) at slot offset block * 128.
+ * nonzero of column 8h + j of the slab; koff = (1 + row in slab) * tm_lg_row_bytes(sizeof(F))
+ * (the row stride of the kernel's LDS slab: 1152 for f64, 512 for f32), 0 = padding (value 0).  vals / koff hold round 0 of block (slab * (m / C) + group) at slot offset block * 128.
  * Entries beyond a column's 8th of a slab are overflow ENTRIES in xkoff (16 bytes each, 16-byte
  * aligned: value (8 bytes; float32 in the first 4), koff, column w = 8h + j of the group), block
  * by block; the block header sits in round 0, chunk 0: koff bits 20..31 of slot 0 = number of
@@ -234,6 +234,7 @@ int tm_csr_dense_sandwich_ellw_f64(const double *vals, const uint32_t *koff, con
  * positions of every column executed without a test.  out: (m, r), overwritten. */
 int tm_lg_rows(void);
 int tm_lg_group_cols(void);
+int tm_lg_row_bytes(int elem_size);
 int tm_csr_dense_sandwich_lg_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,
                                  const float *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
                                  const float *B, int64_t r, const float *d, int unconditional,
@@ -242,6 +243,16 @@ int tm_csr_dense_sandwich_lg_f64(const double *vals, const uint32_t *koff, const
                                  const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
                                  const double *B, int64_t r, const double *d, int unconditional,
                                  double *out, void *stream);
+
+/* The same pass fused with the dense self sandwich (ext/dense.pyx:19-44 dense_sandwich ->
+ * ext/dense_helpers-tmpl.cpp:266-311): B must be exactly 128 columns wide (row stride 128), C-ordered
+ * and 16-byte aligned, A must have more than 256 columns (m > 256, a multiple of 16).  out: (m, 128)
+ * = A^T diag(d) B as above; out_self: (128, 128) = B^T diag(d) B, both triangles, overwritten.
+ * The dense block is read ONCE for both products; the self sandwich runs on the matrix cores in the
+ * gaps of the gather (csrc/sparse_lg.hip).  All rows take part (no row restriction). */
+int tm_csr_dense_sandwich_lg_syrk_f64(const double *vals, const uint32_t *koff, const uint32_t *xkoff,
+                                      int64_t n, int64_t m, const double *B, const double *d,
+                                      double *out, double *out_self, void *stream);
 
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */

@@ -266,7 +266,7 @@ class SlabLg:
     of a group belongs to wave half h = w // 8 and is the half's column j = w % 8.  A round of a
     (slab, group) block is 4 chunks of 32 slots, chunk c = columns j = 2c, 2c + 1 of both halves
     with 8 positions each: slot h*16 + (j&1)*8 + it = the (8*round + it)-th nonzero of column
-    8h + j as {value, koff}; koff = (1 + row in slab) * 128 * sizeof(F), 0 = padding.  Round 0 of
+    8h + j as {value, koff}; koff = (1 + row in slab) * tm_lg_row_bytes(sizeof(F)), 0 = padding.  Round 0 of
     every block lies at a fixed stride.  Entries beyond a column's 8th of a slab (0.4 % of the
     columns at 5 % density) are overflow ENTRIES in xkoff: 16 bytes {value (8 bytes; float32 in
     the first 4), koff, column w = 8h + j of the group}, block by block.  The block header --
@@ -346,7 +346,7 @@ class SlabLg:
             rnd = torch.div(rank, P, rounding_mode="floor")
             del rank, w, j
             rloc = rows[perm] - torch.div(key_sorted, mpad, rounding_mode="floor") * R
-            kv = ((rloc + 1) * (W * fbytes)).to(torch.int32)
+            kv = ((rloc + 1) * int(lib().tm_lg_row_bytes(fbytes))).to(torch.int32)
             del rloc
             v = csr.data[perm]
             first = rnd == 0

@@ -129,6 +129,32 @@ def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
     return out[A.inv]      # kernel rows are the density-sorted columns
 
 
+def lg_syrk_supported(A: SlabLg, B: DenseDev) -> bool:
+    """The fused sparse x dense + dense self sandwich needs float64, a C-ordered dense block of
+    exactly 128 columns and more than 256 (padded) sparse columns (tabmat_hip.h)."""
+    import torch
+
+    return (A is not None and A.vals.dtype == torch.float64 and B.buf.dtype == torch.float64
+            and B.m == 128 and A.mk > 256 and ell_supported(B))
+
+
+def csr_dense_sandwich_lg_syrk(A: SlabLg, B: DenseDev, d):
+    """ONE pass over the dense block for two blocks of the split sandwich: returns
+    (A^T diag(d) B  (m, 128),  B^T diag(d) B  (128, 128)).  Replaces csr_dense_sandwich
+    (ext/sparse.pyx:211-260) + dense_sandwich (ext/dense.pyx:19-44) of the same row weights; the
+    self sandwich runs on the matrix cores inside the gather kernel (csrc/sparse_lg.hip)."""
+    import torch
+
+    assert B.n == A.n and lg_syrk_supported(A, B)
+    D.same_float("csr_dense_sandwich_lg_syrk", A.vals, B.buf, d)
+    out = D.zeros((A.mk, 128), torch.float64)
+    out_self = D.zeros((128, 128), torch.float64)
+    if A.n:
+        call("tm_csr_dense_sandwich_lg_syrk_f64", D.p(A.vals), D.p(A.koff), D.p(A.xkoff), A.n, A.mk,
+             D.p(B.buf), D.p(d), D.p(out), D.p(out_self), D.stream_ptr())
+    return out[A.inv], out_self
+
+
 def _row_table(A: CsrDev, rows, d, as_set: bool):
     """(cm_data, cm_ind, ranges int32 [n_chunks, n_sel, 2], rows_sorted int32, d_sel): the
     {start, end} of every selected row in every column chunk, rows ascending (the sums do not

@@ -38,6 +38,11 @@ from .util import (
 # nothing overlaps but their tails, and interleaved workgroups of different kernels break the L2
 # pairing the kernels are laid out for.  Off by default; kept as the evidence for that choice.
 N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
+# One pass over the dense block for the sparse x dense cross term AND the dense self sandwich
+# (tm_csr_dense_sandwich_lg_syrk_f64).  Off by default: measured SLOWER than the two kernels
+# (9.4 vs 9.1 ms at cfg4) -- the f64 MFMAs and the gather's f64 FMAs share the DP pipe, the
+# matrix work does not hide in the gather's LDS waits.
+FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
 
 
 class _StreamFan:
@@ -383,11 +388,33 @@ class SplitMatrix(MatrixBase):
                         res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
                         xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                         done.add((min(i, w), max(i, w)))
+        self_done = set()
+        if FUSE_SYRK and rows is None and d.dtype == torch.float64:
+            from .ext import sparse as xs
+            for i, mi in enumerate(mats):
+                if not (isinstance(mi, DenseMatrix) and sub_d[i] is None and i not in self_done):
+                    continue
+                for j, mj in enumerate(mats):
+                    if not (isinstance(mj, SparseMatrix) and sub_d[j] is None) \
+                            or (min(i, j), max(i, j)) in done:
+                        continue
+                    Bd = mi._dev_c()
+                    lg = mj._lg() if Bd is not None else None
+                    if lg is None or not xs.lg_syrk_supported(lg, Bd):
+                        continue
+                    cross, selfb = xs.csr_dense_sandwich_lg_syrk(lg, Bd, d)     # (sparse, dense)
+                    xsplit.scatter_block(cross.contiguous(), pos_d[j], pos_d[i], out, mirror=True)
+                    xsplit.scatter_block(selfb, pos_d[i], pos_d[i], out)
+                    done.add((min(i, j), max(i, j)))
+                    self_done.add(i)
+                    break
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
             with fan.lane():
-                if isinstance(mi, CategoricalMatrix):
+                if i in self_done:
+                    pass
+                elif isinstance(mi, CategoricalMatrix):
                     diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
                     if colsum is not None:
                         colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
