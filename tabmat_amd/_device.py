@@ -6,6 +6,8 @@ from __future__ import annotations
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -102,4 +104,16 @@ def zeros(shape, dtype) -> torch.Tensor:
 
 
 def empty(shape, dtype) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=require_gpu())
+
+
+# Result buffer of an entry point that OVERWRITES its output (the *_sandwich family): no fill
+# launch.  TABMAT_AMD_POISON=1 fills it with NaN instead, so that the test-suite proves that every
+# element is written by the kernels.
+POISON = os.environ.get("TABMAT_AMD_POISON", "0") == "1"
+
+
+def out_buf(shape, dtype) -> torch.Tensor:
+    if POISON:
+        return torch.full(shape, float("nan"), dtype=dtype, device=require_gpu())
     return torch.empty(shape, dtype=dtype, device=require_gpu())

@@ -948,9 +948,11 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     if (rc) return rc;
     const int64_t total = (int64_t)cs.total * m;
     if (total == 0) return TM_OK;
-    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
     if (rows != nullptr) n = n_rows;          // positions of the row list from here on
-    if (n == 0) return TM_OK;
+    if (n == 0) {                             // (otherwise the untile kernel writes every element)
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
     {
         // wide-load path: C-ordered, 16-byte aligned rows, <= 4 categoricals, tile + scratch in LDS
         constexpr int VEC = 16 / (int)sizeof(F);
@@ -1073,8 +1075,10 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     if (rc) return rc;
     const int64_t total = (int64_t)cs.total * m;
     if (total == 0) return TM_OK;
-    TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
-    if (n == 0) return TM_OK;
+    if (n == 0) {                             // (otherwise the untile kernel writes every element)
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
     const int64_t stride = (int64_t)cs.total * group_cols;
     const size_t tile_bytes = ((sizeof(F) * (size_t)cs.total * (group_cols + 1) + 15) / 16) * 16;
     if (tile_bytes > HIST_LDS_MAX) {

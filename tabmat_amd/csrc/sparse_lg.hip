@@ -85,6 +85,16 @@ template <typename F>
 inline F lg_buf_load(lg_rsrc_t, int) { return F(0); }
 #endif
 
+// Which of a wave's NV copy pieces are issued before chunk cq of NCQ: spread over the first
+// LG_FRONT chunks of the iteration (the copy must have landed at the barrier that ends it).
+#ifndef LG_FRONT
+#define LG_FRONT 4
+#endif
+constexpr int lg_piece_lo(int cq, int nv, int ncq) {
+    const int f = LG_FRONT < ncq ? LG_FRONT : ncq;
+    return cq >= f ? nv : cq * nv / f;
+}
+
 template <int SEL>
 __device__ __forceinline__ unsigned lg_bcast_add(unsigned k, unsigned off) {
     unsigned r;
@@ -437,7 +447,8 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                 constexpr int NCQ = NG * LG_CHUNKS;
                 if (more) {
 #pragma unroll
-                    for (int i = cq * NV / NCQ; i < (cq + 1) * NV / NCQ; ++i) issue_piece(buf ^ 1, i);
+                    for (int i = lg_piece_lo(cq, NV, NCQ); i < lg_piece_lo(cq + 1, NV, NCQ); ++i)
+                        issue_piece(buf ^ 1, i);
                 }
                 v = pv[q][c];
                 k = pk[q][c];

@@ -10,9 +10,9 @@ def dense_sandwich(X: DenseDev, d, rows, cols):
     """ext/dense.pyx:19-44.  rows/cols: int32 device tensors or None (= all)."""
     out_m = X.m if cols is None else D.nlen(cols)
     in_n = X.n if rows is None else D.nlen(rows)
-    out = D.zeros((out_m, out_m), X.dtype)
     if in_n == 0 or out_m == 0:  # ext/dense.pyx:26-27
-        return out
+        return D.zeros((out_m, out_m), X.dtype)
+    out = D.out_buf((out_m, out_m), X.dtype)
     D.same_float("dense_sandwich", X.buf, d)
     call(f"tm_dense_sandwich_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(d), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())

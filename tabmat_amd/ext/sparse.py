@@ -121,7 +121,7 @@ def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
     assert B.n == A.n and ell_supported(B)
     if A.m == 0 or B.m == 0 or A.n == 0:
         return D.zeros((A.m, B.m), A.vals.dtype)
-    out = D.zeros((A.mk, B.m), A.vals.dtype)
+    out = D.out_buf((A.mk, B.m), A.vals.dtype)
     D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
     call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
          D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d),
@@ -147,8 +147,10 @@ def csr_dense_sandwich_lg_syrk(A: SlabLg, B: DenseDev, d):
 
     assert B.n == A.n and lg_syrk_supported(A, B)
     D.same_float("csr_dense_sandwich_lg_syrk", A.vals, B.buf, d)
-    out = D.zeros((A.mk, 128), torch.float64)
-    out_self = D.zeros((128, 128), torch.float64)
+    if not A.n:
+        return D.zeros((A.m, 128), torch.float64), D.zeros((128, 128), torch.float64)
+    out = D.out_buf((A.mk, 128), torch.float64)
+    out_self = D.out_buf((128, 128), torch.float64)
     if A.n:
         call("tm_csr_dense_sandwich_lg_syrk_f64", D.p(A.vals), D.p(A.koff), D.p(A.xkoff), A.n, A.mk,
              D.p(B.buf), D.p(d), D.p(out), D.p(out_self), D.stream_ptr())
@@ -212,9 +214,9 @@ def csr_dense_sandwich_rows(A: CsrDev, B: DenseDev, d, rows):
 
 def sparse_sandwich_chunked(A: CsrDev, d):
     """Unrestricted fast path of ext/sparse.pyx:17-77 on the chunk-major twin (K2)."""
-    out = D.zeros((A.m, A.m), A.dtype)
     if A.m == 0 or A.n == 0:
-        return out
+        return D.zeros((A.m, A.m), A.dtype)
+    out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_chunked", A.data, d)
     cm_data, cm_ind, cptr = A.chunk_major()
     call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr),

@@ -27,9 +27,9 @@ def sandwich_cat_dense(i_indices, i_ncol, d, mat_j: DenseDev, rows, j_cols, drop
 def sandwich_cat_cat(i_indices, j_indices, i_ncol, j_ncol, d, rows, i_drop_first=False,
                      j_drop_first=False):
     """ext/split.pyx:83-111."""
-    res = D.zeros((i_ncol, j_ncol), d.dtype)
     if i_ncol == 0 or j_ncol == 0 or (rows is not None and D.nlen(rows) == 0):
-        return res
+        return D.zeros((i_ncol, j_ncol), d.dtype)
+    res = D.out_buf((i_ncol, j_ncol), d.dtype)
     call(f"tm_cat_cat_sandwich_{D.fsuf(d)}", D.p(i_indices), D.p(j_indices), i_indices.numel(),
          D.p(d), D.p(rows), D.nlen(rows), i_ncol, j_ncol, int(i_drop_first), int(j_drop_first),
          D.p(res), D.stream_ptr())
@@ -128,9 +128,9 @@ def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev, rows=None):
     rows (int32 device tensor): only those rows are read (wide-load path only, see
     multi_cat_dense_wide_ok)."""
     total = sum(int(c[1]) for c in cats)
-    res = D.zeros((total, mat_j.m), mat_j.dtype)
     if total == 0 or mat_j.m == 0 or mat_j.n == 0 or (rows is not None and D.nlen(rows) == 0):
-        return res
+        return D.zeros((total, mat_j.m), mat_j.dtype)
+    res = D.out_buf((total, mat_j.m), mat_j.dtype)
     codes, ncols, drop, n = _cat_args(cats)
     if rows is not None:
         D.same_float("multi_cat_dense_sandwich", mat_j.buf, d)
@@ -147,9 +147,9 @@ def multi_cat_sparse_sandwich(cats, d, S: SlabCsc):
     """All categorical x sparse cross blocks in one pass over the slab-form sparse block:
     stacked [sum(n_cols) x S.m] (the scipy product of categorical_matrix.py:825-838, fused)."""
     total = sum(int(c[1]) for c in cats)
-    res = D.zeros((total, S.m), S.vals.dtype)
     if total == 0 or S.m == 0 or S.n == 0:
-        return res
+        return D.zeros((total, S.m), S.vals.dtype)
+    res = D.out_buf((total, S.m), S.vals.dtype)
     codes, ncols, drop, n = _cat_args(cats)
     D.same_float("multi_cat_sparse_sandwich", S.vals, d)
     call(f"tm_multi_cat_sparse_sandwich_slab_{D.fsuf(S.vals)}", codes, ncols, drop, n, S.n, D.p(d),
