@@ -60,12 +60,12 @@ __global__ __launch_bounds__(1024) void hist_lds_kernel(
     int drop_j, int i_ncol, int j_ncol, int ti, const int32_t *__restrict__ col_map,
     F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *bins = reinterpret_cast<F *>(smem_raw);
+    lds_acc_t *bins = reinterpret_cast<lds_acc_t *>(smem_raw);      // doubles (common.hpp)
     const int part = blockIdx.y;
     const int i0 = part * ti;
     const int i1 = min(i0 + ti, i_ncol);
     const int nbins = TWO ? (i1 - i0) * j_ncol : (i1 - i0);
-    for (int b = threadIdx.x; b < nbins; b += blockDim.x) bins[b] = F(0);
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) bins[b] = 0.0;
     __syncthreads();
 
     const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void hist_lds_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = cc[e] - drop_i;
-                if (c >= i0 && c < i1 && !(col_map && col_map[c] < 0)) atomic_add(&bins[c - i0], ww[e]);
+                if (c >= i0 && c < i1 && !(col_map && col_map[c] < 0)) atomic_add(&bins[c - i0], (lds_acc_t)ww[e]);
             }
         }
         tbeg = t0 + nvec * 4;
@@ -98,15 +98,15 @@ __global__ __launch_bounds__(1024) void hist_lds_kernel(
         if (TWO) {
             const int c2 = cj[k] - drop_j;
             if (c2 < 0) continue;
-            atomic_add(&bins[(c - i0) * j_ncol + c2], w[k]);
+            atomic_add(&bins[(c - i0) * j_ncol + c2], (lds_acc_t)w[k]);
         } else {
             if (col_map && col_map[c] < 0) continue;
-            atomic_add(&bins[c - i0], w[k]);
+            atomic_add(&bins[c - i0], (lds_acc_t)w[k]);
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nbins; b += blockDim.x) dst[b] = bins[b];
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) dst[b] = (F)bins[b];
 }
 
 // Fallback when one category row of bins does not fit LDS: global atomics into `out`.
@@ -142,7 +142,7 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     if (total == 0) return TM_OK;
     if (!accumulate) TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
     if (n_iter == 0) return TM_OK;
-    const size_t row_bytes = sizeof(F) * (size_t)(TWO ? j_ncol : 1);
+    const size_t row_bytes = sizeof(lds_acc_t) * (size_t)(TWO ? j_ncol : 1);
     if (row_bytes > HIST_LDS_MAX || i_ncol > (int64_t)INT32_MAX / (TWO ? j_ncol : 1)) {
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256 * 4), 2048);
         hipLaunchKernelGGL((hist_global_kernel<F, TWO>), dim3((unsigned)nblk), dim3(256), 0, st, ci,
@@ -161,7 +161,7 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     }
     ti = ceil_div(i_ncol, n_parts);  // balance the parts
     const int64_t stride = ti * (TWO ? j_ncol : 1);
-    const size_t lds = (size_t)stride * sizeof(F);
+    const size_t lds = (size_t)stride * sizeof(lds_acc_t);
     const int threads = lds > 64 * 1024 ? 1024 : 512;
     const int blocks_per_cu = lds > 64 * 1024 ? 1 : 2;
     int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / n_parts);
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(256) void cat_dense_kernel(
     const F *__restrict__ M, int64_t M_nrow, int64_t M_ncol, const int32_t *__restrict__ j_cols,
     int n_j, F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);
     const int part = blockIdx.y;
     const int i0 = part * ti;
     const int i1 = min(i0 + ti, i_ncol);
     const int nel = (i1 - i0) * n_j;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256) void cat_dense_kernel(
         }
         if (ORDER_F) {
             if (c >= 0) {
-                F *trow = tile + (c - i0) * n_j;
+                lds_acc_t *trow = tile + (c - i0) * n_j;
                 for (int jc = 0; jc < n_j; ++jc) {
                     const int64_t j = j_cols ? (int64_t)j_cols[jc] : jc;
-                    atomic_add(&trow[jc], dk * M[j * M_nrow + k]);
+                    atomic_add(&trow[jc], (lds_acc_t)(dk * M[j * M_nrow + k]));
                 }
             }
         } else {
@@ -258,17 +258,17 @@ __global__ __launch_bounds__(256) void cat_dense_kernel(
                 const int cc = __shfl(c, src, 64);
                 const F dd = __shfl(dk, src, 64);
                 const F *mrow = M + kk * M_ncol;
-                F *trow = tile + (cc - i0) * n_j;
+                lds_acc_t *trow = tile + (cc - i0) * n_j;
                 for (int jc = lane; jc < n_j; jc += 64) {
                     const int64_t j = j_cols ? (int64_t)j_cols[jc] : jc;
-                    atomic_add(&trow[jc], dd * mrow[j]);
+                    atomic_add(&trow[jc], (lds_acc_t)(dd * mrow[j]));
                 }
             }
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -283,12 +283,12 @@ __global__ __launch_bounds__(256) void cat_sparse_kernel(
     const int64_t *__restrict__ sptr, const int32_t *__restrict__ col_map, int n_out_cols,
     F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);
     const int part = blockIdx.y;
     const int i0 = part * ti;
     const int i1 = min(i0 + ti, i_ncol);
     const int nel = (i1 - i0) * n_out_cols;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
     constexpr int RPS = 64 / G;  // rows per wave step
@@ -331,19 +331,19 @@ __global__ __launch_bounds__(256) void cat_sparse_kernel(
             const int cc = __shfl(c, srcl, 64);
             const F dd = __shfl(dk, srcl, 64);
             if (src >= 0) {
-                F *trow = tile + (cc - i0) * n_out_cols;
+                lds_acc_t *trow = tile + (cc - i0) * n_out_cols;
                 const int64_t p1 = sptr[kk + 1];
                 for (int64_t p = sptr[kk] + sl; p < p1; p += G) {
                     const int j = sind[p];
                     const int oc = col_map ? col_map[j] : j;
-                    if (oc >= 0) atomic_add(&trow[oc], dd * sdata[p]);
+                    if (oc >= 0) atomic_add(&trow[oc], (lds_acc_t)(dd * sdata[p]));
                 }
             }
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // common launch geometry for the LDS-tile kernels: returns parts / blocks / strides
@@ -380,7 +380,7 @@ static int run_cat_dense(const int32_t *codes, int64_t n, int64_t i_ncol, int dr
     const int64_t n_iter = rows ? n_rows : n;
     if (n_iter == 0) return TM_OK;
     TilePlan p;
-    if (!plan_tile(i_ncol, n_j, sizeof(F), n_iter, 1024, &p)) {
+    if (!plan_tile(i_ncol, n_j, sizeof(lds_acc_t), n_iter, 1024, &p)) {
         set_error("cat_dense_sandwich: %lld selected dense columns exceed the LDS tile",
                   (long long)n_j);
         return TM_EUNSUPPORTED;
@@ -415,7 +415,7 @@ static int run_cat_sparse(const int32_t *codes, int64_t n, int64_t i_ncol, int d
     const int64_t n_iter = rows ? n_rows : n;
     if (n_iter == 0) return TM_OK;
     TilePlan p;
-    if (!plan_tile(i_ncol, n_out, sizeof(F), n_iter, 1024, &p)) {
+    if (!plan_tile(i_ncol, n_out, sizeof(lds_acc_t), n_iter, 1024, &p)) {
         set_error("cat_sparse_sandwich: %lld selected sparse columns exceed the LDS tile",
                   (long long)n_out);
         return TM_EUNSUPPORTED;
@@ -519,9 +519,9 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
     int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][TJ]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][TJ]
     const int nel = cs.total * TJ;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
     constexpr int RPW = 64 / TJ;
     constexpr int UNR = 4;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
 #pragma unroll
                 for (int c = 0; c < NCC; ++c)
                     if (jok && cc[u][c] >= 0)
-                        atomic_add(&tile[(cs.off[c] + cc[u][c]) * TJ + jl], x[u]);
+                        atomic_add(&tile[(cs.off[c] + cc[u][c]) * TJ + jl], (lds_acc_t)x[u]);
         } else {
 #pragma unroll 1
             for (int c = 0; c < cs.n_cats; ++c) {
@@ -561,14 +561,14 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
                 for (int u = 0; u < UNR; ++u) {
                     const int64_t k = k0 + u * step;
                     const int c1 = k < t1 ? cs.codes[c][k] - cs.drop[c] : -1;
-                    if (jok && c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * TJ + jl], x[u]);
+                    if (jok && c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * TJ + jl], (lds_acc_t)x[u]);
                 }
             }
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // C-ordered dense, wide loads (the fast path for aligned operands and <= 4 categoricals):
@@ -583,6 +583,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
 // The narrow kernel above spends one 8-byte load instruction per lane and element and reloads the
 // codes in every lane: ~20 vector-memory instructions per 2 KB of the dense operand.
 constexpr int MCW_RS = 32;
+constexpr int MCW_VEC = 2;
 
 template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
@@ -590,18 +591,20 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     int64_t rows_per_block, F *__restrict__ ws, int64_t stride, const int32_t *__restrict__ rows) {
     // rows != NULL: `n` is the length of the row list and every position is mapped through it
     // (cost proportional to the list; the reference's `for k in rows`, ext/split.pyx:32-80)
-    constexpr int VEC = 16 / (int)sizeof(F);
+    // VEC = 2 columns per lane for both types (16-byte loads for f64, 8-byte loads for f32): the
+    // tile is made of doubles, and 32 columns per part is what fits LDS at a few hundred levels
+    constexpr int VEC = MCW_VEC;
     constexpr int TJ = 16 * VEC;
     constexpr int NI = MCW_RS / 4;               // load instructions per step
     typedef F vec_t __attribute__((ext_vector_type(VEC)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][TJ], lane-column de-interleaved
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][TJ], lane-column de-interleaved
     const int nel = cs.total * TJ;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     // per-wave scratch: d[MCW_RS] then NC x int[MCW_RS] tile-row byte offsets (-1: no level)
-    unsigned char *scr = smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16 +
+    unsigned char *scr = smem_raw + (((size_t)nel * sizeof(lds_acc_t) + 15) / 16) * 16 +
                          (size_t)wave * MCW_RS * (sizeof(F) + NC * sizeof(int));
     F *sd = reinterpret_cast<F *>(scr);
     int *sc = reinterpret_cast<int *>(scr + MCW_RS * sizeof(F));
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int col = cs.codes[c][kc] - cs.drop[c];
-            R.code[c] = (k < t1 && col >= 0) ? (cs.off[c] + col) * TJ * (int)sizeof(F) : -1;
+            R.code[c] = (k < t1 && col >= 0) ? (cs.off[c] + col) * TJ * (int)sizeof(lds_acc_t) : -1;
         }
     };
     auto process = [&](const Regs &R) {
@@ -655,9 +658,9 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (jok && off[c] >= 0) {
-                    F *dst = reinterpret_cast<F *>(smem_raw + off[c]) + jl;
+                    lds_acc_t *dst = reinterpret_cast<lds_acc_t *>(smem_raw + off[c]) + jl;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) atomic_add(dst + 16 * v, x[v]);
+                    for (int v = 0; v < VEC; ++v) atomic_add(dst + 16 * v, (lds_acc_t)x[v]);
                 }
             }
         }
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
     for (int b = threadIdx.x; b < nel; b += blockDim.x) {
         const int c = b % TJ;
-        dst[b] = tile[(b / TJ) * TJ + (c / VEC) + 16 * (c % VEC)];
+        dst[b] = (F)tile[(b / TJ) * TJ + (c / VEC) + 16 * (c % VEC)];
     }
 }
 
@@ -688,9 +691,9 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_f_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
     int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);
     const int nel = cs.total * TJ;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
     const int64_t j0 = (int64_t)blockIdx.y * TJ;
     const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
@@ -705,12 +708,12 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_f_kernel(
             const F x = dk * M[(j0 + jl) * n + k];
 #pragma unroll
             for (int c = 0; c < MAX_CATS; ++c)
-                if (col[c] >= 0) atomic_add(&tile[(cs.off[c] + col[c]) * TJ + jl], x);
+                if (col[c] >= 0) atomic_add(&tile[(cs.off[c] + col[c]) * TJ + jl], (lds_acc_t)x);
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // tmp [part][total][TJ] -> out[total][m]
@@ -736,18 +739,18 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
     const int64_t *__restrict__ gptr, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
     int slab_rows, int group_cols, int64_t n, F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols + 1]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][group_cols + 1]
     const int tstr = group_cols + 1;
     const int nel = cs.total * tstr;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     // per-wave scratch (STAGE): d of the slab rows, then the codes of every categorical
-    F *sd = reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16) +
+    F *sd = reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(lds_acc_t) + 15) / 16) * 16) +
             (size_t)wave * slab_rows;
     int32_t *sc = reinterpret_cast<int32_t *>(
-                      reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16) +
+                      reinterpret_cast<F *>(smem_raw + (((size_t)nel * sizeof(lds_acc_t) + 15) / 16) * 16) +
                       (size_t)nwave * slab_rows) +
                   (size_t)wave * cs.n_cats * slab_rows;
     __syncthreads();
@@ -797,15 +800,15 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_kernel(
                 const int c0 = STAGE ? sc[c * slab_rows + r0] : cs.codes[c][k0] - cs.drop[c];
                 const int c1 = ok1 ? (STAGE ? sc[c * slab_rows + r1] : cs.codes[c][k1] - cs.drop[c])
                                    : -1;
-                if (c0 >= 0) atomic_add(&tile[(cs.off[c] + c0) * tstr + ec0], x0);
-                if (c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * tstr + ec1], x1);
+                if (c0 >= 0) atomic_add(&tile[(cs.off[c] + c0) * tstr + ec0], (lds_acc_t)x0);
+                if (c1 >= 0) atomic_add(&tile[(cs.off[c] + c1) * tstr + ec1], (lds_acc_t)x1);
             }
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
     for (int b = threadIdx.x; b < cs.total * group_cols; b += blockDim.x)
-        dst[b] = tile[(b / group_cols) * tstr + (b % group_cols)];
+        dst[b] = (F)tile[(b / group_cols) * tstr + (b % group_cols)];
 }
 
 // Fast variant for 1..4 categoricals: one (slab, group) block per wave step.  While a block is
@@ -822,14 +825,14 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
     constexpr int SR = 128;              // slab rows (tm_slab_rows)
     constexpr int NQ = 4;                // prefetched 64-entry chunks per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [total][group_cols + 1]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][group_cols + 1]
     const int tstr = group_cols + 1;
     const int nel = cs.total * tstr;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    unsigned char *scratch = smem_raw + (((size_t)nel * sizeof(F) + 15) / 16) * 16;
+    unsigned char *scratch = smem_raw + (((size_t)nel * sizeof(lds_acc_t) + 15) / 16) * 16;
     F *sd = reinterpret_cast<F *>(scratch) + (size_t)wave * SR;
     int32_t *sc = reinterpret_cast<int32_t *>(reinterpret_cast<F *>(scratch) + (size_t)nwave * SR) +
                   (size_t)wave * NC * SR;
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int cc = sc[c * SR + r];
-                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * tstr + ee], x);
+                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * tstr + ee], (lds_acc_t)x);
             }
         };
 #pragma unroll
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
     __syncthreads();
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
     for (int b = threadIdx.x; b < cs.total * group_cols; b += blockDim.x)
-        dst[b] = tile[(b / group_cols) * tstr + (b % group_cols)];
+        dst[b] = (F)tile[(b / group_cols) * tstr + (b % group_cols)];
 }
 
 static int make_catset(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
@@ -955,13 +958,13 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     }
     {
         // wide-load path: C-ordered, 16-byte aligned rows, <= 4 categoricals, tile + scratch in LDS
-        constexpr int VEC = 16 / (int)sizeof(F);
+        constexpr int VEC = MCW_VEC;
         constexpr int TJW = 16 * VEC;
-        const size_t tile_b = ((sizeof(F) * (size_t)cs.total * TJW + 15) / 16) * 16;
+        const size_t tile_b = ((sizeof(lds_acc_t) * (size_t)cs.total * TJW + 15) / 16) * 16;
         const size_t lds_w = tile_b + (size_t)16 * MCW_RS * (sizeof(F) + (size_t)n_cats * sizeof(int));
         if (!order_f && n_cats <= 4 && m >= VEC && m % VEC == 0 &&
             (reinterpret_cast<uintptr_t>(M) & 15) == 0 && lds_w <= 150 * 1024 &&
-            (int64_t)cs.total * TJW * (int64_t)sizeof(F) < (1ll << 30)) {
+            (int64_t)cs.total * TJW * (int64_t)sizeof(lds_acc_t) < (1ll << 30)) {
             const int64_t n_parts = ceil_div(m, TJW);
             const int64_t stride = (int64_t)cs.total * TJW;
             int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
@@ -1003,15 +1006,15 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
         return TM_EUNSUPPORTED;
     }
     int TJ = 64;
-    while (TJ > 1 && sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) TJ >>= 1;
+    while (TJ > 1 && sizeof(lds_acc_t) * (size_t)cs.total * TJ > HIST_LDS_MAX) TJ >>= 1;
     while (TJ > 1 && TJ / 2 >= m) TJ >>= 1;
-    if (sizeof(F) * (size_t)cs.total * TJ > HIST_LDS_MAX) {
+    if (sizeof(lds_acc_t) * (size_t)cs.total * TJ > HIST_LDS_MAX) {
         set_error("multi_cat_dense: %d stacked categories exceed the LDS tile", cs.total);
         return TM_EUNSUPPORTED;
     }
     const int64_t n_parts = ceil_div(m, TJ);
     const int64_t stride = (int64_t)cs.total * TJ;
-    const size_t lds = sizeof(F) * (size_t)stride;
+    const size_t lds = sizeof(lds_acc_t) * (size_t)stride;
     int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
     nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 4096)));
     const int64_t rpb = ceil_div(n, nblk);
@@ -1080,7 +1083,7 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
         return TM_OK;
     }
     const int64_t stride = (int64_t)cs.total * group_cols;
-    const size_t tile_bytes = ((sizeof(F) * (size_t)cs.total * (group_cols + 1) + 15) / 16) * 16;
+    const size_t tile_bytes = ((sizeof(lds_acc_t) * (size_t)cs.total * (group_cols + 1) + 15) / 16) * 16;
     if (tile_bytes > HIST_LDS_MAX) {
         set_error("multi_cat_sparse: %d stacked categories exceed the LDS tile", cs.total);
         return TM_EUNSUPPORTED;

@@ -56,6 +56,12 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------
+// Accumulator type of LDS tiles that are updated with atomics: ALWAYS double.  On gfx950
+// ds_add_f32 runs lane-serially -- 169 cycles per 64-lane instruction against 7.6 for ds_add_f64
+// (scripts/ubench/atomics_f32.hip) -- so float data is accumulated in double tiles (twice the
+// LDS bytes, 20x the atomic rate, and no single-precision loss inside a workgroup).
+typedef double lds_acc_t;
+
 template <typename F>
 __device__ __forceinline__ void atomic_add(F *p, F v) {
     // -munsafe-fp-atomics: lowers to ds_add_f32/f64 (LDS) or global_atomic_add_f32/f64.

@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
     int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out, F *__restrict__ ws,
     F *__restrict__ out, int square) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *bins = reinterpret_cast<F *>(smem_raw);
+    lds_acc_t *bins = reinterpret_cast<lds_acc_t *>(smem_raw);          // doubles (see common.hpp)
     if (USE_LDS) {
-        for (int b = threadIdx.x; b < n_out; b += blockDim.x) bins[b] = F(0);
+        for (int b = threadIdx.x; b < n_out; b += blockDim.x) bins[b] = 0.0;
         __syncthreads();
     }
     const int sl = threadIdx.x % G;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
             const int oc = col_map ? col_map[j] : j;
             if (oc >= 0) {
                 const F x = square ? data[p] * data[p] : data[p];
-                if (USE_LDS) atomic_add(&bins[oc], x * vi);
+                if (USE_LDS) atomic_add(&bins[oc], (lds_acc_t)(x * vi));
                 else atomic_add(&out[oc], x * vi);
             }
         }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
     if (USE_LDS) {
         __syncthreads();
         F *dst = ws + (int64_t)blockIdx.x * n_out;
-        for (int b = threadIdx.x; b < n_out; b += blockDim.x) dst[b] = bins[b];
+        for (int b = threadIdx.x; b < n_out; b += blockDim.x) dst[b] = (F)bins[b];
     }
 }
 
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
     const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_block, F *__restrict__ ws,
     int square) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *bins = reinterpret_cast<F *>(smem_raw);                     // [m]
+    lds_acc_t *bins = reinterpret_cast<lds_acc_t *>(smem_raw);     // [m] doubles
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    F *vrow = bins + m + wave * CSR_CAP;                           // [CSR_CAP] per wave
-    for (int j = threadIdx.x; j < m; j += blockDim.x) bins[j] = F(0);
+    F *vrow = reinterpret_cast<F *>(bins + m) + wave * CSR_CAP;    // [CSR_CAP] per wave
+    for (int j = threadIdx.x; j < m; j += blockDim.x) bins[j] = 0.0;
     __syncthreads();
     const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
     const int64_t cb0 = (int64_t)blockIdx.x * chunks_per_block;
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
 #pragma unroll 4
             for (int e = lane; e < cnt; e += 64) {
                 const F x = data[c0 + e];
-                atomic_add(&bins[ind[c0 + e]], (square ? x * x : x) * vrow[e]);
+                atomic_add(&bins[ind[c0 + e]], (lds_acc_t)((square ? x * x : x) * vrow[e]));
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
     F *dst = ws + (int64_t)blockIdx.x * m;
-    for (int j = threadIdx.x; j < m; j += blockDim.x) dst[j] = bins[j];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) dst[j] = (F)bins[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(256) void csr_dense_kernel(
     const int32_t *__restrict__ a_map, int nA, const int32_t *__restrict__ B_cols, int nB,
     F *__restrict__ ws, int64_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [nA][TB]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [nA][TB] doubles
     const int part = blockIdx.y;
     const int j0 = part * TB;
     const int nel = nA * TB;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
     constexpr int SUB = 64 / TB;
@@ -222,12 +222,12 @@ __global__ __launch_bounds__(256) void csr_dense_kernel(
         }
         for (; p < p1; ++p) {
             const int a = a_map ? a_map[ind[p]] : ind[p];
-            if (a >= 0 && jok) atomic_add(&tile[a * TB + jb], data[p] * bd);
+            if (a >= 0 && jok) atomic_add(&tile[a * TB + jb], (lds_acc_t)(data[p] * bd));
         }
     }
     __syncthreads();
     F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
-    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -269,16 +269,16 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
     int64_t rows_per_block, const int32_t *__restrict__ col_map, int n_out,
     F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);                                   // [TS][TS]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);                   // [TS][TS] doubles
     typedef K2Entry<F> Ent;
-    Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(F) * TS * TS);      // [waves][2][64]
+    Ent *scratch = reinterpret_cast<Ent *>(smem_raw + sizeof(lds_acc_t) * TS * TS);   // [waves][2][64]
     // part -> (I, J), J <= I:  part = I (I + 1) / 2 + J
     int I = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) - 1.0f) * 0.5f);
     while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.y) ++I;
     while (I * (I + 1) / 2 > (int)blockIdx.y) --I;
     const int J = (int)blockIdx.y - I * (I + 1) / 2;
     const int i0 = I * TS, j0 = J * TS;
-    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
                             const Ent eb = sb[b];
                             if (I != J || eb.col <= ea.col)
                                 atomic_add(&tile[ea.col * TS + (eb.col ^ ((ea.col & 15) << 3))],
-                                           ea.val * eb.val);
+                                           (lds_acc_t)(ea.val * eb.val));
                         }
                     }
                 }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
         const int r = b / TS, c = b % TS;
-        dst[b] = tile[r * TS + (c ^ ((r & 15) << 3))];
+        dst[b] = (F)tile[r * TS + (c ^ ((r & 15) << 3))];
     }
 }
 
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     // pipeline walks a row list at a cost proportional to its length (the reference's
     // `for k in rows`, ext/sparse.pyx:46-48) -- the host gathers the table from the chunk pointers.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);  // [TS][TS], column-swizzled
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [TS][TS] doubles, column-swizzled
     // 1-D grid: the nch diagonal tiles come first with nb_diag workgroups each, then the
     // off-diagonal tiles with nb_off each (a diagonal tile has ~40 % fewer pairs per row).
     int part, blk, nblk_part;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     while (I * (I + 1) / 2 > part) --I;
     const int J = part - I * (I + 1) / 2;
     const int i0 = I * TS, j0 = J * TS;
-    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     //            (the swizzle bits and the row-base bits are disjoint from each other and the row
     //            base from kb) and the pair is wanted iff kb <= la -- one signed compare covering
     //            both validities and, on diagonal tiles (offmask 0), the b <= a triangle.
-    constexpr int SH = sizeof(F) == 8 ? 3 : 2;
+    constexpr int SH = 3;                          // byte offsets into a tile of doubles
     constexpr int BIGKEY = 0x7ffffff0;
     constexpr int offmask = DIAG ? 0 : 0x70000000;
     char *const tile_bytes = reinterpret_cast<char *>(tile);
@@ -586,7 +586,8 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     auto a_base = [&](int col) { return (int)(((unsigned)col << (7 + SH)) | ((col & 15) << (3 + SH))); };
     auto b_key = [&](int col) { return col < 0 ? BIGKEY : col << SH; };
     auto add_pair = [&](int kb, int la, int ba, F prod) {
-        if (kb <= la) atomic_add(reinterpret_cast<F *>(tile_bytes + (unsigned)(kb ^ ba)), prod);
+        if (kb <= la)
+            atomic_add(reinterpret_cast<lds_acc_t *>(tile_bytes + (unsigned)(kb ^ ba)), (lds_acc_t)prod);
     };
     auto process = [&](const Grp &cur) {
         const int nA = cur.nA, nB = DIAG ? cur.nA : cur.nB, pA0 = cur.pA, pB0 = DIAG ? cur.pA : cur.pB;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                             const int cb = ind[pBr + b] - j0;
                             const F vb = data[pBr + b];
                             if (!DIAG || cb <= ca)
-                                atomic_add(&tile[ca * TS + (cb ^ ((ca & 15) << 3))], va * vb);
+                                atomic_add(&tile[ca * TS + (cb ^ ((ca & 15) << 3))], (lds_acc_t)(va * vb));
                         }
                     }
                 }
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
         const int r = b / TS, c = b % TS;
-        dst[b] = tile[r * TS + (c ^ ((r & 15) << 3))];
+        dst[b] = (F)tile[r * TS + (c ^ ((r & 15) << 3))];
     }
 }
 
@@ -792,8 +793,9 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     const int64_t n_iter = rows ? n_rows : n;
     const int64_t n_out = cols ? n_cols : m;
     if (n_iter == 0 || n_out == 0) return TM_OK;
-    if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
-        const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
+    if (!rows && !cols &&
+        sizeof(lds_acc_t) * (size_t)m + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= 64 * 1024) {
+        const size_t lds = sizeof(lds_acc_t) * (size_t)m + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
         auto kern = &csr_rmatvec_stream_kernel<F>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -814,7 +816,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
         return launch_reduce_partials<F>(ws, m, (int)nblk, 1, out, m, true, st);
     }
     const size_t map_bytes = cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
-    const bool use_lds = sizeof(F) * (size_t)n_out <= SP_LDS_MAX;
+    const bool use_lds = sizeof(lds_acc_t) * (size_t)n_out <= SP_LDS_MAX;
     int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 2048)), NUM_CU * 2);
     const int64_t rpb = ceil_div(n_iter, nblk);
     nblk = ceil_div(n_iter, rpb);
@@ -831,7 +833,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + map_bytes);
     constexpr int G = 16;
     if (use_lds) {
-        const size_t lds = sizeof(F) * (size_t)n_out;
+        const size_t lds = sizeof(lds_acc_t) * (size_t)n_out;
         auto kern = &csr_rmatvec_kernel<F, G, true>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -863,16 +865,16 @@ static int run_csr_dense(const F *data, const int32_t *ind, const int64_t *ptr, 
     if (n_iter == 0) return TM_OK;
     // TB: B-columns per part (power of two <= 64) such that nA x TB fits the LDS budget
     int TB = 64;
-    while (TB > 1 && sizeof(F) * (size_t)nA * TB > SP_LDS_MAX) TB >>= 1;
+    while (TB > 1 && sizeof(lds_acc_t) * (size_t)nA * TB > SP_LDS_MAX) TB >>= 1;
     while (TB > 1 && TB / 2 >= nB) TB >>= 1;
-    if (sizeof(F) * (size_t)nA * TB > SP_LDS_MAX) {
+    if (sizeof(lds_acc_t) * (size_t)nA * TB > SP_LDS_MAX) {
         set_error("csr_dense_sandwich: %lld selected sparse columns exceed the LDS tile",
                   (long long)nA);
         return TM_EUNSUPPORTED;
     }
     const int64_t n_parts = ceil_div(nB, TB);
     const int64_t stride = nA * TB;
-    const size_t lds = sizeof(F) * (size_t)stride;
+    const size_t lds = sizeof(lds_acc_t) * (size_t)stride;
     const int blocks_per_cu = lds > 64 * 1024 ? 1 : 2;
     int64_t nblk = std::max<int64_t>(1, (NUM_CU * blocks_per_cu) / n_parts);
     nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, 512)));
@@ -944,11 +946,11 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)(n_out * n_out), st));
         return TM_OK;
     }
-    constexpr int TS = 128;   // 128 KB (f64) / 64 KB (f32) tile + 32 KB pair scratch
+    constexpr int TS = 128;   // 128 KB tile of doubles + pair scratch
     const int nchunk = (int)ceil_div(n_out, TS);
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
-    const size_t lds = sizeof(F) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
+    const size_t lds = sizeof(lds_acc_t) * (size_t)(TS * TS) + sizeof(K2Entry<F>) * K2_WAVES * 2 * 64;
     int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
     nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_iter, 256)));
     const int64_t rpb = ceil_div(n_iter, nblk);
@@ -1001,7 +1003,7 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     const int nchunk = (int)ceil_div(m, TS);
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(n_parts <= 65535, "too many sparse columns for the tiled sandwich");
-    const size_t lds = sizeof(F) * (size_t)(TS * TS);   // the tile only: pairs are formed in registers
+    const size_t lds = sizeof(lds_acc_t) * (size_t)(TS * TS);   // the tile only: pairs are formed in registers
     // workgroups per tile.  A diagonal tile (one list per row, pairs b <= a, no B-overhang phase)
     // costs ~0.75 of an off-diagonal one per row (measured: 22 / 28 workgroups per tile is the
     // optimum at 512 columns, 4.74 ms against 5.10 ms for 24 / 26): split the CUs by that weight.

@@ -23,10 +23,10 @@ __global__ __launch_bounds__(RK_WAVES * 64) void csr_dense_rows_kernel(
     const F *__restrict__ B, int64_t ldb, int order_f, int64_t n, int nB, int64_t rows_per_block,
     F *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *tile = reinterpret_cast<F *>(smem_raw);            // [RK_TS][RK_W]
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);   // [RK_TS][RK_W] doubles
     const int chunk = blockIdx.y;
     const int j0 = blockIdx.z * RK_W;
-    for (int b = threadIdx.x; b < RK_TS * RK_W; b += blockDim.x) tile[b] = F(0);
+    for (int b = threadIdx.x; b < RK_TS * RK_W; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(RK_WAVES * 64) void csr_dense_rows_kernel(
             for (int e = 0; e < cnt; ++e) {
                 const int col = __builtin_amdgcn_readlane(ci, e);
                 const F v = rl(cv, e);
-                atomic_add(tile + col * RK_W + lane, v * x0);
-                atomic_add(tile + col * RK_W + 64 + lane, v * x1);
+                atomic_add(tile + col * RK_W + lane, (lds_acc_t)(v * x0));
+                atomic_add(tile + col * RK_W + 64 + lane, (lds_acc_t)(v * x1));
             }
         }
     };
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(RK_WAVES * 64) void csr_dense_rows_kernel(
     __syncthreads();
     // ws: [part = chunk * n_dense_parts + z][block][RK_TS * RK_W]
     F *dst = ws + (((int64_t)chunk * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (RK_TS * RK_W);
-    for (int b = threadIdx.x; b < RK_TS * RK_W; b += blockDim.x) dst[b] = tile[b];
+    for (int b = threadIdx.x; b < RK_TS * RK_W; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
 // tmp [chunk][zpart][RK_TS][RK_W] -> out[m][nB]
@@ -117,7 +117,7 @@ static int run_csr_dense_rows(const F *data, const int32_t *ind, const int32_t *
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    const size_t lds = sizeof(F) * (size_t)stride;
+    const size_t lds = sizeof(lds_acc_t) * (size_t)stride;
     auto kern = &csr_dense_rows_kernel<F>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

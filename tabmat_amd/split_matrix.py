@@ -362,7 +362,7 @@ class SplitMatrix(MatrixBase):
         #      every categorical block (tm_multi_cat_*), instead of one pass per pair
         cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
                    and m.shape[1] > 0]
-        budget = (128 * 1024) // np.dtype(self.dtype).itemsize
+        budget = (128 * 1024) // 8       # LDS tiles are made of doubles for float32 data too
         if len(cat_ids) >= 1 and len(cat_ids) <= xsplit.MAX_FUSED_CATS:
             d_eff = d
             if rows is not None:   # row restriction = masked d (excluded rows contribute 0)

@@ -35,6 +35,7 @@ def sparse_block(n: int, m: int, density: float = 0.05, dtype=torch.float64, see
     g = _gen(seed)
     dev = g.device
     datas, inds, counts = [], [], []
+    chunk = max(1, min(chunk, (1 << 30) // max(m, 1)))      # torch.nonzero: < 2^31 elements per call
     for r0 in range(0, n, chunk):
         r = min(chunk, n - r0)
         mask = torch.rand((r, m), device=dev, generator=g) < density
