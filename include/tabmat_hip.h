@@ -452,6 +452,28 @@ int tm_cat_transpose_matvec_det_f64(const int32_t *perm, const int64_t *bstart, 
                                     const int64_t *cat_bptr, int64_t n_cols, const double *v,
                                     double *out, int accumulate, void *stream);
 
+/* Categorical cross terms on the SAME row grouping, for categoricals with many levels
+ * (ext/split.pyx:32-80 sandwich_cat_dense; the scipy product of categorical_matrix.py:825-838):
+ * out (n_cols, m) = C^T diag(d) Y with C the one-hot block described by perm / bstart / cat_bptr as
+ * above.  A workgroup sums d[k] * Y[k, :] over the rows of one block (one level), the blocks of a
+ * level are added in order: cost independent of the number of levels, results reproducible from run
+ * to run.  Dense Y: C-ordered (m columns, row stride m), 16-byte aligned, m a multiple of
+ * 16 / sizeof(F).  Sparse Y: CSR.  Rows with d == 0 are not read.  out: overwritten. */
+int tm_cat_dense_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                     const int64_t *cat_bptr, int64_t n_cols, const float *d,
+                                     const float *Y, int64_t m, float *out, void *stream);
+int tm_cat_dense_sandwich_sorted_f64(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                     const int64_t *cat_bptr, int64_t n_cols, const double *d,
+                                     const double *Y, int64_t m, double *out, void *stream);
+int tm_cat_sparse_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                      const int64_t *cat_bptr, int64_t n_cols, const float *d,
+                                      const float *csr_data, const int32_t *csr_indices,
+                                      const int64_t *csr_indptr, int64_t m, float *out, void *stream);
+int tm_cat_sparse_sandwich_sorted_f64(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
+                                      const int64_t *cat_bptr, int64_t n_cols, const double *d,
+                                      const double *csr_data, const int32_t *csr_indices,
+                                      const int64_t *csr_indptr, int64_t m, double *out, void *stream);
+
 /* =====================================================================================
  * Multi-right-hand-side matvec / transpose-matvec (2-D `vec`).  The reference hands these to
  * scipy.sparse (sparse_matrix.py:252-254, 266-268) and NumPy BLAS (dense_matrix.py:212-217 with

@@ -421,6 +421,12 @@ class CategoricalMatrix(MatrixBase):
                 if (other.dtype == self.dtype and d.dtype == other._dev_c().buf.dtype
                         and xsplit.multi_cat_dense_wide_ok(cats, other._dev_c())):
                     res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev_c())
+                elif (d.dtype == other._dev_c().buf.dtype
+                      and xsplit.cat_dense_sorted_ok(other._dev_c())):
+                    # more levels than one LDS tile holds: rows grouped by level, one pass over
+                    # the dense block whatever the number of levels
+                    res = xsplit.cat_dense_sandwich_sorted(self._det_plan(), self.shape[1], d,
+                                                           other._dev_c())
                 else:
                     oh, inv = self._onehot(other._dev_c().buf.dtype)
                     res = xs.csr_dense_sandwich_slab(oh, other._dev_c(), d)[inv]
@@ -429,7 +435,20 @@ class CategoricalMatrix(MatrixBase):
                                             R_cols, self.drop_first)
             return self._restrict(res, L_cols, None)
         if isinstance(other, SparseMatrix):
-            res = xsplit.sandwich_cat_sparse(self._dev(), self.shape[1], d, other._dev(), rows,
+            S = other._dev()
+            n_out = other.shape[1] if R_cols is None else D.nlen(R_cols)
+            if (self.shape[0] >= 4096 and self.shape[1] * n_out * 8 > 128 * 1024
+                    and d.dtype == S.data.dtype and S.data.numel() > 0):
+                # the [levels][columns] tile would take several passes over the rows: level-sorted
+                # kernel instead (masked d for a row restriction, sub-selection of the result)
+                if rows is not None:
+                    dm = torch.zeros_like(d)
+                    r64 = rows.to(torch.int64)
+                    dm[r64] = d[r64]
+                    d = dm
+                res = xsplit.cat_sparse_sandwich_sorted(self._det_plan(), self.shape[1], d, S)
+                return self._restrict(res, L_cols, R_cols)
+            res = xsplit.sandwich_cat_sparse(self._dev(), self.shape[1], d, S, rows,
                                              R_cols, self.drop_first)
             return self._restrict(res, L_cols, None)
         if isinstance(other, CategoricalMatrix):

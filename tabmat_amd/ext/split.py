@@ -50,6 +50,41 @@ def sandwich_cat_sparse(i_indices, i_ncol, d, S: CsrDev, rows, cols, drop_first=
     return res
 
 
+def cat_dense_sandwich_sorted(plan, n_cols, d, mat_j: DenseDev):
+    """ext/split.pyx:32-80 for a categorical with many levels: the rows grouped by level once
+    (plan = CategoricalMatrix._det_plan()), one pass over the C-ordered dense block whatever the
+    number of levels (csrc/cat_sorted.hip).  Returns (n_cols, mat_j.m)."""
+    perm, bstart, n_blocks, cat_bptr = plan
+    if n_cols == 0 or mat_j.m == 0:
+        return D.zeros((n_cols, mat_j.m), mat_j.dtype)
+    res = D.out_buf((n_cols, mat_j.m), mat_j.dtype)
+    D.same_float("cat_dense_sandwich_sorted", mat_j.buf, d)
+    call(f"tm_cat_dense_sandwich_sorted_{D.fsuf(mat_j.buf)}", D.p(perm), D.p(bstart), int(n_blocks),
+         D.p(cat_bptr), int(n_cols), D.p(d), D.p(mat_j.buf), mat_j.m, D.p(res), D.stream_ptr())
+    return res
+
+
+def cat_dense_sorted_ok(mat_j: DenseDev) -> bool:
+    vec = 16 // mat_j.buf.element_size()
+    return (not mat_j.order_f and mat_j.m >= vec and mat_j.m % vec == 0
+            and mat_j.buf.data_ptr() % 16 == 0)
+
+
+def cat_sparse_sandwich_sorted(plan, n_cols, d, S: CsrDev):
+    """The scipy product behind CategoricalMatrix._cross_sparse (categorical_matrix.py:825-838) for
+    a categorical with many levels: rows grouped by level, an LDS row of doubles per block
+    (csrc/cat_sorted.hip).  Returns (n_cols, S.m)."""
+    perm, bstart, n_blocks, cat_bptr = plan
+    if n_cols == 0 or S.m == 0:
+        return D.zeros((n_cols, S.m), S.dtype)
+    res = D.out_buf((n_cols, S.m), S.dtype)
+    D.same_float("cat_sparse_sandwich_sorted", S.data, d)
+    call(f"tm_cat_sparse_sandwich_sorted_{D.fsuf(S.data)}", D.p(perm), D.p(bstart), int(n_blocks),
+         D.p(cat_bptr), int(n_cols), D.p(d), D.p(S.data), D.p(S.indices), D.p(S.indptr), S.m, D.p(res),
+         D.stream_ptr())
+    return res
+
+
 def scatter_block(src, ri, ci, out, mirror=False, diag=False):
     """out[ri[a], ci[b]] = src[a, b] (+ transpose); diag: out[ri[a], ri[a]] += src[a].
     Device form of split_matrix.py:341-354."""

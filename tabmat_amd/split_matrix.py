@@ -195,14 +195,14 @@ class SplitMatrix(MatrixBase):
 
     def _onehot_slab(self, cat_ids):
         key = tuple(cat_ids)
-        cache = getattr(self, "_onehot_cache", None)
-        if cache is None or cache[0] != key:
+        cache = self.__dict__.setdefault("_onehot_cache", {})
+        if key not in cache:
             from .ext._types import onehot_slab
 
             mats = self.matrices
             cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in cat_ids]
-            self._onehot_cache = (key, onehot_slab(cats, self.shape[0], D.torch_dtype(self.dtype)))
-        return self._onehot_cache[1]
+            cache[key] = onehot_slab(cats, self.shape[0], D.torch_dtype(self.dtype))
+        return cache[key]
 
     def _dev_idx(self, arrs):
         return [D.idx_dev(a, torch.int64) for a in arrs]
@@ -222,12 +222,16 @@ class SplitMatrix(MatrixBase):
         self._full_dev_indices()
         cat_ids = [i for i, m in enumerate(self.matrices)
                    if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
-        if 1 <= len(cat_ids) <= xsplit.MAX_FUSED_CATS:
+        for grp in self._cat_groups(cat_ids):
             cats = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
-                    for i in cat_ids]
+                    for i in grp]
             if any(isinstance(m, DenseMatrix) and not xsplit.multi_cat_dense_wide_ok(cats, m._dev_c())
-                   for m in self.matrices):
-                self._onehot_slab(cat_ids)
+                   and not xsplit.cat_dense_sorted_ok(m._dev_c()) for m in self.matrices):
+                self._onehot_slab(grp)
+        others = any(not isinstance(m, CategoricalMatrix) for m in self.matrices)
+        for i in cat_ids:            # many levels: the row grouping of the level-sorted kernels
+            if self.matrices[i].shape[1] > self.FUSED_LEVELS and others:
+                self.matrices[i]._det_plan()
         return self
 
     def astype(self, dtype, order="K", casting="unsafe", copy=True):
@@ -325,6 +329,28 @@ class SplitMatrix(MatrixBase):
             xtd[pd] = cs.to(torch.float64)
         return out, xtd
 
+    # levels that fit one LDS tile of doubles next to 32 dense / 33 sparse columns
+    FUSED_LEVELS = 496
+
+    def _cat_groups(self, cat_ids):
+        """Categorical blocks whose cross terms are fused into one pass (tm_multi_cat_*): groups of
+        at most 4 blocks and FUSED_LEVELS stacked levels, in block order.  A categorical with more
+        levels than that is left out: its cross terms go through the level-sorted kernels, whose
+        cost does not depend on the number of levels (CategoricalMatrix._cross_sandwich_dev)."""
+        groups, cur, tot = [], [], 0
+        for i in cat_ids:
+            k = self.matrices[i].shape[1]
+            if k > self.FUSED_LEVELS:
+                continue
+            if cur and (len(cur) == 4 or tot + k > self.FUSED_LEVELS):
+                groups.append(cur)
+                cur, tot = [], 0
+            cur.append(i)
+            tot += k
+        if cur:
+            groups.append(cur)
+        return groups
+
     def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget, d_rows=None):
         """All categorical x `mw` cross blocks from ONE pass over `mw` (tm_multi_cat_*), stacked
         [sum of levels, mw columns], or None when no fused kernel applies."""
@@ -336,8 +362,11 @@ class SplitMatrix(MatrixBase):
                 return xsplit.multi_cat_dense_sandwich(cats, d_rows, mw._dev_c(), rows)
             return xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
         if isinstance(mw, DenseMatrix):
-            # stacked one-hot encodings as a 1-nonzero-per-row-and-categorical sparse
-            # block in slab form -> atomic-free gather kernel (sparse.hip, K3 v2)
+            if xsplit.cat_dense_sorted_ok(mw._dev_c()):
+                return None          # pair by pair on the level-sorted kernel
+            # (F-ordered / unaligned operand) stacked one-hot encodings as a
+            # 1-nonzero-per-row-and-categorical sparse block in slab form -> atomic-free gather
+            # kernel (sparse.hip, K3 v2)
             from .ext import sparse as xs
 
             oh, inv = self._onehot_slab(cat_ids)
@@ -363,23 +392,25 @@ class SplitMatrix(MatrixBase):
         cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
                    and m.shape[1] > 0]
         budget = (128 * 1024) // 8       # LDS tiles are made of doubles for float32 data too
-        if len(cat_ids) >= 1 and len(cat_ids) <= xsplit.MAX_FUSED_CATS:
+        groups = self._cat_groups(cat_ids)
+        if groups:
             d_eff = d
             if rows is not None:   # row restriction = masked d (excluded rows contribute 0)
                 d_eff = torch.zeros_like(d)
                 r64 = rows.to(torch.int64)
                 d_eff[r64] = d[r64]
-            cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in cat_ids]
+        for grp in groups:
+            cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in grp]
             total = sum(c[1] for c in cats)
             offs = np.concatenate([[0], np.cumsum([c[1] for c in cats])])
             for w, mw in enumerate(mats):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
                 with fan.lane():
-                    stacked = self._fused_cats(mw, cats, cat_ids, d_eff, rows, total, budget, d)
+                    stacked = self._fused_cats(mw, cats, grp, d_eff, rows, total, budget, d)
                     if stacked is None:
                         continue
-                    for ci, i in enumerate(cat_ids):
+                    for ci, i in enumerate(grp):
                         res = stacked[int(offs[ci]):int(offs[ci + 1])]
                         if (colsum is not None and colsum[w] is None and not mats[i].drop_first
                                 and not mats[i]._has_missings):
