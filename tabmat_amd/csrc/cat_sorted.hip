@@ -83,17 +83,33 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cat_sparse_sorted_kernel(
     for (int c = threadIdx.x; c < mc; c += blockDim.x) acc[c] = 0.0;
     __syncthreads();
     const int64_t i0 = bstart[b], i1 = bstart[b + 1];
-    // 32 lanes per row, two rows per wave and step
+    // 32 lanes per row, two rows per wave at a time.  The chain perm -> {d, indptr} -> entries is
+    // three dependent memory round trips: each half-wave resolves the first two for 32 of its rows
+    // AT ONCE (lane <-> row) and then walks those rows with the values broadcast from the lanes.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 5, sl = lane & 31;
-    for (int64_t i = i0 + wave * 2 + sub; i < i1; i += CS_WAVES * 2) {
-        const int64_t k = perm[i];
-        const F dk = d[k];
-        if (dk == F(0)) continue;
-        const int64_t p1 = ptr[k + 1];
-        for (int64_t p = ptr[k] + sl; p < p1; p += 32) {
-            const int c = ind[p];
-            if (c >= c0 && c < c1) atomicAdd(&acc[c - c0], (double)dk * (double)data[p]);
+    constexpr int NH = CS_WAVES * 2;                       // half-waves of the workgroup
+    const int h = wave * 2 + sub;
+    for (int64_t base = i0 + h; base < i1; base += (int64_t)NH * 32) {
+        const int64_t i = base + (int64_t)sl * NH;         // this lane's row of the batch
+        int64_t k = 0, p0 = 0, p1 = 0;
+        F dk = F(0);
+        if (i < i1) {
+            k = perm[i];
+            dk = d[k];
+            p0 = ptr[k];
+            p1 = ptr[k + 1];
+        }
+        if (dk == F(0)) p1 = p0;                           // d == 0: the row is not read
+        const int nrow = (int)min((int64_t)32, (i1 - base + NH - 1) / NH);
+        for (int t = 0; t < nrow; ++t) {
+            const int src = sub * 32 + t;
+            const int64_t q0 = __shfl(p0, src, 64), q1 = __shfl(p1, src, 64);
+            const double dd = (double)__shfl(dk, src, 64);
+            for (int64_t p = q0 + sl; p < q1; p += 32) {
+                const int c = ind[p];
+                if (c >= c0 && c < c1) atomicAdd(&acc[c - c0], dd * (double)data[p]);
+            }
         }
     }
     __syncthreads();
