@@ -158,7 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                                                    const int32_t *__restrict__ rows,
                                                    int64_t n_iter, int64_t rows_per_block,
                                                    const int32_t *__restrict__ cols, int n_cols,
-                                                   F *__restrict__ ws) {
+                                                   F *__restrict__ ws, int64_t coff0, int64_t coff1) {
+    // coff0 / coff1 (LOAD_C_VEC only): first column of X behind the virtual columns 0..127 and
+    // 128..255 -- a 128-column panel of a wider block, or the two panels of a rectangular pass,
+    // read with the same 16-byte loads as a whole block (0 / 128 = the block itself)
     using C = SyrkCfg<F, NBLK, RECT>;
     using acc_t = typename Mfma<F>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 for (int e = 0; e < C::VEC; ++e) v[e] = F(0);
                 if (q < C::NVEC && t < t1 && c < n_cols) {
                     const int64_t row = rows ? (int64_t)rows[t] : t;
-                    v = *reinterpret_cast<const vec_t *>(X + row * m + c);
+                    v = *reinterpret_cast<const vec_t *>(X + row * m + (c < 128 ? coff0 + c : coff1 + c - 128));
                 }
 #pragma unroll
                 for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
@@ -400,7 +403,7 @@ template <typename F, int NBLK, bool RECT = false>
 static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d,
                        const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
                        const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
-                       hipStream_t st) {
+                       hipStream_t st, int64_t coff0 = 0, int64_t coff1 = 128) {
     using C = SyrkCfg<F, NBLK, RECT>;
     const int blocks_per_cu = (2 * C::LDS <= LDS_BYTES) ? 2 : 1;
     int64_t nblk = std::min<int64_t>((int64_t)NUM_CU * blocks_per_cu,
@@ -422,7 +425,7 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
-                           rows, n_iter, rpb, cols, n_cols, part);
+                           rows, n_iter, rpb, cols, n_cols, part, coff0, coff1);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
@@ -459,22 +462,22 @@ template <typename F>
 static int syrk_dispatch(const F *X, int64_t n, int64_t m, int order_f, const F *d,
                          const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
                          const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
-                         hipStream_t st) {
+                         hipStream_t st, int64_t coff0 = 0) {
     if (n_cols <= 16)
         return launch_syrk<F, 1>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st);
+                                 wsbase, ws_off, st, coff0, coff0 + 128);
     if (n_cols <= 32)
         return launch_syrk<F, 2>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st);
+                                 wsbase, ws_off, st, coff0, coff0 + 128);
     if (n_cols <= 64)
         return launch_syrk<F, 4>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st);
+                                 wsbase, ws_off, st, coff0, coff0 + 128);
     if (n_cols <= 128)
         return launch_syrk<F, 8>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st);
+                                 wsbase, ws_off, st, coff0, coff0 + 128);
     if constexpr (sizeof(F) == 4) {
         return launch_syrk<F, 16>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                  wsbase, ws_off, st);
+                                  wsbase, ws_off, st, coff0, coff0 + 128);
     } else {
         set_error("internal: f64 syrk panel wider than 128 columns");
         return TM_EINVAL;
@@ -517,6 +520,12 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     char *base = reinterpret_cast<char *>(wsv);
     int32_t *vcols = reinterpret_cast<int32_t *>(base);
     int32_t *vpos = vcols + 256;
+    // all columns of a C-ordered, aligned block: the panels are column OFFSETS for the 16-byte-load
+    // kernels (a column list would send them down the element-wise load path: 5.9 instead of
+    // 3.4 ms for 2M x 256 f64)
+    constexpr int VECW = 16 / (int)sizeof(F);
+    const bool contiguous = cols == nullptr && !order_f && m % VECW == 0 &&
+                            (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     for (int a = 0; a < np; ++a) {
         const int wa = (int)std::min<int64_t>(PW, n_cols - (int64_t)a * PW);
         hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vcols, cols, a * PW,
@@ -524,8 +533,8 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
         hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos,
                            (const int32_t *)nullptr, a * PW, wa);
         TM_LAUNCH_CHECK();
-        rc = syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, vcols, wa, vpos, out, n_cols, base,
-                              idx_bytes, st);
+        rc = syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, contiguous ? nullptr : vcols, wa, vpos,
+                              out, n_cols, base, idx_bytes, st, contiguous ? (int64_t)a * PW : 0);
         if (rc) return rc;
         for (int b = a + 1; b < np; ++b) {
             const int wb = (int)std::min<int64_t>(PW, n_cols - (int64_t)b * PW);
@@ -534,8 +543,10 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
             hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos + PW,
                                (const int32_t *)nullptr, b * PW, wb);
             TM_LAUNCH_CHECK();
-            rc = launch_syrk<F, 16, true>(X, n, m, order_f, d, rows, n_iter, vcols, PW + wb, vpos,
-                                          out, n_cols, base, idx_bytes, st);
+            rc = launch_syrk<F, 16, true>(X, n, m, order_f, d, rows, n_iter, contiguous ? nullptr : vcols,
+                                          PW + wb, vpos, out, n_cols, base, idx_bytes, st,
+                                          contiguous ? (int64_t)a * PW : 0,
+                                          contiguous ? (int64_t)b * PW : 128);
             if (rc) return rc;
         }
     }
