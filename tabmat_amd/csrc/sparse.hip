@@ -423,7 +423,33 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_kernel(
 constexpr int K2_ED = 2;   // groups whose entry loads are in flight
 constexpr int K2_NP = 2;   // further groups whose chunk-pointer loads are in flight
 
-template <typename F, int TS>
+// slot K (0 .. S - 1) of the lane's own S-lane row group, broadcast to its S lanes
+template <int S, int K>
+__device__ __forceinline__ int k2_bcast_i32(int v, int x4) {
+    if constexpr (S == 8) {
+        return dpp_bcast8_i32<K>(v, x4);
+    } else if constexpr (S == 4) {
+        return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true);                    // quad_perm [K,K,K,K]
+    } else {
+        return __builtin_amdgcn_mov_dpp(v, K | (K << 2) | ((2 + K) << 4) | ((2 + K) << 6), 0xF, 0xF,
+                                        true);                                           // [K,K,2+K,2+K]
+    }
+}
+template <int S, int K>
+__device__ __forceinline__ double k2_bcast(double v, double x4) {
+    return __hiloint2double(k2_bcast_i32<S, K>(__double2hiint(v), __double2hiint(x4)),
+                            k2_bcast_i32<S, K>(__double2loint(v), __double2loint(x4)));
+}
+template <int S, int K>
+__device__ __forceinline__ float k2_bcast(float v, float x4) {
+    return __int_as_float(k2_bcast_i32<S, K>(__float_as_int(v), __float_as_int(x4)));
+}
+
+// S = slots per row and list half (8, 4 or 2; 64 / S rows per wave step): 8 suits ~6 nonzeros per
+// row and 128-column chunk (5 % density); a block with 1-2 nonzeros per row and chunk (wide and
+// sparse: 2048 columns at 1.25 %) would fill 3 % of the lanes of its 8 ds_adds per 8 rows -- with
+// S = 2 the same pairs take 2 ds_adds per 32 rows.
+template <typename F, int TS, int S>
 __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
@@ -467,7 +493,8 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lr = lane >> 3, lt = lane & 7;       // load phase: row-in-group, entry slot
+    constexpr int RG = 64 / S;                      // rows per group (wave step)
+    const int lr = lane / S, lt = lane % S;         // load phase: row-in-group, entry slot
     const int64_t t0 = (int64_t)blk * rows_per_block;
     const int64_t t1 = min(t0 + rows_per_block, n);
     const int64_t pstride = pairs ? 2 * n : n + 1;   // cptr is [nch][n + 1] (chunk-major twin)
@@ -522,7 +549,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         }
         return q;
     };
-    auto load_entries = [&](const Ptr &q) {   // slots lt and lt + 8 of both lists: 16 entries per list
+    auto load_entries = [&](const Ptr &q) {   // slots lt and lt + S of both lists: 2 S entries per list
         Grp e;
         const bool on = q.valid && q.d != F(0);      // rows with d == 0 contribute nothing
         e.d = q.d;
@@ -533,7 +560,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         const unsigned rA = (unsigned)(q.a0 - baseA), rB = (unsigned)(q.b0 - baseB);
         const unsigned lA = (unsigned)max(e.nA - 1, 0), lB = (unsigned)max(e.nB - 1, 0);
         const unsigned iA = min(rA + min((unsigned)lt, lA), spanA1);
-        const unsigned iA2 = min(rA + min((unsigned)lt + 8u, lA), spanA1);
+        const unsigned iA2 = min(rA + min((unsigned)lt + (unsigned)S, lA), spanA1);
         // 32-bit BYTE offsets (host: < 2^32 per workgroup range) -> SGPR base + VGPR offset loads
         auto ldi = [](const int32_t *base, unsigned i) {
             return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (i << 2));
@@ -548,7 +575,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         e.va2 = ldf(dataA, iA2);
         if constexpr (!DIAG) {
             const unsigned iB = min(rB + min((unsigned)lt, lB), spanB1);
-            const unsigned iB2 = min(rB + min((unsigned)lt + 8u, lB), spanB1);
+            const unsigned iB2 = min(rB + min((unsigned)lt + (unsigned)S, lB), spanB1);
             e.cb = ldi(indB, iB);
             e.vb = ldf(dataB, iB);
             e.cb2 = ldi(indB, iB2);
@@ -561,8 +588,8 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         }
         return e;
     };
-    const int gstep = K2_WAVES * 8;
-    const int gw = wave * 8;
+    const int gstep = K2_WAVES * RG;
+    const int gw = wave * RG;
     Grp ea[K2_ED], eb[K2_ED];      // two register sets: the loop is unrolled by two turns
     Ptr ps[K2_NP];
 #pragma unroll
@@ -601,37 +628,43 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         const int la = a_lim(colA), ba = a_base(colA), kb = b_key(colB);
         const F av = cur.va * dk, vb = DIAG ? cur.va : cur.vb;
         add_pair(kb, la, ba, av * vb);
-        add_pair(dpp_xor_i32<1>(kb), la, ba, av * dpp_xor<1>(vb));
-        add_pair(dpp_xor_i32<2>(kb), la, ba, av * dpp_xor<2>(vb));
-        add_pair(dpp_xor_i32<3>(kb), la, ba, av * dpp_xor<3>(vb));
-        const int kb4 = dpp_xor_i32<4>(kb);
-        const F vb4 = dpp_xor<4>(vb);
-        add_pair(kb4, la, ba, av * vb4);
-        add_pair(dpp_xor_i32<1>(kb4), la, ba, av * dpp_xor<1>(vb4));
-        add_pair(dpp_xor_i32<2>(kb4), la, ba, av * dpp_xor<2>(vb4));
-        add_pair(dpp_xor_i32<3>(kb4), la, ba, av * dpp_xor<3>(vb4));
-        // second halves (slots 8..15, ~19 % of the rows have one): slot 8 + k of a row is
-        // broadcast to the row's 8 lanes, k = 0 .. (longest overhang of the 8 rows) - 1, ~2 steps
-        const bool anyA2 = __any(nA > 8), anyB2 = __any(nB > 8);
-        const int colB2 = lt + 8 < nB ? (DIAG ? cur.ca2 : cur.cb2) - j0 : -1;
+        if constexpr (S >= 2) add_pair(dpp_xor_i32<1>(kb), la, ba, av * dpp_xor<1>(vb));
+        if constexpr (S >= 4) {
+            add_pair(dpp_xor_i32<2>(kb), la, ba, av * dpp_xor<2>(vb));
+            add_pair(dpp_xor_i32<3>(kb), la, ba, av * dpp_xor<3>(vb));
+        }
+        if constexpr (S == 8) {
+            const int kb4 = dpp_xor_i32<4>(kb);
+            const F vb4 = dpp_xor<4>(vb);
+            add_pair(kb4, la, ba, av * vb4);
+            add_pair(dpp_xor_i32<1>(kb4), la, ba, av * dpp_xor<1>(vb4));
+            add_pair(dpp_xor_i32<2>(kb4), la, ba, av * dpp_xor<2>(vb4));
+            add_pair(dpp_xor_i32<3>(kb4), la, ba, av * dpp_xor<3>(vb4));
+        }
+        // second halves (slots S .. 2 S - 1; at S = 8 and 5 % density ~19 % of the rows have one):
+        // slot S + k of a row is broadcast to the row's S lanes, k = 0 .. (longest overhang of the
+        // group's rows) - 1
+        const bool anyA2 = __any(nA > S), anyB2 = __any(nB > S);
+        const int colB2 = lt + S < nB ? (DIAG ? cur.ca2 : cur.cb2) - j0 : -1;
         const int kb2 = b_key(colB2);
         const F vb2 = DIAG ? cur.va2 : cur.vb2;
         if (anyA2) {
             // A overhang x (B first half, B overhang)
-            const int colA2 = lt + 8 < nA ? cur.ca2 - i0 : -1;
+            const int colA2 = lt + S < nA ? cur.ca2 - i0 : -1;
             const int la2 = a_lim(colA2), ba2 = a_base(colA2);
             const F av2 = cur.va2 * dk;
-            const int la2x = dpp_xor_i32<4>(la2), ba2x = dpp_xor_i32<4>(ba2);
-            const F av2x = dpp_xor<4>(av2);
+            // (the S = 8 broadcast needs the value of the other quad as a second operand)
+            const int la2x = S == 8 ? dpp_xor_i32<4>(la2) : 0, ba2x = S == 8 ? dpp_xor_i32<4>(ba2) : 0;
+            const F av2x = S == 8 ? dpp_xor<4>(av2) : F(0);
             bool go = true;
-            static_for<8>([&](auto kc) {
+            static_for<S>([&](auto kc) {
                 constexpr int K = decltype(kc)::value;
                 if (go) {
-                    if (!__any(nA > 8 + K)) {
+                    if (!__any(nA > S + K)) {
                         go = false;
                     } else {
-                        const int lk = dpp_bcast8_i32<K>(la2, la2x), bk = dpp_bcast8_i32<K>(ba2, ba2x);
-                        const F ak = dpp_bcast8<K>(av2, av2x);
+                        const int lk = k2_bcast_i32<S, K>(la2, la2x), bk = k2_bcast_i32<S, K>(ba2, ba2x);
+                        const F ak = k2_bcast<S, K>(av2, av2x);
                         add_pair(kb, lk, bk, ak * vb);
                         if (anyB2) add_pair(kb2, lk, bk, ak * vb2);
                     }
@@ -640,30 +673,30 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         }
         if (!DIAG && anyB2) {
             // A first half x B overhang (empty on diagonal tiles: those columns are all > a's)
-            const int kb2x = dpp_xor_i32<4>(kb2);
-            const F vb2x = dpp_xor<4>(vb2);
+            const int kb2x = S == 8 ? dpp_xor_i32<4>(kb2) : 0;
+            const F vb2x = S == 8 ? dpp_xor<4>(vb2) : F(0);
             bool go = true;
-            static_for<8>([&](auto kc) {
+            static_for<S>([&](auto kc) {
                 constexpr int K = decltype(kc)::value;
                 if (go) {
-                    if (!__any(nB > 8 + K)) {
+                    if (!__any(nB > S + K)) {
                         go = false;
                     } else {
-                        add_pair(dpp_bcast8_i32<K>(kb2, kb2x), la, ba, av * dpp_bcast8<K>(vb2, vb2x));
+                        add_pair(k2_bcast_i32<S, K>(kb2, kb2x), la, ba, av * k2_bcast<S, K>(vb2, vb2x));
                     }
                 }
             });
         }
-        if (__any(nA > 16) || __any(nB > 16)) {
-            // very long lists (> 16 entries of one row in one 128-column chunk): remaining
+        if (__any(nA > 2 * S) || __any(nB > 2 * S)) {
+            // very long lists (> 2 S entries of one row in one 128-column chunk): remaining
             // 8 x 8 blocks straight from the CSR arrays
-            for (int r = 0; r < 8; ++r) {
-                const int nAr = __builtin_amdgcn_readlane(nA, r * 8);
-                const int nBr = __builtin_amdgcn_readlane(nB, r * 8);
-                if ((nAr <= 16 && nBr <= 16) || nAr == 0 || nBr == 0) continue;
-                const int pAr = __builtin_amdgcn_readlane(pA0, r * 8);
-                const int pBr = __builtin_amdgcn_readlane(pB0, r * 8);
-                const F dr = readlane_f<F>(dk, r * 8);
+            for (int r = 0; r < RG; ++r) {
+                const int nAr = __builtin_amdgcn_readlane(nA, r * S);
+                const int nBr = __builtin_amdgcn_readlane(nB, r * S);
+                if ((nAr <= 2 * S && nBr <= 2 * S) || nAr == 0 || nBr == 0) continue;
+                const int pAr = __builtin_amdgcn_readlane(pA0, r * S);
+                const int pBr = __builtin_amdgcn_readlane(pB0, r * S);
+                const F dr = readlane_f<F>(dk, r * S);
                 for (int a0 = 0; a0 < nAr; a0 += 8) {
                     const int a = a0 + pa;
                     int ca = 0;
@@ -672,9 +705,10 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
                         ca = ind[pAr + a] - i0;
                         va = data[pAr + a] * dr;
                     }
-                    for (int b0 = (a0 < 16 ? 16 : 0); b0 < nBr; b0 += 8) {
+                    // (pairs with a < 2 S and b < 2 S were formed above)
+                    for (int b0 = (a0 + 8 <= 2 * S ? (2 * S) / 8 * 8 : 0); b0 < nBr; b0 += 8) {
                         const int b = b0 + pb;
-                        if (a < nAr && b < nBr) {
+                        if (a < nAr && b < nBr && (a >= 2 * S || b >= 2 * S)) {
                             const int cb = ind[pBr + b] - j0;
                             const F vb = data[pBr + b];
                             if (!DIAG || cb <= ca)
@@ -1029,7 +1063,15 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    auto kern = &sparse_sandwich_chunked_kernel<F, TS>;
+    // slots per row and list half by the mean number of nonzeros per row and 128-column chunk
+    const double per_chunk = (double)nnz / ((double)n * nchunk);
+    static const int force_s = getenv("TABMAT_AMD_K2_SLOTS") ? atoi(getenv("TABMAT_AMD_K2_SLOTS")) : 0;
+    // measured at 2M rows (profiles/r2_microbench.txt): 8 slots win above ~4.5 nonzeros per row and
+    // chunk, 2 slots below ~0.9
+    const int slots = force_s ? force_s : (per_chunk > 4.5 ? 8 : per_chunk > 0.9 ? 4 : 2);
+    auto kern = slots == 8   ? &sparse_sandwich_chunked_kernel<F, TS, 8>
+                : slots == 4 ? &sparse_sandwich_chunked_kernel<F, TS, 4>
+                             : &sparse_sandwich_chunked_kernel<F, TS, 2>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // every tile's partials are reduced over nblk slots: tiles with fewer workgroups leave theirs 0

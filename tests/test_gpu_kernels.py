@@ -671,3 +671,34 @@ def test_sandwich_graph_replay_matches_eager():
     big.sandwich(rng.random(300_000))
     d = torch.from_numpy(np.random.default_rng(9).random(20_000)).cuda()
     assert rel_err(f(d).cpu().numpy(), X.sandwich(d).cpu().numpy()) < F64_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,dens", [(30_011, 2048, 0.0125), (20_000, 1024, 0.003), (9000, 700, 0.01),
+                                      (5000, 384, 0.002)])
+def test_sparse_sandwich_few_nonzeros_per_chunk(n, m, dens, dtype):
+    """Wide and sparse blocks: the chunked K2 kernel runs with 4 or 2 slots per row and chunk
+    (sparse.hip, template parameter S); a few dense rows exercise the overhang steps and the
+    long-list fallback of those geometries."""
+    import tabmat_amd as tm
+    from oracle import oracle as orc
+    from tabmat_amd import _device as D
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=dens, format="lil", random_state=rng, dtype=np.float64)
+    for r in rng.choice(n, 40, replace=False):          # rows with 3 .. 40 nonzeros per chunk
+        cols = rng.choice(m, int(m * rng.uniform(0.03, 0.3)), replace=False)
+        S[r, cols] = rng.standard_normal(len(cols))
+    S = sps.csc_matrix(S).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 10)] = 0
+    sm = tm.SparseMatrix(S)
+    got = sm.sandwich(d)
+    want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, None, None)
+    tol = 1e-10 if dtype == np.float64 else 3e-4
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    rows = np.sort(rng.choice(n, n // 5, replace=False))
+    got = sm.sandwich(d, rows=rows)
+    want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, rows, None)
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
