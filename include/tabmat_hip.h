@@ -426,6 +426,16 @@ int tm_sparse_sandwich_chunked_rows_f32(const float *cm_data, const int32_t *cm_
 int tm_sparse_sandwich_chunked_rows_f64(const double *cm_data, const int32_t *cm_indices,
                                         const int32_t *row_ranges, int64_t n_sel, int64_t m,
                                         int64_t nnz, const double *d_sel, double *out, void *stream);
+/* The same product for WIDE, VERY SPARSE blocks (fewer than one nonzero per row and 128-column
+ * chunk): plain CSR in, one L2 atomic per pair into a double accumulator, cost proportional to the
+ * number of pairs instead of rows x tiles (csrc/sparse_direct.hip).  All rows (a row restriction is
+ * a masked d: rows with d == 0 are not read).  out: (m, m), both triangles, overwritten. */
+int tm_sparse_sandwich_direct_f32(const float *csr_data, const int32_t *csr_indices,
+                                  const int64_t *csr_indptr, int64_t n, int64_t m, const float *d,
+                                  float *out, void *stream);
+int tm_sparse_sandwich_direct_f64(const double *csr_data, const int32_t *csr_indices,
+                                  const int64_t *csr_indptr, int64_t n, int64_t m, const double *d,
+                                  double *out, void *stream);
 int tm_csr_dense_sandwich_rows_f32(const float *cm_data, const int32_t *cm_indices,
                                    const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
                                    const float *d_sel, int64_t n, int64_t m, const float *B, int64_t r,

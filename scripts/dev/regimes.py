@@ -12,6 +12,8 @@ CASES = [
     ("density 0.2 %", dict(density=0.002)),
     ("density 20 %", dict(density=0.20)),
     ("sparse 2048 cols @ 1.25 %", dict(k_sparse=2048, density=0.0125)),
+    ("sparse 4096 cols @ 0.2 %", dict(k_sparse=4096, density=0.002)),
+    ("sparse 8192 cols @ 0.05 %", dict(k_sparse=8192, density=0.0005)),
     ("sparse 100 cols @ 5 %", dict(k_sparse=100)),
     ("dense 64 cols", dict(k_dense=64)),
     ("dense 256 cols", dict(k_dense=256)),

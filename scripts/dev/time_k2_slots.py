@@ -6,7 +6,7 @@ from tabmat_amd import synth, _lib
 from tabmat_amd.ext import sparse as xs
 n = 2_000_000
 out = []
-for m, dens in ((512, 0.05), (512, 0.025), (512, 0.015), (512, 0.01), (512, 0.005), (2048, 0.0125), (2048, 0.004), (4096, 0.002)):
+for m, dens in ((512, 0.10), (512, 0.075), (512, 0.05), (512, 0.025), (512, 0.015), (512, 0.01), (512, 0.005), (2048, 0.0125), (2048, 0.004), (4096, 0.002)):
     sm = synth.sparse_block(n, m, dens, torch.float64, 7)
     d = torch.rand(n, dtype=torch.float64, device="cuda")
     A = sm._dev()

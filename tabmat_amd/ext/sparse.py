@@ -224,6 +224,32 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     return out
 
 
+def sparse_sandwich_direct(A: CsrDev, d):
+    """ext/sparse.pyx:17-77 for wide, very sparse blocks: one L2 atomic per pair
+    (csrc/sparse_direct.hip); cost follows the pairs, not rows x tiles."""
+    if A.m == 0 or A.n == 0:
+        return D.zeros((A.m, A.m), A.dtype)
+    out = D.out_buf((A.m, A.m), A.dtype)
+    D.same_float("sparse_sandwich_direct", A.data, d)
+    call(f"tm_sparse_sandwich_direct_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(A.indptr),
+         A.n, A.m, D.p(d), D.p(out), D.stream_ptr())
+    return out
+
+
+def direct_sandwich_pays(A: CsrDev) -> bool:
+    """Cost model (measured, profiles/r2_microbench.txt): the tiled kernel pays ~15 ps per row and
+    tile once rows have fewer than one nonzero per chunk, the direct one ~1 / 15e9 s per pair."""
+    nnz, n, m = int(A.data.numel()), A.n, A.m
+    if n == 0 or nnz == 0 or m <= 1024:
+        return False
+    nch = (m + 127) // 128
+    per_row = nnz / n
+    if per_row / nch > 0.6:
+        return False
+    pairs = n * per_row * (per_row + 1.0) / 2.0 * 1.3          # (+ spread of the row lengths)
+    return pairs / 15e9 < n * (nch * (nch + 1) / 2) * 15e-12
+
+
 def transpose_square_dot_weights(A: CsrDev, weights):
     """ext/sparse.pyx:262-282: out[j] = sum_i w[i] * A[i, j]**2."""
     out = D.zeros((A.m,), A.dtype)

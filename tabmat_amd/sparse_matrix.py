@@ -230,6 +230,21 @@ class SparseMatrix(MatrixBase):
     # ---- hot path -----------------------------------------------------------------------
     def _sandwich_dev(self, d, rows, cols):
         A = self._dev()
+        pays = getattr(self, "_direct_pays", None)
+        if pays is None:
+            pays = self._direct_pays = xs.direct_sandwich_pays(A)
+        if pays:
+            # wide and very sparse: cost per pair instead of per (row, tile)
+            if rows is not None:
+                dm = torch.zeros_like(d)
+                r64 = rows.to(torch.int64)
+                dm[r64] = d[r64]
+                d = dm
+            res = xs.sparse_sandwich_direct(A, d)
+            if cols is not None:
+                c64 = cols.to(torch.int64)
+                res = res[c64][:, c64].contiguous()
+            return res
         if A.data.numel() > 0 and A.data.numel() < 2**31 and self.shape[1] <= 128 * 32:
             if rows is not None and 0 < D.nlen(rows) <= ROW_LIST_FRACTION * self.shape[0]:
                 # short row list: the same pipeline over the selected rows only

@@ -702,3 +702,35 @@ def test_sparse_sandwich_few_nonzeros_per_chunk(n, m, dens, dtype):
     got = sm.sandwich(d, rows=rows)
     want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, rows, None)
     assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,dens", [(20_000, 4096, 0.002), (3001, 1500, 0.004), (64, 1100, 0.05)])
+def test_sparse_sandwich_direct(n, m, dens, dtype):
+    """Wide, very sparse blocks: one L2 atomic per pair (sparse_direct.hip) against the oracle,
+    with a few long rows (several 16-entry blocks per row) and zero weights."""
+    import tabmat_amd as tm
+    from oracle import oracle as orc
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=dens, format="lil", random_state=rng, dtype=np.float64)
+    for r in rng.choice(n, 12, replace=False):
+        cols = rng.choice(m, int(rng.integers(17, 90)), replace=False)
+        S[r, cols] = rng.standard_normal(len(cols))
+    S = sps.csc_matrix(S).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 10)] = 0
+    sm = tm.SparseMatrix(S)
+    got = D.to_host(xs.sparse_sandwich_direct(sm._dev(), D.to_dev(d)))
+    want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, None, None)
+    tol = 1e-10 if dtype == np.float64 else 3e-4
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    if xs.direct_sandwich_pays(sm._dev()):          # and through the public entry point
+        rows = np.sort(rng.choice(n, n // 3, replace=False))
+        cols = np.arange(0, m, 3)
+        got = sm.sandwich(d, rows=rows, cols=cols)
+        want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, rows, cols)
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
