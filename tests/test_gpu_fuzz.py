@@ -27,13 +27,13 @@ def _random_split(rng, dtype):
             blocks.append(tm.DenseMatrix(X))
             dense_parts.append(X.astype(np.float64))
         elif kind == "sparse":
-            m = int(rng.choice([1, 5, 33, 128, 200, 513]))
-            dens = float(rng.choice([0.0, 0.02, 0.05, 0.12, 0.4]))
+            m = int(rng.choice([1, 5, 33, 128, 200, 513, 1100, 2100]))
+            dens = float(rng.choice([0.0, 0.02, 0.05, 0.12, 0.4] if m < 1000 else [0.0008, 0.004, 0.02]))
             S = sps.random(n, m, density=dens, format="csc", random_state=rng).astype(dtype)
             blocks.append(tm.SparseMatrix(S))
             dense_parts.append(S.toarray().astype(np.float64))
         else:
-            ncat = int(rng.choice([1, 2, 5, 40, 300]))
+            ncat = int(rng.choice([1, 2, 5, 40, 300, 700, 5000]))
             drop = bool(rng.random() < 0.4)
             codes = rng.integers(0, ncat, n)
             missing = rng.random() < 0.3
