@@ -475,6 +475,20 @@ int tm_cat_dense_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart,
 int tm_cat_dense_sandwich_sorted_f64(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
                                      const int64_t *cat_bptr, int64_t n_cols, const double *d,
                                      const double *Y, int64_t m, double *out, void *stream);
+/* The dense-operand kernel above with a VALUE per entry: the sparse x dense term
+ * A^T diag(d) Y (ext/sparse.pyx:211-260 csr_dense_sandwich) on the CSC form of A, column by column
+ * -- for blocks with only a few nonzeros per row (wide and very sparse), where the slab / gather
+ * kernels pay per (slab, column group).  rows / vals: CSC row indices and values; the entries of a
+ * column cut into blocks of at most tm_cat_det_block_rows(): bstart (n_blocks + 1), blocks of column
+ * j = col_bptr[j] .. col_bptr[j + 1].  out: (n_cols, m), overwritten. */
+int tm_csc_dense_sandwich_sorted_f32(const int32_t *rows, const float *vals, const int64_t *bstart,
+                                     int64_t n_blocks, const int64_t *col_bptr, int64_t n_cols,
+                                     const float *d, const float *Y, int64_t m, float *out,
+                                     void *stream);
+int tm_csc_dense_sandwich_sorted_f64(const int32_t *rows, const double *vals, const int64_t *bstart,
+                                     int64_t n_blocks, const int64_t *col_bptr, int64_t n_cols,
+                                     const double *d, const double *Y, int64_t m, double *out,
+                                     void *stream);
 int tm_cat_sparse_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
                                       const int64_t *cat_bptr, int64_t n_cols, const float *d,
                                       const float *csr_data, const int32_t *csr_indices,

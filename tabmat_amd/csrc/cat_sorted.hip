@@ -20,10 +20,13 @@ namespace tmh {
 constexpr int CS_WAVES = 4;
 
 // ---- dense Y (C-ordered, 16-byte aligned rows): lane <-> VEC adjacent columns of a 64 * VEC chunk
+// `val` != NULL: entry i additionally carries a value (a SPARSE column instead of a one-hot level:
+// the column-sorted form of the sparse x dense term, see tm_csc_dense_sandwich_sorted_*).
 template <typename F>
 __global__ __launch_bounds__(CS_WAVES * 64) void cat_dense_sorted_kernel(
     const int32_t *__restrict__ perm, const int64_t *__restrict__ bstart, const F *__restrict__ d,
-    const F *__restrict__ Y, int64_t ld, int m, double *__restrict__ partial) {
+    const F *__restrict__ val, const F *__restrict__ Y, int64_t ld, int m,
+    double *__restrict__ partial) {
     constexpr int VEC = 16 / (int)sizeof(F);
     typedef F vec_t __attribute__((ext_vector_type(VEC)));
     __shared__ double red[CS_WAVES][64 * VEC];
@@ -44,6 +47,11 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cat_dense_sorted_kernel(
         for (int u = 0; u < 4; ++u) k[u] = perm[min(i + u, i1 - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) dk[u] = i + u < i1 ? d[k[u]] : F(0);
+        if (val != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dk[u] != F(0)) dk[u] *= val[min(i + u, i1 - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -132,8 +140,8 @@ __global__ __launch_bounds__(256) void cat_sorted_final_kernel(const double *__r
 
 template <typename F>
 static int run_cat_dense_sorted(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
-                                const int64_t *cat_bptr, int64_t n_cols, const F *d, const F *Y,
-                                int64_t m, F *out, hipStream_t st) {
+                                const int64_t *cat_bptr, int64_t n_cols, const F *d, const F *val,
+                                const F *Y, int64_t m, F *out, hipStream_t st) {
     if (n_cols == 0 || m == 0) return TM_OK;
     constexpr int VEC = 16 / (int)sizeof(F);
     if ((reinterpret_cast<uintptr_t>(Y) & 15) != 0 || m % VEC != 0 || m < VEC) {
@@ -149,7 +157,7 @@ static int run_cat_dense_sorted(const int32_t *perm, const int64_t *bstart, int6
         prof_begin(st);
         hipLaunchKernelGGL((cat_dense_sorted_kernel<F>),
                            dim3((unsigned)n_blocks, (unsigned)ceil_div(m, 64 * VEC)), dim3(CS_WAVES * 64),
-                           0, st, perm, bstart, d, Y, m, (int)m, partial);
+                           0, st, perm, bstart, d, val, Y, m, (int)m, partial);
         prof_end(st);
         TM_LAUNCH_CHECK();
     }
@@ -195,13 +203,27 @@ extern "C" {
 int tm_cat_dense_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
                                      const int64_t *cat_bptr, int64_t n_cols, const float *d,
                                      const float *Y, int64_t m, float *out, void *stream) {
-    return tmh::run_cat_dense_sorted<float>(perm, bstart, n_blocks, cat_bptr, n_cols, d, Y, m, out,
-                                            tmh::as_stream(stream));
+    return tmh::run_cat_dense_sorted<float>(perm, bstart, n_blocks, cat_bptr, n_cols, d, nullptr, Y, m,
+                                            out, tmh::as_stream(stream));
 }
 int tm_cat_dense_sandwich_sorted_f64(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,
                                      const int64_t *cat_bptr, int64_t n_cols, const double *d,
                                      const double *Y, int64_t m, double *out, void *stream) {
-    return tmh::run_cat_dense_sorted<double>(perm, bstart, n_blocks, cat_bptr, n_cols, d, Y, m, out,
+    return tmh::run_cat_dense_sorted<double>(perm, bstart, n_blocks, cat_bptr, n_cols, d, nullptr, Y, m,
+                                             out, tmh::as_stream(stream));
+}
+int tm_csc_dense_sandwich_sorted_f32(const int32_t *rows, const float *vals, const int64_t *bstart,
+                                     int64_t n_blocks, const int64_t *col_bptr, int64_t n_cols,
+                                     const float *d, const float *Y, int64_t m, float *out,
+                                     void *stream) {
+    return tmh::run_cat_dense_sorted<float>(rows, bstart, n_blocks, col_bptr, n_cols, d, vals, Y, m, out,
+                                            tmh::as_stream(stream));
+}
+int tm_csc_dense_sandwich_sorted_f64(const int32_t *rows, const double *vals, const int64_t *bstart,
+                                     int64_t n_blocks, const int64_t *col_bptr, int64_t n_cols,
+                                     const double *d, const double *Y, int64_t m, double *out,
+                                     void *stream) {
+    return tmh::run_cat_dense_sorted<double>(rows, bstart, n_blocks, col_bptr, n_cols, d, vals, Y, m, out,
                                              tmh::as_stream(stream));
 }
 int tm_cat_sparse_sandwich_sorted_f32(const int32_t *perm, const int64_t *bstart, int64_t n_blocks,

@@ -96,6 +96,37 @@ class CsrDev:
             self._cm = cm
         return cm
 
+    def csc_blocks(self):
+        """(rows int32, vals, bstart int64, n_blocks, col_bptr int64): the CSC form of the block with
+        every column's entries cut into blocks of at most tm_cat_det_block_rows() -- the input of
+        tm_csc_dense_sandwich_sorted_*.  Built once (a stable device sort by column), cached."""
+        cb = getattr(self, "_cscb", None)
+        if cb is None:
+            from .._lib import lib
+
+            blk = int(lib().tm_cat_det_block_rows())
+            dev = self.data.device
+            nnz = int(self.data.numel())
+            counts = self.indptr[1:] - self.indptr[:-1]
+            rows = torch.repeat_interleave(torch.arange(self.n, device=dev, dtype=torch.int32), counts)
+            order = torch.sort(self.indices.to(torch.int64), stable=True).indices    # rows stay ascending
+            cnt = torch.bincount(self.indices.to(torch.int64), minlength=self.m) if nnz else \
+                torch.zeros(self.m, dtype=torch.int64, device=dev)
+            nb = torch.div(cnt + blk - 1, blk, rounding_mode="floor")
+            col_bptr = torch.zeros(self.m + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(nb, dim=0, out=col_bptr[1:])
+            n_blocks = int(col_bptr[-1].item())
+            seg0 = torch.cumsum(cnt, dim=0) - cnt
+            col_of_blk = torch.repeat_interleave(torch.arange(self.m, device=dev), nb)
+            within = torch.arange(n_blocks, device=dev) - col_bptr[:-1][col_of_blk]
+            bstart = torch.empty(n_blocks + 1, dtype=torch.int64, device=dev)
+            bstart[:-1] = seg0[col_of_blk] + within * blk
+            bstart[-1] = nnz
+            cb = (rows[order].contiguous(), self.data[order].contiguous(), bstart.contiguous(),
+                  n_blocks, col_bptr.contiguous())
+            self._cscb = cb
+        return cb
+
     def take_rows(self, kind, *arg) -> "CsrDev":
         """Row-indexed copy built on the device: kind "slice" (lo, hi) or "index" (row ids)."""
         dev = self.data.device

@@ -224,6 +224,20 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     return out
 
 
+def csc_dense_sandwich_sorted(A: CsrDev, B: DenseDev, d):
+    """ext/sparse.pyx:211-260 for blocks with only a few nonzeros per row: column by column on
+    the CSC form, a workgroup sums d[k] * A[k, j] * B[k, :] over (a block of) column j's entries
+    (csrc/cat_sorted.hip).  Cost ~ one row of B per nonzero, independent of the width of A."""
+    if A.m == 0 or B.m == 0:
+        return D.zeros((A.m, B.m), A.dtype)
+    rows, vals, bstart, n_blocks, col_bptr = A.csc_blocks()
+    out = D.out_buf((A.m, B.m), A.dtype)
+    D.same_float("csc_dense_sandwich_sorted", vals, B.buf, d)
+    call(f"tm_csc_dense_sandwich_sorted_{D.fsuf(vals)}", D.p(rows), D.p(vals), D.p(bstart),
+         int(n_blocks), D.p(col_bptr), A.m, D.p(d), D.p(B.buf), B.m, D.p(out), D.stream_ptr())
+    return out
+
+
 def sparse_sandwich_direct(A: CsrDev, d):
     """ext/sparse.pyx:17-77 for wide, very sparse blocks: one L2 atomic per pair
     (csrc/sparse_direct.hip); cost follows the pairs, not rows x tiles."""

@@ -29,6 +29,7 @@ ELL_MAX_PAD = 8.0
 # proportional to len(rows)); above it the full-pass kernels with a masked d are cheaper
 # (scripts/dev/time_rows.py: break-even near one half for the self sandwich, one quarter for the
 # sparse x dense term whose row-list form pays two LDS atomics per nonzero).
+SORTED_K3_NNZ_PER_ROW = 6.0      # below: sparse x dense on the column-sorted kernel (wide blocks)
 ROW_LIST_FRACTION = 0.5
 ROW_LIST_FRACTION_K3 = 0.25
 
@@ -307,6 +308,15 @@ class SparseMatrix(MatrixBase):
                     r64 = rows.to(torch.int64)
                     dm[r64] = d[r64]
                     d = dm
+                if (A.data.numel() <= SORTED_K3_NNZ_PER_ROW * self.shape[0] and self.shape[1] >= 1024
+                        and xs.ell_supported(Bd)):
+                    # a few nonzeros per row in a wide block: column by column on the CSC form
+                    res = xs.csc_dense_sandwich_sorted(A, Bd, d)
+                    if L_cols is not None:
+                        res = res[L_cols.to(torch.int64)]
+                    if R_cols is not None:
+                        res = res[:, R_cols.to(torch.int64)]
+                    return res
                 lg = self._lg() if (Bd.m > 64 and xs.ell_supported(Bd)) else None
                 ell = None
                 if lg is None and xs.ell_supported(Bd):

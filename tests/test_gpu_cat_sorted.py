@@ -77,3 +77,31 @@ def test_excluded_rows_may_hold_inf():
     B2[excl[50:90], 7] = np.nan
     got = cat._cross_sandwich(tm.DenseMatrix(B2), d, rows)
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,dens,k", [(30_011, 2048, 0.001, 72), (5000, 1500, 0.003, 128), (64, 1100, 0.002, 16)])
+def test_column_sorted_sparse_dense(n, m, dens, k, dtype):
+    """Sparse x dense for wide blocks with a few nonzeros per row: the column-sorted kernel
+    (tm_csc_dense_sandwich_sorted_*) directly and through SparseMatrix._cross_sandwich."""
+    import tabmat_amd as tm
+    from oracle import oracle as orc
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng, dtype=np.float64)
+    S.data -= 0.5
+    S = S.astype(dtype)
+    B = rng.standard_normal((n, k)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 8)] = 0
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    want = orc.csr_dense_sandwich(sps.csr_matrix(S), B, d, None, None, None)
+    got = D.to_host(xs.csc_dense_sandwich_sorted(sm._dev(), dm._dev_c(), D.to_dev(d)))
+    assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30)
+    rows = np.sort(rng.choice(n, n // 2, replace=False))
+    got = sm._cross_sandwich(dm, d, rows, np.arange(0, m, 2), np.arange(1, k, 3))
+    want = orc.csr_dense_sandwich(sps.csr_matrix(S), B, d, rows, np.arange(0, m, 2), np.arange(1, k, 3))
+    assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30)
