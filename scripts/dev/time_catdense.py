@@ -1,0 +1,16 @@
+"""Fused cat x dense (multi_cat_dense_wide_kernel) at cfg4 size with the library in TABMAT_AMD_LIB."""
+import os, sys, ctypes as C, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tabmat_amd import synth, _lib
+from tabmat_amd.ext import split as xsplit
+n = 10_000_000
+dm = synth.dense_block(n, 128, torch.float64, 3)
+cats = [synth.cat_block(n, c, 2000 + i) for i, c in enumerate((256, 96, 32))]
+d = torch.rand(n, dtype=torch.float64, device="cuda")
+cl = [(c._dev(), c.shape[1], c.drop_first) for c in cats]
+_lib.call("tm_profile_enable", 1)
+ts = []
+for _ in range(6):
+    out = xsplit.multi_cat_dense_sandwich(cl, d, dm._dev_c())
+    ms = C.c_float(0); _lib.call("tm_profile_last_ms", C.byref(ms)); ts.append(ms.value)
+print(f"{os.path.basename(os.environ.get('TABMAT_AMD_LIB', 'default')):20s} min {min(ts):.3f} ms  median {sorted(ts)[3]:.3f}  checksum {out.sum().item():.10e}", flush=True)
