@@ -105,3 +105,22 @@ def test_column_sorted_sparse_dense(n, m, dens, k, dtype):
     got = sm._cross_sandwich(dm, d, rows, np.arange(0, m, 2), np.arange(1, k, 3))
     want = orc.csr_dense_sandwich(sps.csr_matrix(S), B, d, rows, np.arange(0, m, 2), np.arange(1, k, 3))
     assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30)
+
+
+def test_sorted_cat_sparse_wide_output():
+    """More sparse columns than one LDS row of doubles holds (8192): several column passes."""
+    import tabmat_amd as tm
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import split as xsplit
+
+    rng = np.random.default_rng(21)
+    n, m, levels = 6000, 9100, 900
+    codes = rng.integers(0, levels, n).astype(np.int32)
+    S = sps.random(n, m, density=0.002, format="csr", random_state=rng, dtype=np.float64)
+    d = rng.random(n)
+    cat = tm.CategoricalMatrix(codes, categories=np.arange(levels))
+    got = D.to_host(xsplit.cat_sparse_sandwich_sorted(cat._det_plan(), levels, D.to_dev(d),
+                                                      tm.SparseMatrix(sps.csc_matrix(S))._dev()))
+    oh = sps.csr_matrix((d, (codes, np.arange(n))), shape=(levels, n))
+    want = (oh @ S).toarray()
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
