@@ -43,6 +43,8 @@ N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
 # (9.4 vs 9.1 ms at cfg4) -- the f64 MFMAs and the gather's f64 FMAs share the DP pipe, the
 # matrix work does not hide in the gather's LDS waits.
 FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
+# a categorical block's diagonal as the row sum of its table with a complete partner categorical
+DIAG_FROM_PAIRS = True
 
 
 class _StreamFan:
@@ -439,6 +441,26 @@ class SplitMatrix(MatrixBase):
                     done.add((min(i, j), max(i, j)))
                     self_done.add(i)
                     break
+        # categorical x categorical tables first: the diagonal of a categorical block is the row sum
+        # of its table with any COMPLETE partner (every row has exactly one level there), which
+        # saves its histogram pass
+        cat_diag = {}
+        complete = [isinstance(m, CategoricalMatrix) and not m.drop_first and not m._has_missings
+                    and sub_d[k] is None and not empty[k] for k, m in enumerate(mats)]
+        for i, mi in enumerate(mats):
+            if empty[i] or not isinstance(mi, CategoricalMatrix):
+                continue
+            for j in range(i + 1, len(mats)):
+                if empty[j] or not isinstance(mats[j], CategoricalMatrix) or (i, j) in done:
+                    continue
+                with fan.lane():
+                    res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
+                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
+                    done.add((i, j))
+                    if DIAG_FROM_PAIRS and complete[j] and i not in cat_diag:
+                        cat_diag[i] = res.sum(dim=1)
+                    if DIAG_FROM_PAIRS and complete[i] and j not in cat_diag:
+                        cat_diag[j] = res.sum(dim=0)
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
@@ -446,7 +468,8 @@ class SplitMatrix(MatrixBase):
                 if i in self_done:
                     pass
                 elif isinstance(mi, CategoricalMatrix):
-                    diag = mi._sandwich_diag_dev(d, rows, sub_d[i])
+                    diag = cat_diag[i] if (i in cat_diag and N_STREAMS == 1) else \
+                        mi._sandwich_diag_dev(d, rows, sub_d[i])
                     if colsum is not None:
                         colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
                     xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
