@@ -2,6 +2,8 @@
 /root/reference/src/tabmat/sparse_matrix.py).  Kernels: tabmat_amd/csrc/sparse.hip."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from scipy import sparse as sps
@@ -29,6 +31,7 @@ ELL_MAX_PAD = 8.0
 # proportional to len(rows)); above it the full-pass kernels with a masked d are cheaper
 # (scripts/dev/time_rows.py: break-even near one half for the self sandwich, one quarter for the
 # sparse x dense term whose row-list form pays two LDS atomics per nonzero).
+PART_NNZ = int(os.environ.get("TABMAT_AMD_PART_NNZ", str(2**31 - 2**24)))   # see split_matrix._parts
 SORTED_K3_NNZ_PER_ROW = 6.0      # below: sparse x dense on the column-sorted kernel (wide blocks)
 ROW_LIST_FRACTION = 0.5
 ROW_LIST_FRACTION_K3 = 0.25
@@ -229,7 +232,41 @@ class SparseMatrix(MatrixBase):
         return type(self)(self._host().multiply(other))
 
     # ---- hot path -----------------------------------------------------------------------
+    def _row_parts(self):
+        """None, or [(r0, r1, SparseMatrix)] row slices with fewer than PART_NNZ nonzeros each (the
+        twins index entries with 32 bits)."""
+        parts = self.__dict__.get("_parts_cache", False)
+        if parts is False:
+            parts = None
+            ptr = self._dev().indptr
+            nnz = int(self._dev().data.numel())
+            if nnz >= PART_NNZ:
+                n = self.shape[0]
+                k = -(-nnz // max(1, int(0.8 * PART_NNZ)))
+                targets = torch.arange(1, k, device=ptr.device, dtype=torch.int64) * nnz // k
+                cuts = sorted(set([0] + torch.searchsorted(ptr, targets).clamp_(0, n).tolist() + [n]))
+                parts = [(a, b, self[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            self.__dict__["_parts_cache"] = parts
+        return parts
+
     def _sandwich_dev(self, d, rows, cols):
+        parts = self._row_parts()
+        if parts is not None:
+            out = None
+            for a, b, part in parts:
+                r = None
+                if rows is not None:
+                    r64 = rows.to(torch.int64)
+                    sel = r64[(r64 >= a) & (r64 < b)]
+                    if sel.numel() == 0:
+                        continue
+                    r = (sel - a).to(torch.int32)
+                res = part._sandwich_dev(d[a:b], r, cols)
+                out = res if out is None else out + res
+            if out is None:
+                k = self.shape[1] if cols is None else D.nlen(cols)
+                out = D.zeros((k, k), d.dtype)
+            return out
         A = self._dev()
         pays = getattr(self, "_direct_pays", None)
         if pays is None:

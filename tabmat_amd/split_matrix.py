@@ -45,6 +45,10 @@ N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
 FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
 DIAG_FROM_PAIRS = True
+# Entry indices inside one sparse block's twins are 32-bit: a SplitMatrix whose sparse block holds
+# this many nonzeros or more is worked on in ROW PARTS (the sandwich is a sum over rows), each with
+# twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
+from . import sparse_matrix as _spm      # PART_NNZ lives there (also used by SparseMatrix itself)
 
 
 class _StreamFan:
@@ -215,6 +219,12 @@ class SplitMatrix(MatrixBase):
         return self._dev_indices
 
     def to_device(self):
+        parts = self._parts()
+        if parts is not None:
+            for _, _, p in parts:
+                p.to_device()
+            self._full_dev_indices()
+            return self
         dense_w = [m.shape[1] for m in self.matrices if isinstance(m, DenseMatrix)]
         for m in self.matrices:
             if isinstance(m, SparseMatrix):
@@ -378,11 +388,71 @@ class SplitMatrix(MatrixBase):
             return xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
         return None
 
+    def _parts(self):
+        """None, or [(r0, r1, SplitMatrix over rows r0 .. r1 - 1)] when a sparse block holds PART_NNZ
+        nonzeros or more.  The parts are device row slices (views of the block storage); their twins
+        are built per part."""
+        parts = self.__dict__.get("_row_parts", False)
+        if parts is False:
+            parts = None
+            big = [m for m in self.matrices
+                   if isinstance(m, SparseMatrix) and m._dev().data.numel() >= _spm.PART_NNZ]
+            if big:
+                n = self.shape[0]
+                lead = max(big, key=lambda m: m._dev().data.numel())
+                ptr = lead._dev().indptr
+                nnz = int(ptr[-1].item())
+                k = -(-nnz // max(1, int(0.8 * _spm.PART_NNZ)))
+                while True:
+                    targets = torch.arange(1, k, device=ptr.device, dtype=torch.int64) * nnz // k
+                    cuts = [0] + torch.searchsorted(ptr, targets).clamp_(0, n).tolist() + [n]
+                    cuts = sorted(set(int(c) for c in cuts))
+                    ok = all(int((m._dev().indptr[cuts[1:]] - m._dev().indptr[cuts[:-1]]).max().item())
+                             < _spm.PART_NNZ for m in big)
+                    if ok or k >= n:
+                        break
+                    k += 1
+                parts = [(a, b, self[a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            self.__dict__["_row_parts"] = parts
+        return parts
+
+    def _sandwich_parts(self, parts, d, rows, cols_host, colsum):
+        """Sum of the parts' sandwiches (and of their column sums)."""
+        out = None
+        for a, b, part in parts:
+            r = None
+            if rows is not None:
+                r64 = rows.to(torch.int64)
+                sel = r64[(r64 >= a) & (r64 < b)]
+                if sel.numel() == 0:
+                    continue
+                r = (sel - a).to(torch.int32)
+            cs = [None] * len(self.matrices) if colsum is not None else None
+            res = part._sandwich_dev(d[a:b], r, cols_host, None, cs)
+            out = res if out is None else out + res
+            if colsum is not None:
+                for i, c in enumerate(cs):
+                    if c is None:
+                        colsum[i] = False            # not available for every part: recompute
+                    elif colsum[i] is not False:
+                        colsum[i] = c if colsum[i] is None else colsum[i] + c
+        if colsum is not None:
+            for i, c in enumerate(colsum):
+                if c is False:
+                    colsum[i] = None
+        if out is None:
+            _, _, n_cols = self._sandwich_plan(cols_host)
+            out = D.zeros((n_cols, n_cols), torch.float64)
+        return out
+
     def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None):
         """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
         Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
         colsum: optional list (one slot per block) that receives X_block' d[rows] (restricted to
         the block's columns) wherever it falls out of the sandwich for free."""
+        parts = self._parts()
+        if parts is not None:
+            return self._sandwich_parts(parts, d, rows, cols_host, colsum)
         pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
         out = D.zeros((n_cols, n_cols), torch.float64)
         mats = self.matrices
