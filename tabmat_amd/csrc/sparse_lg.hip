@@ -144,7 +144,7 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ xptr,
     const F *__restrict__ xvals, const unsigned *__restrict__ xkoff, int n_groups, int64_t n_slabs,
     int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r, int nB,
-    const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_syrk) {
+    const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_syrk, int *__restrict__ prog) {
     static_assert(!SYRK || (sizeof(F) == 8 && NG == 2), "fused syrk: f64, two groups per wave");
     const uint4 *__restrict__ xent = reinterpret_cast<const uint4 *>(xkoff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -295,10 +295,18 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     unsigned next_base = lds_base + (unsigned)L::BUFB;
     const F *dl = dl_all;
     const F *dl_next = dl_all + L::DLN;
+    // soft lockstep of the workgroups that share a slab range (blockIdx.z): nobody runs more than one
+    // slab ahead of its neighbour, so the second reader of a slab of B finds it in the XCD's L2
+    int *const my_prog = prog ? prog + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z : nullptr;
+    const int zn = (int)((blockIdx.z + 1) % gridDim.z);
+    bool waiting = true;               // given up for good after one timeout (neighbour not resident)
     for (int w = 0; w < ns; ++w) {
         const int buf = w & 1;
         const bool more = w + 1 < ns;
         if (more) load_d();
+        int pseen = 0x7fffffff;
+        if (my_prog != nullptr && tid == 0 && gridDim.z > 1)
+            pseen = __hip_atomic_load(my_prog + zn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (SYRK) fragments of K step s -> registers; the MFMAs of the step held in the registers
         // per-iteration fragment bases, opaque to the optimiser: with the step offsets as
         // IMMEDIATES of the ds_read (s * 4 * RSB <= 32256 from one of two bases) nothing is
@@ -515,6 +523,17 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
             advance();
             finish_slab(buf ^ 1);
         }
+        if (my_prog != nullptr && tid == 0 && gridDim.z > 1) {
+            __hip_atomic_store(my_prog + blockIdx.z, w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (pseen was read at the top of the iteration: the round trip is hidden; a neighbour that
+            // is not resident must not hang us: bounded spin)
+            int spin = 0;
+            for (; waiting && pseen < w && spin < 2048; ++spin) {
+                __builtin_amdgcn_s_sleep(8);
+                pseen = __hip_atomic_load(my_prog + zn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (spin == 2048) waiting = false;
+        }
         __syncthreads();
         const unsigned tb = slab_base; slab_base = next_base; next_base = tb;
         const F *td = dl; dl = dl_next; dl_next = td;
@@ -628,13 +647,22 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     const int64_t stride = m * LG_W;  // per (part, block)
     const size_t tmp_bytes = (sizeof(F) * (size_t)(n_parts * stride) + 255) / 256 * 256;
     const size_t part_bytes = (sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 255) / 256 * 256;
-    const size_t syrk_bytes = fused ? sizeof(F) * (size_t)(nblk * 16 * 3 * 256) : 0;
+    const size_t syrk_bytes = (fused ? sizeof(F) * (size_t)(nblk * 16 * 3 * 256) : 0) + 256;
+    // soft lockstep of the column-half workgroups (21.2 -> 18.1 GB of HBM traffic at cfg4, same
+    // time); TABMAT_AMD_LG_LOCKSTEP=0 switches it off
+    static const int lockstep = getenv("TABMAT_AMD_LG_LOCKSTEP") ? atoi(getenv("TABMAT_AMD_LG_LOCKSTEP")) : 1;
+    const size_t prog_bytes = (sizeof(int) * (size_t)(n_parts * nblk * nz) + 255) / 256 * 256;
     void *wsv = nullptr;
-    int rc = get_workspace(tmp_bytes + part_bytes + syrk_bytes + 256, &wsv, st);
+    int rc = get_workspace(tmp_bytes + part_bytes + syrk_bytes + prog_bytes + 256, &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     F *ws_syrk = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes);
+    int *prog = nullptr;
+    if (lockstep && nz > 1) {
+        prog = reinterpret_cast<int *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes + syrk_bytes);
+        TM_HIP(hipMemsetAsync(prog, 0, prog_bytes, st));
+    }
     const size_t lds = (size_t)LgLds<F>::TOTAL;
     static const int ng = getenv("TABMAT_AMD_LG_NG") ? atoi(getenv("TABMAT_AMD_LG_NG")) : 1;
     auto kern = ng == 2 ? &csr_dense_lg_kernel<F, 2, 2, false>
@@ -652,7 +680,7 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(threads),
                        lds, st, vals, koff, xptr, xvals, xkoff, n_groups, n_slabs, spb, B, n, r,
-                       (int)nB, d, ws, ws_syrk);
+                       (int)nB, d, ws, ws_syrk, prog);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
