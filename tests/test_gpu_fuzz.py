@@ -85,6 +85,18 @@ def test_random_split_products(seed):
     close(X.sandwich(d, rows, cols), Er.T @ (d64[rows, None] * Er))
     close(X.matvec(v, cols), E[:, cols] @ v64[cols])
     close(X.transpose_matvec(w, rows, cols), Er.T @ w64[rows])
+    # a short row list (row-list kernels: cost proportional to len(rows)), with repeats allowed
+    few = rng.choice(n, size=max(1, n // 9), replace=False).astype(np.int64)
+    Ef = E[few]
+    close(X.sandwich(d, few), Ef.T @ (d64[few, None] * Ef))
     if isinstance(X, tm.SplitMatrix):
         Xd = X.to_device()
         close(Xd.sandwich(d), E.T @ (d64[:, None] * E))
+        # the standardized view on the same blocks (one pass for the inner sandwich and X' d)
+        shift = rng.standard_normal(p)
+        mult = rng.random(p) + 0.5
+        Es = E * mult + shift
+        got = tm.StandardizedMatrix(X, shift, mult).sandwich(d, rows, cols)
+        want = Es[np.ix_(rows, cols)].T @ (d64[rows, None] * Es[np.ix_(rows, cols)])
+        scale = max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(np.asarray(got) - want).max()) / scale < (tol if dtype == np.float64 else 5e-3)
