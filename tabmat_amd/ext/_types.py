@@ -78,17 +78,20 @@ class CsrDev:
             dev = self.data.device
             counts = self.indptr[1:] - self.indptr[:-1]
             rows = torch.repeat_interleave(torch.arange(self.n, device=dev, dtype=torch.int64), counts)
-            key = torch.div(self.indices.to(torch.int64), ch, rounding_mode="floor") * self.n + rows
-            del rows
-            # CSR rows are column-sorted: a STABLE sort by (chunk, row) keeps the column order
-            key_sorted, perm = torch.sort(key, stable=True)
-            del key
+            chunk = torch.div(self.indices, ch, rounding_mode="floor")
+            # CSR is row-major with ascending columns: a STABLE sort by the chunk number alone is
+            # the (chunk, row, column) order -- an 8- or 16-bit radix sort instead of a 64-bit one
+            small = chunk.to(torch.uint8 if nch <= 255 else torch.int16 if nch < 2**15 else torch.int32)
+            perm = torch.sort(small, stable=True).indices
+            del small
             cm_data = self.data[perm].contiguous()
             cm_ind = self.indices[perm].contiguous()
             del perm
-            per = torch.bincount(key_sorted, minlength=nch * self.n) if nnz else \
+            key = chunk.to(torch.int64) * self.n + rows
+            del rows, chunk
+            per = torch.bincount(key, minlength=nch * self.n) if nnz else \
                 torch.zeros(nch * self.n, dtype=torch.int64, device=dev)
-            del key_sorted
+            del key
             start = (torch.cumsum(per, dim=0) - per).view(nch, self.n)
             ends = torch.cat([start[1:, 0], torch.tensor([nnz], device=dev, dtype=torch.int64)])
             cptr = torch.cat([start, ends[:, None]], dim=1).to(torch.int32).contiguous()
