@@ -56,7 +56,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cat_dense_sorted_kernel(
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) y[u][v] = F(0);
-            if (dk[u] != F(0)) y[u] = *reinterpret_cast<const vec_t *>(Y + k[u] * ld + jc);
+            if (dk[u] != F(0))
+                y[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Y + k[u] * ld + jc));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)

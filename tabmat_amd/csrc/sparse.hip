@@ -124,7 +124,8 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
         for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
             const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
 #pragma unroll 4
-            for (int e = lane; e < cnt; e += 64) prod[e] = data[c0 + e] * vl[ind[c0 + e]];
+            for (int e = lane; e < cnt; e += 64)
+                prod[e] = __builtin_nontemporal_load(data + c0 + e) * vl[__builtin_nontemporal_load(ind + c0 + e)];
             __builtin_amdgcn_wave_barrier();
             const int lo = (int)(max(rlo, c0) - c0);
             const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
