@@ -398,6 +398,35 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
                                           double *out, void *stream);
 
 /* =====================================================================================
+ * ALL categorical x categorical blocks (and the categorical diagonals) of one sandwich in one pass
+ * over the codes (ext/split.pyx:83-111 sandwich_cat_cat, ext/categorical.pyx:183-218): the pair
+ * tables are packed into bundles of at most tm_multi_cat_pairs_max_bins() doubles (one LDS tile).
+ * h_codes / h_ncols / h_drop_first: host arrays of n_cats (<= 32) device code pointers, column
+ * counts and drop_first flags (as for tm_multi_cat_dense_sandwich_*).  pair_list: device int32:
+ * word 0 = words per bundle row (a multiple of 4), words 1..3 unused, then one row per bundle:
+ * {bit mask of the categoricals its tables use, number of tables, 0, 0} followed by 4 words per
+ * table {i, j, offset of the table inside the bundle's tile, L_j} with i <= j; table (i, j) is
+ * L_i x L_j row-major, table (i, i) the L_i diagonal entries.  tables: device double
+ * [n_bundles][bins], overwritten with the tables.  desc: device int64 [n_pairs][6] =
+ * {offset into tables, L_i, L_j, first entry of block i's / block j's positions in pos, diagonal
+ * flag}; pos: device int64 positions of the blocks' columns in the p x p float64 `out`
+ * (out[pos_i[a], pos_j[b]] = table[a, b] and its mirror; out may be NULL: tables only).
+ * rows: int32 device row list or NULL.
+ * ===================================================================================== */
+int tm_multi_cat_pairs_max_bins(void);
+int tm_multi_cat_pairs_max_tables(void);   /* tables per bundle */
+int tm_multi_cat_pairs_f32(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first,
+                           int n_cats, int64_t n, const float *d, const int32_t *rows, int64_t n_rows,
+                           const int32_t *pair_list, int n_bundles, int64_t bins, const int64_t *desc,
+                           int64_t n_pairs, const int64_t *pos, double *tables, double *out, int64_t p,
+                           void *stream);
+int tm_multi_cat_pairs_f64(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first,
+                           int n_cats, int64_t n, const double *d, const int32_t *rows, int64_t n_rows,
+                           const int32_t *pair_list, int n_bundles, int64_t bins, const int64_t *desc,
+                           int64_t n_pairs, const int64_t *pos, double *tables, double *out, int64_t p,
+                           void *stream);
+
+/* =====================================================================================
  * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block
  * result into the float64 p x p output at the block's global column positions,
  *   out[ri[a], ci[b]] = src[a, b]  (and the transpose when mirror != 0);

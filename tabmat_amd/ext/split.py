@@ -85,6 +85,77 @@ def cat_sparse_sandwich_sorted(plan, n_cols, d, S: CsrDev):
     return res
 
 
+class CatPairsPlan:
+    """Packing of the categorical x categorical tables (and diagonals) of a SplitMatrix into
+    LDS-sized bundles for tm_multi_cat_pairs_* -- static per matrix, built once.
+    cats: list of (block id, n_cols); pairs listed as (block i, block j) with i <= j."""
+
+    def __init__(self, cats, pos_arrays):
+        from .._lib import lib
+        import torch
+
+        self.cat_ids = [c[0] for c in cats]
+        k = len(cats)
+        cap = int(lib().tm_multi_cat_pairs_max_bins())
+        max_tab = int(lib().tm_multi_cat_pairs_max_tables())
+        sizes = [int(c[1]) for c in cats]
+        # greedy bundles over the tables that fit one tile (diagonals first: they are tiny)
+        # (a table is bundled only when at least four of its size share a tile: a bundle with one
+        # or two big tables is no better than the per-pair kernel, which has the whole chip)
+        items = [(a, a, sizes[a]) for a in range(k) if sizes[a] <= cap] + \
+                [(a, b, sizes[a] * sizes[b]) for b in range(k) for a in range(b)
+                 if sizes[a] * sizes[b] <= cap // 4]
+        bundles, fill = [[]], 0
+        for a, b, sz in items:
+            if sz == 0:
+                continue
+            if fill + sz > cap or len(bundles[-1]) >= max_tab:
+                bundles.append([])
+                fill = 0
+            bundles[-1].append((a, b, fill, sz))
+            fill += sz
+        bundles = [bd for bd in bundles if bd]
+        self.n_bundles = len(bundles)
+        self.bins = max((bd[-1][2] + bd[-1][3] for bd in bundles), default=1)
+        stride = 4 + 4 * max((len(bd) for bd in bundles), default=0)
+        pl = np.zeros(4 + max(self.n_bundles, 1) * stride, dtype=np.int64)
+        pl[0] = stride
+        pstart = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        desc, self.pairs = [], []
+        for y, bd in enumerate(bundles):
+            row = 4 + y * stride
+            mask = 0
+            for t, (a, b, o, sz) in enumerate(bd):
+                pl[row + 4 + 4 * t: row + 8 + 4 * t] = (a, b, o, sizes[b])
+                mask |= (1 << a) | (1 << b)
+                desc.append([y * self.bins + o, sizes[a], sizes[b], pstart[a], pstart[b], int(a == b)])
+                self.pairs.append((self.cat_ids[a], self.cat_ids[b], y * self.bins + o, sizes[a], sizes[b]))
+            pl[row] = mask
+            pl[row + 1] = len(bd)
+        self.pair_list = D.to_dev(pl.astype(np.uint32).view(np.int32))
+        self.desc = D.to_dev(np.asarray(desc, dtype=np.int64).reshape(-1, 6))
+        self.pos = torch.cat([p.to(torch.int64) for p in pos_arrays]) if pos_arrays else \
+            D.zeros((0,), torch.int64)
+        self.n_pairs = len(desc)
+        self.covered = {(min(i, j), max(i, j)) for i, j, *_ in self.pairs}
+
+
+def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out):
+    """All bundled categorical x categorical tables + diagonals in one pass, scattered into the
+    float64 (p, p) `out`; returns the tables buffer (float64, [n_bundles * bins])."""
+    import torch
+
+    tables = D.out_buf((max(plan.n_bundles, 1) * plan.bins,), torch.float64)
+    if plan.n_pairs == 0:
+        return tables
+    codes, ncols, drop, n = _cat_args(cats)
+    nrows = int(cats[0][0].numel())
+    call(f"tm_multi_cat_pairs_{D.fsuf(d)}", codes, ncols, drop, n, nrows, D.p(d), D.p(rows),
+         D.nlen(rows), D.p(plan.pair_list), plan.n_bundles, plan.bins, D.p(plan.desc), plan.n_pairs,
+         D.p(plan.pos), D.p(tables), D.p(out), out.shape[0], D.stream_ptr())
+    return tables
+
+
 def scatter_block(src, ri, ci, out, mirror=False, diag=False):
     """out[ri[a], ci[b]] = src[a, b] (+ transpose); diag: out[ri[a], ri[a]] += src[a].
     Device form of split_matrix.py:341-354."""

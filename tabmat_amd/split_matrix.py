@@ -45,6 +45,8 @@ N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
 FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
 DIAG_FROM_PAIRS = True
+# all small categorical x categorical tables + diagonals in one launch (tm_multi_cat_pairs_*)
+CAT_PAIRS_FUSED = os.environ.get("TABMAT_AMD_CAT_PAIRS", "1") != "0"
 # Entry indices inside one sparse block's twins are 32-bit: a SplitMatrix whose sparse block holds
 # this many nonzeros or more is worked on in ROW PARTS (the sandwich is a sum over rows), each with
 # twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
@@ -363,6 +365,21 @@ class SplitMatrix(MatrixBase):
             groups.append(cur)
         return groups
 
+    def _cat_pairs_plan(self):
+        """Bundling of the categorical x categorical tables for tm_multi_cat_pairs_* (None when the
+        matrix has no or more than 32 categorical blocks).  Static: built once."""
+        plan = self.__dict__.get("_cp_plan", False)
+        if plan is False:
+            plan = None
+            ids = [i for i, m in enumerate(self.matrices)
+                   if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
+            if 1 <= len(ids) <= 32:
+                pos = self._full_dev_indices()
+                plan = xsplit.CatPairsPlan([(i, self.matrices[i].shape[1]) for i in ids],
+                                           [pos[i] for i in ids])
+            self.__dict__["_cp_plan"] = plan
+        return plan
+
     def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget, d_rows=None):
         """All categorical x `mw` cross blocks from ONE pass over `mw` (tm_multi_cat_*), stacked
         [sum of levels, mw columns], or None when no fused kernel applies."""
@@ -511,10 +528,26 @@ class SplitMatrix(MatrixBase):
                     done.add((min(i, j), max(i, j)))
                     self_done.add(i)
                     break
-        # categorical x categorical tables first: the diagonal of a categorical block is the row sum
-        # of its table with any COMPLETE partner (every row has exactly one level there), which
-        # saves its histogram pass
+        # ---- all categorical x categorical tables that fit an LDS tile, and the categorical
+        #      diagonals, in ONE pass over the codes (tm_multi_cat_pairs_*): a design with k
+        #      categoricals has k (k - 1) / 2 of them, one launch each was ~30 us apiece
         cat_diag = {}
+        diag_scattered = set()
+        plan = self._cat_pairs_plan() if CAT_PAIRS_FUSED else None
+        if (plan is not None and plan.n_pairs > 0 and N_STREAMS == 1 and cols_host is None
+                and all(sub_d[i] is None and not empty[i] for i in plan.cat_ids)
+                and d.dtype in (torch.float32, torch.float64)):
+            cl = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in plan.cat_ids]
+            tables = xsplit.multi_cat_pairs(plan, cl, d, rows, out)
+            for i, j, toff, li, lj in plan.pairs:
+                if i == j:
+                    cat_diag[i] = tables[toff:toff + li].to(d.dtype)
+                    diag_scattered.add(i)
+                else:
+                    done.add((i, j))
+        # the other categorical x categorical tables: the diagonal of a categorical block is the
+        # row sum of its table with any COMPLETE partner (every row has exactly one level there),
+        # which saves its histogram pass
         complete = [isinstance(m, CategoricalMatrix) and not m.drop_first and not m._has_missings
                     and sub_d[k] is None and not empty[k] for k, m in enumerate(mats)]
         for i, mi in enumerate(mats):
@@ -542,7 +575,8 @@ class SplitMatrix(MatrixBase):
                         mi._sandwich_diag_dev(d, rows, sub_d[i])
                     if colsum is not None:
                         colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
-                    xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
+                    if i not in diag_scattered:
+                        xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
                 else:
                     res = mi._sandwich_dev(d, rows, sub_d[i])
                     xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
