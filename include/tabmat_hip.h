@@ -401,30 +401,40 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
  * ALL categorical x categorical blocks (and the categorical diagonals) of one sandwich in one pass
  * over the codes (ext/split.pyx:83-111 sandwich_cat_cat, ext/categorical.pyx:183-218): the pair
  * tables are packed into bundles of at most tm_multi_cat_pairs_max_bins() doubles (one LDS tile).
- * h_codes / h_ncols / h_drop_first: host arrays of n_cats (<= 32) device code pointers, column
- * counts and drop_first flags (as for tm_multi_cat_dense_sandwich_*).  pair_list: device int32:
- * word 0 = words per bundle row (a multiple of 4), words 1..3 unused, then one row per bundle:
- * {bit mask of the categoricals its tables use, number of tables, 0, 0} followed by 4 words per
- * table {i, j, offset of the table inside the bundle's tile, L_j} with i <= j; table (i, j) is
- * L_i x L_j row-major, table (i, i) the L_i diagonal entries.  tables: device double
- * [n_bundles][bins], overwritten with the tables.  desc: device int64 [n_pairs][6] =
- * {offset into tables, L_i, L_j, first entry of block i's / block j's positions in pos, diagonal
- * flag}; pos: device int64 positions of the blocks' columns in the p x p float64 `out`
- * (out[pos_i[a], pos_j[b]] = table[a, b] and its mirror; out may be NULL: tables only).
- * rows: int32 device row list or NULL.
+ * A bundle is a rectangle of tables: lists A and B of at most tm_multi_cat_pairs_max_slots()
+ * categoricals, tile = [sum of A's levels] x [sum of B's levels] row-major (width = tile width),
+ * table (a, b) the sub-rectangle at (first tile row of a, first tile column of b).
+ * cat_tab: device int64 [n categoricals][2] = {device pointer of the int32 codes, code of the first
+ * kept level (1 with drop_first, else 0; codes below it -- also -1 = missing -- contribute nothing)}.
+ * bundles: device int32, tm_multi_cat_pairs_row_words() words per bundle:
+ *   {|A|, |B|, mode, tile width, first workgroup, workgroups, bins of the tile, 0,
+ *    A: {index into cat_tab, first tile row x tile width} x max_slots,
+ *    B: {index into cat_tab, first tile column} x max_slots}
+ *   mode 0: all tables A x B;  1: B = A, tables a <= b ("triangle"; the diagonal of table (a, a) is
+ *   the categorical's own diagonal);  2: diagonals only, tile width 1, one bin per level.
+ * wg_map: device int32 [n_wg]: the bundle every workgroup works for (a bundle's workgroups are
+ *   consecutive from its "first workgroup"; the row range is cut evenly among them).
+ * slots: largest |A| or |B| (selects the kernel).  bins: largest tile (<= max_bins).
+ * tables: device double [n_bundles][bins], overwritten with the bundle tiles.  desc: device int64
+ * [n_pairs][8] = {offset of the table's first bin in `tables`, L_i, L_j, tile width (diagonal
+ * entry: distance between consecutive diagonal bins), first entry of block i's / block j's
+ * positions in pos, diagonal flag, 0}; pos: device int64 positions of the blocks' columns in the
+ * p x p float64 `out` (out[pos_i[a], pos_j[b]] = table[a, b] and its mirror; out may be NULL:
+ * tables only).  rows: int32 device row list or NULL.
  * ===================================================================================== */
 int tm_multi_cat_pairs_max_bins(void);
-int tm_multi_cat_pairs_max_tables(void);   /* tables per bundle */
-int tm_multi_cat_pairs_f32(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first,
-                           int n_cats, int64_t n, const float *d, const int32_t *rows, int64_t n_rows,
-                           const int32_t *pair_list, int n_bundles, int64_t bins, const int64_t *desc,
-                           int64_t n_pairs, const int64_t *pos, double *tables, double *out, int64_t p,
-                           void *stream);
-int tm_multi_cat_pairs_f64(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first,
-                           int n_cats, int64_t n, const double *d, const int32_t *rows, int64_t n_rows,
-                           const int32_t *pair_list, int n_bundles, int64_t bins, const int64_t *desc,
-                           int64_t n_pairs, const int64_t *pos, double *tables, double *out, int64_t p,
-                           void *stream);
+int tm_multi_cat_pairs_max_slots(void);
+int tm_multi_cat_pairs_row_words(void);
+int tm_multi_cat_pairs_f32(const int64_t *cat_tab, int64_t n, const float *d, const int32_t *rows,
+                           int64_t n_rows, const int32_t *bundles, int n_bundles,
+                           const int32_t *wg_map, int n_wg, int slots, int64_t bins,
+                           const int64_t *desc, int64_t n_pairs, const int64_t *pos, double *tables,
+                           double *out, int64_t p, void *stream);
+int tm_multi_cat_pairs_f64(const int64_t *cat_tab, int64_t n, const double *d, const int32_t *rows,
+                           int64_t n_rows, const int32_t *bundles, int n_bundles,
+                           const int32_t *wg_map, int n_wg, int slots, int64_t bins,
+                           const int64_t *desc, int64_t n_pairs, const int64_t *pos, double *tables,
+                           double *out, int64_t p, void *stream);
 
 /* =====================================================================================
  * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block

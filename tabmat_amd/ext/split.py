@@ -88,7 +88,13 @@ def cat_sparse_sandwich_sorted(plan, n_cols, d, S: CsrDev):
 class CatPairsPlan:
     """Packing of the categorical x categorical tables (and diagonals) of a SplitMatrix into
     LDS-sized bundles for tm_multi_cat_pairs_* -- static per matrix, built once.
-    cats: list of (block id, n_cols); pairs listed as (block i, block j) with i <= j."""
+    cats: list of (block id, n_cols).  A bundle is a rectangle A x B of categoricals whose tile
+    [sum of A's levels] x [sum of B's levels] fits the LDS (csrc/cat_pairs.hip); the triangle of
+    all pairs is cut recursively (halving the side with more levels) until every piece fits.
+    pairs: (block i, block j, offset in the tables buffer, L_i, L_j, stride) with i <= j; for
+    i == j the L_i diagonal entries lie `stride` apart."""
+
+    N_WG = 512          # workgroups dealt to the bundles (two rounds on 256 CUs)
 
     def __init__(self, cats, pos_arrays):
         from .._lib import lib
@@ -97,47 +103,118 @@ class CatPairsPlan:
         self.cat_ids = [c[0] for c in cats]
         k = len(cats)
         cap = int(lib().tm_multi_cat_pairs_max_bins())
-        max_tab = int(lib().tm_multi_cat_pairs_max_tables())
-        sizes = [int(c[1]) for c in cats]
-        # greedy bundles over the tables that fit one tile (diagonals first: they are tiny)
-        # (a table is bundled only when at least four of its size share a tile: a bundle with one
-        # or two big tables is no better than the per-pair kernel, which has the whole chip)
-        items = [(a, a, sizes[a]) for a in range(k) if sizes[a] <= cap] + \
-                [(a, b, sizes[a] * sizes[b]) for b in range(k) for a in range(b)
-                 if sizes[a] * sizes[b] <= cap // 4]
-        bundles, fill = [[]], 0
-        for a, b, sz in items:
-            if sz == 0:
+        slots = int(lib().tm_multi_cat_pairs_max_slots())
+        roww = int(lib().tm_multi_cat_pairs_row_words())
+        L = [int(c[1]) for c in cats]
+        bundles = []          # (A list, B list, mode)
+        lone = []             # categoricals whose diagonal no triangle holds
+
+        def tot(g):
+            return sum(L[a] for a in g)
+
+        def halves(g):
+            h = len(g) // 2
+            return g[:h], g[h:]
+
+        def cross(A, B):
+            if tot(A) * tot(B) <= cap and len(A) <= slots and len(B) <= slots:
+                bundles.append((A, B, 0))
+            elif len(A) == 1 and len(B) == 1:
+                return                     # the pair's own table exceeds a tile: per-pair kernel
+            elif len(B) == 1 or (len(A) > 1 and (tot(A) >= tot(B) or len(A) > slots)
+                                 and not len(B) > slots):
+                a1, a2 = halves(A)
+                cross(a1, B)
+                cross(a2, B)
+            else:
+                b1, b2 = halves(B)
+                cross(A, b1)
+                cross(A, b2)
+
+        def tri(G):
+            if tot(G) ** 2 <= cap and len(G) <= slots:
+                bundles.append((G, G, 1))
+            elif len(G) == 1:
+                lone.append(G[0])
+            else:
+                g1, g2 = halves(G)
+                tri(g1)
+                tri(g2)
+                cross(g1, g2)
+
+        live = [a for a in range(k) if L[a] > 0]
+        if live:
+            tri(live)
+        cur = []
+        for a in lone:                     # diagonals only: one bin per level
+            if L[a] > cap:
                 continue
-            if fill + sz > cap or len(bundles[-1]) >= max_tab:
-                bundles.append([])
-                fill = 0
-            bundles[-1].append((a, b, fill, sz))
-            fill += sz
-        bundles = [bd for bd in bundles if bd]
+            if cur and (tot(cur) + L[a] > cap or len(cur) >= slots):
+                bundles.append((cur, cur, 2))
+                cur = []
+            cur.append(a)
+        if cur:
+            bundles.append((cur, cur, 2))
         self.n_bundles = len(bundles)
-        self.bins = max((bd[-1][2] + bd[-1][3] for bd in bundles), default=1)
-        stride = 4 + 4 * max((len(bd) for bd in bundles), default=0)
-        pl = np.zeros(4 + max(self.n_bundles, 1) * stride, dtype=np.int64)
-        pl[0] = stride
-        pstart = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        desc, self.pairs = [], []
-        for y, bd in enumerate(bundles):
-            row = 4 + y * stride
-            mask = 0
-            for t, (a, b, o, sz) in enumerate(bd):
-                pl[row + 4 + 4 * t: row + 8 + 4 * t] = (a, b, o, sizes[b])
-                mask |= (1 << a) | (1 << b)
-                desc.append([y * self.bins + o, sizes[a], sizes[b], pstart[a], pstart[b], int(a == b)])
-                self.pairs.append((self.cat_ids[a], self.cat_ids[b], y * self.bins + o, sizes[a], sizes[b]))
-            pl[row] = mask
-            pl[row + 1] = len(bd)
-        self.pair_list = D.to_dev(pl.astype(np.uint32).view(np.int32))
-        self.desc = D.to_dev(np.asarray(desc, dtype=np.int64).reshape(-1, 6))
+        self.slots = max((max(len(A), len(B)) for A, B, _ in bundles), default=1)
+        # workgroups in proportion to the work per row: one LDS atomic per table, one load per
+        # categorical, the row's own bookkeeping
+        def cost(A, B, mode):
+            nt = len(A) * len(B) if mode == 0 else (len(A) * (len(A) + 1) // 2 if mode == 1 else len(A))
+            nl = len(A) + (len(B) if mode == 0 else 0)
+            return nt + 0.5 * nl + 1.0
+
+        costs = [cost(*bd) for bd in bundles]
+        n_wg = max(self.N_WG, self.n_bundles)
+        share = [max(1, int(n_wg * c / max(sum(costs), 1e-9))) for c in costs]
+        rows_w = np.zeros((max(self.n_bundles, 1), roww), dtype=np.int32)
+        pstart = np.concatenate([[0], np.cumsum(L)]).astype(np.int64)
+        desc, self.pairs, wg_map = [], [], []
+        self.bins = max((tot(A) * (tot(B) if mode != 2 else 1) for A, B, mode in bundles), default=1)
+        for y, (A, B, mode) in enumerate(bundles):
+            width = tot(B) if mode != 2 else 1
+            r = rows_w[y]
+            r[0], r[1], r[2], r[3] = len(A), len(B), mode, width
+            r[4], r[5], r[6] = len(wg_map), share[y], tot(A) * width
+            wg_map += [y] * share[y]
+            ra = np.concatenate([[0], np.cumsum([L[a] for a in A])]).astype(np.int64)
+            cb = np.concatenate([[0], np.cumsum([L[b] for b in B])]).astype(np.int64)
+            for s, a in enumerate(A):
+                r[8 + 2 * s], r[9 + 2 * s] = a, ra[s] * width
+            for s, b in enumerate(B):
+                r[8 + 2 * slots + 2 * s], r[9 + 2 * slots + 2 * s] = b, (cb[s] if mode != 2 else 0)
+            base = y * self.bins
+            for s, a in enumerate(A):
+                for t, b in enumerate(B):
+                    if (mode == 1 and t < s) or (mode == 2 and t != s):
+                        continue
+                    if a == b:
+                        off = base + ra[s] * width + (cb[s] if mode == 1 else 0)
+                        stride = width + 1 if mode == 1 else 1
+                        desc.append([off, L[a], L[a], stride, pstart[a], pstart[a], 1, 0])
+                    else:
+                        i, j = (a, b)
+                        off = base + ra[s] * width + cb[t]
+                        stride = width
+                        desc.append([off, L[i], L[j], stride, pstart[i], pstart[j], 0, 0])
+                    self.pairs.append((self.cat_ids[a], self.cat_ids[b], int(off), L[a], L[b], int(stride)))
+        self.bundles = D.to_dev(rows_w.reshape(-1))
+        self.wg_map = D.to_dev(np.asarray(wg_map if wg_map else [0], dtype=np.int32))
+        self.n_wg = len(wg_map)
+        self.desc = D.to_dev(np.asarray(desc, dtype=np.int64).reshape(-1, 8))
         self.pos = torch.cat([p.to(torch.int64) for p in pos_arrays]) if pos_arrays else \
             D.zeros((0,), torch.int64)
         self.n_pairs = len(desc)
         self.covered = {(min(i, j), max(i, j)) for i, j, *_ in self.pairs}
+        self._cat_tab = (None, None)
+
+    def cat_tab(self, cats):
+        """Device [k][2] int64 {codes pointer, first kept code}; rebuilt when a pointer changes."""
+        key = tuple((c[0].data_ptr(), bool(c[2])) for c in cats)
+        if self._cat_tab[0] != key:
+            tab = np.asarray([[c[0].data_ptr(), int(bool(c[2]))] for c in cats], dtype=np.int64)
+            self._cat_tab = (key, D.to_dev(tab.reshape(-1)))
+        return self._cat_tab[1]
 
 
 def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out):
@@ -148,11 +225,14 @@ def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out):
     tables = D.out_buf((max(plan.n_bundles, 1) * plan.bins,), torch.float64)
     if plan.n_pairs == 0:
         return tables
-    codes, ncols, drop, n = _cat_args(cats)
+    if rows is not None and rows.numel() == 0:
+        # (an empty device tensor has a NULL pointer, which the C ABI reads as "all rows")
+        return tables.zero_()
     nrows = int(cats[0][0].numel())
-    call(f"tm_multi_cat_pairs_{D.fsuf(d)}", codes, ncols, drop, n, nrows, D.p(d), D.p(rows),
-         D.nlen(rows), D.p(plan.pair_list), plan.n_bundles, plan.bins, D.p(plan.desc), plan.n_pairs,
-         D.p(plan.pos), D.p(tables), D.p(out), out.shape[0], D.stream_ptr())
+    call(f"tm_multi_cat_pairs_{D.fsuf(d)}", D.p(plan.cat_tab(cats)), nrows, D.p(d), D.p(rows),
+         D.nlen(rows), D.p(plan.bundles), plan.n_bundles, D.p(plan.wg_map), plan.n_wg, plan.slots,
+         plan.bins, D.p(plan.desc), plan.n_pairs, D.p(plan.pos), D.p(tables),
+         D.p(out), out.shape[0] if out is not None else 0, D.stream_ptr())
     return tables
 
 

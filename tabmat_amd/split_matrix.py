@@ -367,13 +367,13 @@ class SplitMatrix(MatrixBase):
 
     def _cat_pairs_plan(self):
         """Bundling of the categorical x categorical tables for tm_multi_cat_pairs_* (None when the
-        matrix has no or more than 32 categorical blocks).  Static: built once."""
+        matrix has no categorical block).  Static: built once."""
         plan = self.__dict__.get("_cp_plan", False)
         if plan is False:
             plan = None
             ids = [i for i, m in enumerate(self.matrices)
                    if isinstance(m, CategoricalMatrix) and m.shape[1] > 0]
-            if 1 <= len(ids) <= 32:
+            if len(ids) >= 1:
                 pos = self._full_dev_indices()
                 plan = xsplit.CatPairsPlan([(i, self.matrices[i].shape[1]) for i in ids],
                                            [pos[i] for i in ids])
@@ -539,9 +539,9 @@ class SplitMatrix(MatrixBase):
                 and d.dtype in (torch.float32, torch.float64)):
             cl = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in plan.cat_ids]
             tables = xsplit.multi_cat_pairs(plan, cl, d, rows, out)
-            for i, j, toff, li, lj in plan.pairs:
+            for i, j, toff, li, lj, stride in plan.pairs:
                 if i == j:
-                    cat_diag[i] = tables[toff:toff + li].to(d.dtype)
+                    cat_diag[i] = tables[toff:toff + (li - 1) * stride + 1:stride].to(d.dtype)
                     diag_scattered.add(i)
                 else:
                     done.add((i, j))

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("cats,missing,drop", [((12,) * 9, False, False), ((7, 300, 40, 2, 90), True, True),
-                                               ((200, 150, 3), False, True), ((5,) * 20, True, False)])
+                                               ((200, 150, 3), False, True), ((5,) * 20, True, False),
+                                               ((3,) * 40, True, True), ((130, 129, 127, 2), False, False),
+                                               ((20_000, 5, 9, 4000), True, False), ((50,) * 7, False, True)])
 def test_many_categoricals(cats, missing, drop, dtype):
     from oracle import oracle as orc
 
