@@ -20,6 +20,8 @@ CASES = [
     ("dense 50 cols (unaligned)", dict(k_dense=50)),
     ("cats 10000 / 500", dict(cats=(10000, 500))),
     ("cats 5 x 20", dict(cats=(20, 20, 20, 20, 20))),
+    ("cats 12 x 30", dict(cats=(30,) * 12)),
+    ("cats 24 x 10, dense 32, sparse 128", dict(cats=(10,) * 24, k_dense=32, k_sparse=128)),
     ("no categoricals", dict(cats=())),
     ("no sparse block", dict(k_sparse=0)),
 ]

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
     for (int b = threadIdx.x; b < nel; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
-// C-ordered dense, wide loads (the fast path for aligned operands and <= 4 categoricals):
+// C-ordered dense, wide loads (the fast path for aligned operands and <= 8 categoricals):
 // a wave step covers MCW_RS = 32 rows x TJ = 16 * VEC columns (VEC = columns per 16-byte load):
 // 8 global_load_dwordx4 per lane bring the 32 rows in (16 lanes per row, 4 rows per instruction),
 // d and the codes arrive lane <-> row with one coalesced load each and are parked in a per-wave
@@ -958,12 +958,12 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
         return TM_OK;
     }
     {
-        // wide-load path: C-ordered, 16-byte aligned rows, <= 4 categoricals, tile + scratch in LDS
+        // wide-load path: C-ordered, 16-byte aligned rows, <= 8 categoricals, tile + scratch in LDS
         constexpr int VEC = MCW_VEC;
         constexpr int TJW = 16 * VEC;
         const size_t tile_b = ((sizeof(lds_acc_t) * (size_t)cs.total * TJW + 15) / 16) * 16;
         const size_t lds_w = tile_b + (size_t)16 * MCW_RS * (sizeof(F) + (size_t)n_cats * sizeof(int));
-        if (!order_f && n_cats <= 4 && m >= VEC && m % VEC == 0 &&
+        if (!order_f && n_cats <= 8 && m >= VEC && m % VEC == 0 &&
             (reinterpret_cast<uintptr_t>(M) & 15) == 0 && lds_w <= 150 * 1024 &&
             (int64_t)cs.total * TJW * (int64_t)sizeof(lds_acc_t) < (1ll << 30)) {
             const int64_t n_parts = ceil_div(m, TJW);
@@ -991,7 +991,11 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
             if (n_cats == 1) rc = gow(&multi_cat_dense_wide_kernel<F, 1>);
             else if (n_cats == 2) rc = gow(&multi_cat_dense_wide_kernel<F, 2>);
             else if (n_cats == 3) rc = gow(&multi_cat_dense_wide_kernel<F, 3>);
-            else rc = gow(&multi_cat_dense_wide_kernel<F, 4>);
+            else if (n_cats == 4) rc = gow(&multi_cat_dense_wide_kernel<F, 4>);
+            else if (n_cats == 5) rc = gow(&multi_cat_dense_wide_kernel<F, 5>);
+            else if (n_cats == 6) rc = gow(&multi_cat_dense_wide_kernel<F, 6>);
+            else if (n_cats == 7) rc = gow(&multi_cat_dense_wide_kernel<F, 7>);
+            else rc = gow(&multi_cat_dense_wide_kernel<F, 8>);
             if (rc) return rc;
             rc = launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, tmp, n_parts * stride,
                                            false, st);
@@ -1106,11 +1110,15 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    if (stage && n_cats <= 4 && slab_rows == 128) {
+    if (stage && n_cats <= 8 && slab_rows == 128) {
         auto kpf = n_cats == 1   ? &multi_cat_sparse_pf_kernel<F, 1>
                    : n_cats == 2 ? &multi_cat_sparse_pf_kernel<F, 2>
                    : n_cats == 3 ? &multi_cat_sparse_pf_kernel<F, 3>
-                                 : &multi_cat_sparse_pf_kernel<F, 4>;
+                   : n_cats == 4 ? &multi_cat_sparse_pf_kernel<F, 4>
+                   : n_cats == 5 ? &multi_cat_sparse_pf_kernel<F, 5>
+                   : n_cats == 6 ? &multi_cat_sparse_pf_kernel<F, 6>
+                   : n_cats == 7 ? &multi_cat_sparse_pf_kernel<F, 7>
+                                 : &multi_cat_sparse_pf_kernel<F, 8>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kpf),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

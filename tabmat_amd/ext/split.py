@@ -297,14 +297,14 @@ def _cat_args(cats):
 
 def multi_cat_dense_wide_ok(cats, mat_j: DenseDev) -> bool:
     """True when tm_multi_cat_dense_sandwich_* takes its wide-load LDS-atomic kernel (cat.hip,
-    multi_cat_dense_wide_kernel): C-ordered operand with 16-byte aligned rows, <= 4 categoricals,
+    multi_cat_dense_wide_kernel): C-ordered operand with 16-byte aligned rows, <= 8 categoricals,
     stacked tile of DOUBLES [sum(n_cols)][32] plus the per-wave scratch within 150 KB of LDS."""
     fb = mat_j.buf.element_size()
     vec = 2
     total = sum(int(c[1]) for c in cats)
     tile = (total * 16 * vec * 8 + 15) // 16 * 16
     lds = tile + 16 * 32 * (fb + 4 * len(cats))
-    return (not mat_j.order_f and 1 <= len(cats) <= 4 and mat_j.m >= vec and mat_j.m % vec == 0
+    return (not mat_j.order_f and 1 <= len(cats) <= 8 and mat_j.m >= vec and mat_j.m % vec == 0
             and mat_j.buf.data_ptr() % 16 == 0 and lds <= 150 * 1024)
 
 

@@ -345,10 +345,11 @@ class SplitMatrix(MatrixBase):
 
     # levels that fit one LDS tile of doubles next to 32 dense / 33 sparse columns
     FUSED_LEVELS = 496
+    FUSED_CATS = int(os.environ.get("TABMAT_AMD_FUSED_CATS", "8"))
 
     def _cat_groups(self, cat_ids):
         """Categorical blocks whose cross terms are fused into one pass (tm_multi_cat_*): groups of
-        at most 4 blocks and FUSED_LEVELS stacked levels, in block order.  A categorical with more
+        at most FUSED_CATS (8) blocks and FUSED_LEVELS stacked levels, in block order.  A categorical with more
         levels than that is left out: its cross terms go through the level-sorted kernels, whose
         cost does not depend on the number of levels (CategoricalMatrix._cross_sandwich_dev)."""
         groups, cur, tot = [], [], 0
@@ -356,7 +357,7 @@ class SplitMatrix(MatrixBase):
             k = self.matrices[i].shape[1]
             if k > self.FUSED_LEVELS:
                 continue
-            if cur and (len(cur) == 4 or tot + k > self.FUSED_LEVELS):
+            if cur and (len(cur) == self.FUSED_CATS or tot + k > self.FUSED_LEVELS):
                 groups.append(cur)
                 cur, tot = [], 0
             cur.append(i)
@@ -499,14 +500,24 @@ class SplitMatrix(MatrixBase):
                     stacked = self._fused_cats(mw, cats, grp, d_eff, rows, total, budget, d)
                     if stacked is None:
                         continue
+                    # no column restriction: the stacked result goes out in ONE scatter (24
+                    # categoricals x 2 operands were 48 launches of ~5 us)
+                    whole = cols_host is None and len(grp) > 1
+                    if whole:
+                        cache = self.__dict__.setdefault("_group_pos", {})
+                        gpos = cache.get(tuple(grp))
+                        if gpos is None:
+                            gpos = cache[tuple(grp)] = torch.cat([pos_d[i] for i in grp])
+                        xsplit.scatter_block(stacked.contiguous(), gpos, pos_d[w], out, mirror=True)
                     for ci, i in enumerate(grp):
                         res = stacked[int(offs[ci]):int(offs[ci + 1])]
                         if (colsum is not None and colsum[w] is None and not mats[i].drop_first
                                 and not mats[i]._has_missings):
                             cs = res.sum(dim=0)           # all levels of a complete categorical
                             colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
-                        res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
-                        xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
+                        if not whole:
+                            res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
+                            xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                         done.add((min(i, w), max(i, w)))
         self_done = set()
         if FUSE_SYRK and rows is None and d.dtype == torch.float64:
