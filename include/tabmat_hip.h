@@ -404,8 +404,9 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
  * A bundle is a rectangle of tables: lists A and B of at most tm_multi_cat_pairs_max_slots()
  * categoricals, tile = [sum of A's levels] x [sum of B's levels] row-major (width = tile width),
  * table (a, b) the sub-rectangle at (first tile row of a, first tile column of b).
- * cat_tab: device int64 [n categoricals][2] = {device pointer of the int32 codes, code of the first
- * kept level (1 with drop_first, else 0; codes below it -- also -1 = missing -- contribute nothing)}.
+ * cat_tab: device int64 [n categoricals][4] = {device pointer of the int32 codes, code of the first
+ * kept level (1 with drop_first, else 0; codes below it -- also -1 = missing -- contribute nothing),
+ * first entry of the block's column positions in `pos`, 0}.
  * bundles: device int32, tm_multi_cat_pairs_row_words() words per bundle:
  *   {|A|, |B|, mode, tile width, first workgroup, workgroups, bins of the tile, 0,
  *    A: {index into cat_tab, first tile row x tile width} x max_slots,
@@ -435,6 +436,17 @@ int tm_multi_cat_pairs_f64(const int64_t *cat_tab, int64_t n, const double *d, c
                            const int32_t *wg_map, int n_wg, int slots, int64_t bins,
                            const int64_t *desc, int64_t n_pairs, const int64_t *pos, double *tables,
                            double *out, int64_t p, void *stream);
+
+/* =====================================================================================
+ * SplitMatrix.matvec over ALL categorical blocks in one pass (split_matrix.py:373-420 calling
+ * ext/categorical.pyx:110-136 block by block):  out[k] += sum_c v[pos[first_c + code_c[k] - kept_c]].
+ * cat_tab / pos as for tm_multi_cat_pairs_*; v: the full coefficient vector (device, length = number
+ * of columns of the split matrix); out: device, length n, accumulated into.
+ * ===================================================================================== */
+int tm_multi_cat_matvec_f32(const int64_t *cat_tab, int n_cats, const int64_t *pos, const float *v,
+                            int64_t n, float *out, void *stream);
+int tm_multi_cat_matvec_f64(const int64_t *cat_tab, int n_cats, const int64_t *pos, const double *v,
+                            int64_t n, double *out, void *stream);
 
 /* =====================================================================================
  * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block

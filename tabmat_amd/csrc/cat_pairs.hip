@@ -59,14 +59,14 @@ __global__ __launch_bounds__(1024) void multi_cat_pairs_kernel(
         if (s < na) {
             const int id = __builtin_amdgcn_readfirstlane(br[8 + 2 * s]);
             offa[s] = __builtin_amdgcn_readfirstlane(br[9 + 2 * s]);
-            pa[s] = reinterpret_cast<const int32_t *>(cat_tab[2 * id]);
-            dropa[s] = (int)cat_tab[2 * id + 1];
+            pa[s] = reinterpret_cast<const int32_t *>(cat_tab[4 * id]);
+            dropa[s] = (int)cat_tab[4 * id + 1];
         }
         if (s < nb) {
             const int id = __builtin_amdgcn_readfirstlane(br[8 + 2 * CP_SLOTS + 2 * s]);
             offb[s] = __builtin_amdgcn_readfirstlane(br[9 + 2 * CP_SLOTS + 2 * s]);
-            pb[s] = reinterpret_cast<const int32_t *>(cat_tab[2 * id]);
-            dropb[s] = (int)cat_tab[2 * id + 1];
+            pb[s] = reinterpret_cast<const int32_t *>(cat_tab[4 * id]);
+            dropb[s] = (int)cat_tab[4 * id + 1];
         }
     });
     constexpr int UNR = NS <= 8 ? 4 : 2;           // rows per thread and step (loads in flight)
@@ -199,6 +199,99 @@ __global__ __launch_bounds__(256) void multi_cat_pairs_scatter_kernel(
     }
 }
 
+// out[k] += sum over the categoricals of v[pos[first position of c + code_c(k) - first kept code]]
+// (SplitMatrix.matvec over all categorical blocks at once; reference: split_matrix.py:373-420 calling
+// ext/categorical.pyx:110-136 matvec_fast block by block).  Lane <-> row, 4 rows per thread; the
+// categoricals' descriptors sit in registers (lane c of a page = categorical c) and are read back
+// with v_readlane; two categoricals per step = 8 code loads, then 8 + 8 dependent gathers in flight.
+template <typename F>
+__global__ __launch_bounds__(256) void multi_cat_matvec_kernel(
+    const int64_t *__restrict__ cat_tab, int n_cats, const int64_t *__restrict__ pos,
+    const F *__restrict__ v, int64_t n, F *__restrict__ out) {
+    constexpr int UNR = 4;
+    const int lane = threadIdx.x & 63;
+    int64_t k[UNR];
+    double acc[UNR];
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x * UNR + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int64_t t = base + (int64_t)u * blockDim.x;
+        k[u] = t < n ? t : n - 1;
+        acc[u] = 0.0;
+    }
+    for (int c0 = 0; c0 < n_cats; c0 += 64) {
+        const int cnt = min(n_cats - c0, 64);
+        const int cl = min(c0 + lane, n_cats - 1);
+        const int64_t ptr = cat_tab[4 * cl], poff = cat_tab[4 * cl + 2];
+        const int plo = (int)(uint32_t)ptr, phi = (int)(uint32_t)((uint64_t)ptr >> 32);
+        const int drop = (int)cat_tab[4 * cl + 1];
+        const int olo = (int)(uint32_t)poff, ohi = (int)(uint32_t)((uint64_t)poff >> 32);
+        auto desc = [&](int c, const int32_t *&codes, int &dr, int64_t &po) {
+            const uint64_t p = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(plo, c) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(phi, c) << 32);
+            codes = reinterpret_cast<const int32_t *>(p);
+            dr = __builtin_amdgcn_readlane(drop, c);
+            po = (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane(olo, c) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(ohi, c) << 32));
+        };
+        int c = 0;
+        for (; c + 2 <= cnt; c += 2) {
+            const int32_t *ca, *cb;
+            int da, db;
+            int64_t pa, pb;
+            desc(c, ca, da, pa);
+            desc(c + 1, cb, db, pb);
+            int ia[UNR], ib[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                ia[u] = __builtin_nontemporal_load(ca + k[u]) - da;
+                ib[u] = __builtin_nontemporal_load(cb + k[u]) - db;
+            }
+            int64_t qa[UNR], qb[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                qa[u] = pos[pa + max(ia[u], 0)];
+                qb[u] = pos[pb + max(ib[u], 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const double xa = (double)v[qa[u]], xb = (double)v[qb[u]];
+                acc[u] += (ia[u] >= 0 ? xa : 0.0) + (ib[u] >= 0 ? xb : 0.0);
+            }
+        }
+        if (c < cnt) {
+            const int32_t *ca;
+            int da;
+            int64_t pa;
+            desc(c, ca, da, pa);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ia = __builtin_nontemporal_load(ca + k[u]) - da;
+                const double xa = (double)v[pos[pa + max(ia, 0)]];
+                acc[u] += ia >= 0 ? xa : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int64_t t = base + (int64_t)u * blockDim.x;
+        if (t < n) out[t] += (F)acc[u];
+    }
+}
+
+template <typename F>
+static int run_multi_cat_matvec(const int64_t *cat_tab, int n_cats, const int64_t *pos, const F *v,
+                                int64_t n, F *out, hipStream_t st) {
+    if (n <= 0 || n_cats <= 0) return TM_OK;
+    const int64_t nblk = ceil_div(n, 256 * 4);
+    prof_begin(st);
+    hipLaunchKernelGGL((multi_cat_matvec_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, cat_tab,
+                       n_cats, pos, v, n, out);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 template <typename F>
 static int run_multi_cat_pairs(const int64_t *cat_tab, int64_t n, const F *d, const int32_t *rows,
                                int64_t n_rows, const int32_t *bundles, int n_bundles,
@@ -271,5 +364,13 @@ int tm_multi_cat_pairs_f64(const int64_t *cat_tab, int64_t n, const double *d, c
     return tmh::run_multi_cat_pairs<double>(cat_tab, n, d, rows, n_rows, bundles, n_bundles, wg_map, n_wg,
                                             slots, bins, desc, n_pairs, pos, tables, out, p,
                                             tmh::as_stream(stream));
+}
+int tm_multi_cat_matvec_f32(const int64_t *cat_tab, int n_cats, const int64_t *pos, const float *v,
+                            int64_t n, float *out, void *stream) {
+    return tmh::run_multi_cat_matvec<float>(cat_tab, n_cats, pos, v, n, out, tmh::as_stream(stream));
+}
+int tm_multi_cat_matvec_f64(const int64_t *cat_tab, int n_cats, const int64_t *pos, const double *v,
+                            int64_t n, double *out, void *stream) {
+    return tmh::run_multi_cat_matvec<double>(cat_tab, n_cats, pos, v, n, out, tmh::as_stream(stream));
 }
 }  // extern "C"

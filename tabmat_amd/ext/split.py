@@ -96,7 +96,9 @@ class CatPairsPlan:
 
     N_WG = 512          # workgroups dealt to the bundles (two rounds on 256 CUs)
 
-    def __init__(self, cats, pos_arrays):
+    def __init__(self, cats, pos_arrays, diag_only=False):
+        """diag_only: only the diagonals = the weighted histograms of all categoricals in one pass
+        (SplitMatrix.transpose_matvec)."""
         from .._lib import lib
         import torch
 
@@ -143,7 +145,9 @@ class CatPairsPlan:
                 cross(g1, g2)
 
         live = [a for a in range(k) if L[a] > 0]
-        if live:
+        if diag_only:
+            lone = list(live)
+        elif live:
             tri(live)
         cur = []
         for a in lone:                     # diagonals only: one bin per level
@@ -168,7 +172,7 @@ class CatPairsPlan:
         n_wg = max(self.N_WG, self.n_bundles)
         share = [max(1, int(n_wg * c / max(sum(costs), 1e-9))) for c in costs]
         rows_w = np.zeros((max(self.n_bundles, 1), roww), dtype=np.int32)
-        pstart = np.concatenate([[0], np.cumsum(L)]).astype(np.int64)
+        pstart = self.pstart = np.concatenate([[0], np.cumsum(L)]).astype(np.int64)
         desc, self.pairs, wg_map = [], [], []
         self.bins = max((tot(A) * (tot(B) if mode != 2 else 1) for A, B, mode in bundles), default=1)
         for y, (A, B, mode) in enumerate(bundles):
@@ -209,17 +213,21 @@ class CatPairsPlan:
         self._cat_tab = (None, None)
 
     def cat_tab(self, cats):
-        """Device [k][2] int64 {codes pointer, first kept code}; rebuilt when a pointer changes."""
+        """Device [k][4] int64 {codes pointer, first kept code, first entry in pos, 0}; rebuilt when
+        a pointer changes."""
         key = tuple((c[0].data_ptr(), bool(c[2])) for c in cats)
         if self._cat_tab[0] != key:
-            tab = np.asarray([[c[0].data_ptr(), int(bool(c[2]))] for c in cats], dtype=np.int64)
+            tab = np.asarray([[c[0].data_ptr(), int(bool(c[2])), int(self.pstart[a]), 0]
+                              for a, c in enumerate(cats)], dtype=np.int64)
             self._cat_tab = (key, D.to_dev(tab.reshape(-1)))
         return self._cat_tab[1]
 
 
-def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out):
+def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out, vector=False):
     """All bundled categorical x categorical tables + diagonals in one pass, scattered into the
-    float64 (p, p) `out`; returns the tables buffer (float64, [n_bundles * bins])."""
+    float64 (p, p) `out`; returns the tables buffer (float64, [n_bundles * bins]).
+    vector: `out` is a float64 VECTOR over the columns and only diagonals are written
+    (out[pos] = histogram: a diag_only plan)."""
     import torch
 
     tables = D.out_buf((max(plan.n_bundles, 1) * plan.bins,), torch.float64)
@@ -232,8 +240,17 @@ def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out):
     call(f"tm_multi_cat_pairs_{D.fsuf(d)}", D.p(plan.cat_tab(cats)), nrows, D.p(d), D.p(rows),
          D.nlen(rows), D.p(plan.bundles), plan.n_bundles, D.p(plan.wg_map), plan.n_wg, plan.slots,
          plan.bins, D.p(plan.desc), plan.n_pairs, D.p(plan.pos), D.p(tables),
-         D.p(out), out.shape[0] if out is not None else 0, D.stream_ptr())
+         D.p(out), 0 if (vector or out is None) else out.shape[0], D.stream_ptr())
     return tables
+
+
+def multi_cat_matvec(plan: CatPairsPlan, cats, v, out):
+    """out[k] += sum over the plan's categoricals of v[position of the row's level] (one pass over
+    all codes; v: the FULL coefficient vector of the split matrix)."""
+    D.same_float("multi_cat_matvec", v, out)
+    call(f"tm_multi_cat_matvec_{D.fsuf(v)}", D.p(plan.cat_tab(cats)), len(cats), D.p(plan.pos), D.p(v),
+         int(cats[0][0].numel()), D.p(out), D.stream_ptr())
+    return out
 
 
 def scatter_block(src, ri, ci, out, mirror=False, diag=False):

@@ -50,6 +50,7 @@ CAT_PAIRS_FUSED = os.environ.get("TABMAT_AMD_CAT_PAIRS", "1") != "0"
 # Entry indices inside one sparse block's twins are 32-bit: a SplitMatrix whose sparse block holds
 # this many nonzeros or more is worked on in ROW PARTS (the sandwich is a sum over rows), each with
 # twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
+from . import categorical_matrix as _cm
 from . import sparse_matrix as _spm      # PART_NNZ lives there (also used by SparseMatrix itself)
 
 
@@ -381,6 +382,21 @@ class SplitMatrix(MatrixBase):
             self.__dict__["_cp_plan"] = plan
         return plan
 
+    def _cat_hist_plan(self):
+        """All categorical blocks' weighted histograms in one launch (transpose_matvec): the
+        diagonals-only form of the pair-table plan.  None with fewer than two categoricals."""
+        plan = self.__dict__.get("_ch_plan", False)
+        if plan is False:
+            plan = None
+            ids = [i for i, m in enumerate(self.matrices)
+                   if isinstance(m, CategoricalMatrix) and m.shape[1] > 0 and m.shape[0] > 0]
+            if len(ids) >= 2:
+                pos = self._full_dev_indices()
+                plan = xsplit.CatPairsPlan([(i, self.matrices[i].shape[1]) for i in ids],
+                                           [pos[i] for i in ids], diag_only=True)
+            self.__dict__["_ch_plan"] = plan
+        return plan
+
     def _fused_cats(self, mw, cats, cat_ids, d_eff, rows, total, budget, d_rows=None):
         """All categorical x `mw` cross blocks from ONE pass over `mw` (tm_multi_cat_*), stacked
         [sum of levels, mw columns], or None when no fused kernel applies."""
@@ -643,8 +659,17 @@ class SplitMatrix(MatrixBase):
         idx_d = self._full_dev_indices()
         if v_dev.ndim == 1:
             res = D.zeros((self.shape[0],), tdt)
-            for mat, idx, sc in zip(self.matrices, idx_d, sub_cols):
-                if sc is not None and len(sc) == 0:
+            fused = set()
+            plan = self._cat_hist_plan() if (CAT_PAIRS_FUSED and cols_n is None) else None
+            if plan is not None:
+                # all categorical blocks in ONE pass (one gather + one launch per block before:
+                # 20 categoricals 0.33 ms for 0.18 GB)
+                cl = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
+                      for i in plan.cat_ids]
+                xsplit.multi_cat_matvec(plan, cl, v_dev, res)
+                fused = set(plan.cat_ids)
+            for bi, (mat, idx, sc) in enumerate(zip(self.matrices, idx_d, sub_cols)):
+                if (sc is not None and len(sc) == 0) or bi in fused:
                     continue
                 vb = v_dev[idx]
                 scd = D.idx_dev(sc)
@@ -702,8 +727,21 @@ class SplitMatrix(MatrixBase):
             res = D.zeros((n_cols,), tdt)
             pos_d = self._full_dev_indices() if cols_n is None else self._dev_idx(pos)
             empty_rows = rows_n is not None and len(rows_n) == 0
-            for mat, pd, sc in zip(self.matrices, pos_d, sub_cols):
-                if empty_rows or (sc is not None and len(sc) == 0):
+            fused = set()
+            plan = self._cat_hist_plan() if (CAT_PAIRS_FUSED and cols_n is None and not empty_rows
+                                             and not _cm.DETERMINISTIC) else None
+            if plan is not None and plan.n_pairs > 0:
+                # every categorical block's histogram from ONE pass over the codes (one launch per
+                # block was ~35 us each: 20 categoricals 0.69 ms for 0.18 GB)
+                cl = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
+                      for i in plan.cat_ids]
+                tgt = res if tdt == torch.float64 else D.zeros((n_cols,), torch.float64)
+                xsplit.multi_cat_pairs(plan, cl, v_dev, rd, tgt, vector=True)
+                if tgt is not res:
+                    res += tgt.to(tdt)
+                fused = {i for i, *_ in plan.pairs}
+            for bi, (mat, pd, sc) in enumerate(zip(self.matrices, pos_d, sub_cols)):
+                if empty_rows or (sc is not None and len(sc) == 0) or bi in fused:
                     continue
                 scd = D.idx_dev(sc)
                 if isinstance(mat, CategoricalMatrix):
