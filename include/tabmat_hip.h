@@ -420,8 +420,9 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
  * [n_pairs][8] = {offset of the table's first bin in `tables`, L_i, L_j, tile width (diagonal
  * entry: distance between consecutive diagonal bins), first entry of block i's / block j's
  * positions in pos, diagonal flag, 0}; pos: device int64 positions of the blocks' columns in the
- * p x p float64 `out` (out[pos_i[a], pos_j[b]] = table[a, b] and its mirror; out may be NULL:
- * tables only).  rows: int32 device row list or NULL.
+ * p x p float64 `out` (out[pos_i[a], pos_j[b]] = table[a, b] and its mirror; a negative position =
+ * level not selected, nothing written; out may be NULL: tables only; p = 0: `out` is a VECTOR and
+ * only the diagonal entries are written, out[pos_i[a]] = diagonal a).  rows: int32 device row list or NULL.
  * ===================================================================================== */
 int tm_multi_cat_pairs_max_bins(void);
 int tm_multi_cat_pairs_max_slots(void);

@@ -188,13 +188,15 @@ __global__ __launch_bounds__(256) void multi_cat_pairs_scatter_kernel(
          e += (int64_t)gridDim.y * blockDim.x) {
         if (diag) {
             const int64_t r = pos[pi + e];
-            out[r * p + r] = tables[toff + e * w];
+            if (r >= 0) out[r * p + r] = tables[toff + e * w];
         } else {
             const int64_t ei = e / lj, ej = e % lj;
             const double v = tables[toff + ei * w + ej];
             const int64_t r = pos[pi + ei], cc = pos[pj + ej];
-            out[r * p + cc] = v;
-            out[cc * p + r] = v;
+            if (r >= 0 && cc >= 0) {
+                out[r * p + cc] = v;
+                out[cc * p + r] = v;
+            }
         }
     }
 }

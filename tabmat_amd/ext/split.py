@@ -223,11 +223,12 @@ class CatPairsPlan:
         return self._cat_tab[1]
 
 
-def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out, vector=False):
+def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out, vector=False, pos=None):
     """All bundled categorical x categorical tables + diagonals in one pass, scattered into the
     float64 (p, p) `out`; returns the tables buffer (float64, [n_bundles * bins]).
     vector: `out` is a float64 VECTOR over the columns and only diagonals are written
-    (out[pos] = histogram: a diag_only plan)."""
+    (out[pos] = histogram: a diag_only plan).  pos: positions to use instead of the plan's (-1 =
+    level not selected: nothing is written for it)."""
     import torch
 
     tables = D.out_buf((max(plan.n_bundles, 1) * plan.bins,), torch.float64)
@@ -239,7 +240,7 @@ def multi_cat_pairs(plan: CatPairsPlan, cats, d, rows, out, vector=False):
     nrows = int(cats[0][0].numel())
     call(f"tm_multi_cat_pairs_{D.fsuf(d)}", D.p(plan.cat_tab(cats)), nrows, D.p(d), D.p(rows),
          D.nlen(rows), D.p(plan.bundles), plan.n_bundles, D.p(plan.wg_map), plan.n_wg, plan.slots,
-         plan.bins, D.p(plan.desc), plan.n_pairs, D.p(plan.pos), D.p(tables),
+         plan.bins, D.p(plan.desc), plan.n_pairs, D.p(plan.pos if pos is None else pos), D.p(tables),
          D.p(out), 0 if (vector or out is None) else out.shape[0], D.stream_ptr())
     return tables
 
@@ -267,11 +268,43 @@ def scatter_block(src, ri, ci, out, mirror=False, diag=False):
          int(mirror), int(diag), D.stream_ptr())
 
 
+def _col_maps(self):
+    """(block of column c, local index of column c) for a SplitMatrix whose blocks list their
+    columns in increasing order and cover every column once; else None.  Cached on the matrix."""
+    maps = self.__dict__.get("_col_maps", False)
+    if maps is False:
+        maps = None
+        inds = [np.asarray(i) for i in self.indices]
+        p = int(sum(i.size for i in inds))
+        if all(i.size < 2 or bool((i[1:] > i[:-1]).all()) for i in inds) and \
+                all(i.size == 0 or (i.min() >= 0 and i.max() < p) for i in inds):
+            block_of = np.full(p, -1, dtype=np.int64)
+            local_of = np.zeros(p, dtype=np.int32)
+            for j, i in enumerate(inds):
+                block_of[i] = j
+                local_of[i] = np.arange(i.size, dtype=np.int32)
+            if p == 0 or block_of.min() >= 0:
+                maps = (block_of, local_of)
+        self.__dict__["_col_maps"] = maps
+    return maps
+
+
 def split_col_subsets(self, cols: np.ndarray):
     """ext/split.pyx:157-209: host-side index bookkeeping (p-sized), same outputs:
     (subset_cols_indices, subset_cols, n_cols)."""
     cols = np.asarray(cols, dtype=np.int32)
     n_blocks = len(self.indices)
+    maps = _col_maps(self)
+    if maps is not None and (cols.size < 2 or bool((cols[1:] > cols[:-1]).all())):
+        # strictly increasing selection, every block's own indices increasing (the case the
+        # reference's merge loop is written for): the same lists from two table lookups
+        block_of, local_of = maps
+        b, loc = block_of[cols], local_of[cols]
+        order = np.argsort(b, kind="stable").astype(np.int32)
+        ends = np.cumsum(np.bincount(b, minlength=n_blocks))
+        starts = np.concatenate([[0], ends[:-1]])
+        return ([order[s:e] for s, e in zip(starts, ends)],
+                [loc[order[s:e]] for s, e in zip(starts, ends)], len(cols))
     next_idx = [0] * n_blocks
     sub_idx = [[] for _ in range(n_blocks)]
     sub_cols = [[] for _ in range(n_blocks)]

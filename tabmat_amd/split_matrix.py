@@ -26,6 +26,7 @@ from .util import (
     check_matvec_out_shape,
     check_sandwich_compatible,
     check_transpose_matvec_out_shape,
+    collapse_identity,
     normalize_index,
     set_up_rows_or_cols,
 )
@@ -47,6 +48,15 @@ FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
 DIAG_FROM_PAIRS = True
 # all small categorical x categorical tables + diagonals in one launch (tm_multi_cat_pairs_*)
 CAT_PAIRS_FUSED = os.environ.get("TABMAT_AMD_CAT_PAIRS", "1") != "0"
+# a column selection that keeps at least this share of the columns is computed as the UNRESTRICTED
+# product followed by a selection of the result (every entry of X'DX / X'v depends on its own
+# columns only, so the entries are the same; the unrestricted kernels are the tuned ones).  matvec:
+# zeros in the coefficient vector instead.
+FULL_THEN_SELECT = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT", "0.5"))
+# matvec / transpose_matvec stream all of X whatever the selection (row-major dense rows, CSR): the
+# unrestricted kernels are never slower (cfg4 shape, 2M rows, 5 % of the columns: 0.88 / 0.99 ms
+# restricted, 0.55 / 0.60 ms unrestricted + selection), so they always take this form
+FULL_THEN_SELECT_MV = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT_MV", "0.0"))
 # Entry indices inside one sparse block's twins are 32-bit: a SplitMatrix whose sparse block holds
 # this many nonzeros or more is worked on in ROW PARTS (the sandwich is a sum over rows), each with
 # twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
@@ -313,10 +323,48 @@ class SplitMatrix(MatrixBase):
     def _sandwich_plan(self, cols_host):
         """Column bookkeeping of one sandwich call, staged on the device once: output positions
         and per-block column subsets (split_matrix.py:341-349)."""
+        if cols_host is None:
+            return self._full_dev_indices(), [None] * len(self.indices), self.shape[1]
+        # the last selection's index arrays stay on the device: a solver repeats its active set,
+        # and the 2 uploads per block were 0.8 ms for 20 blocks
+        key = np.asarray(cols_host).tobytes()
+        hit = self.__dict__.get("_plan_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
         pos, sub_cols, n_cols = self._split_col_subsets(cols_host)
-        pos_d = self._full_dev_indices() if cols_host is None else self._dev_idx(pos)
+        pos_d = self._dev_idx(pos)
         sub_d = [None if sc is None else D.idx_dev(sc) for sc in sub_cols]
+        self._cols_dev64(cols_host)
+        if CAT_PAIRS_FUSED:
+            plan = self._cat_pairs_plan()
+            if plan is not None and plan.n_pairs > 0:
+                self._pairs_pos_sel(plan, cols_host, (pos, sub_cols))    # staged here (no copies
+        self.__dict__["_plan_cache"] = (key, (pos_d, sub_d, n_cols))    # inside a graph capture)
         return pos_d, sub_d, n_cols
+
+    def _cols_dev64(self, cols_host):
+        """The column selection as an int64 device tensor (last selection cached)."""
+        key = np.asarray(cols_host).tobytes()
+        hit = self.__dict__.get("_cols64")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_cols64"] = (key, D.idx_dev(cols_host, torch.int64))
+        return hit[1]
+
+    def _pairs_pos_sel(self, plan, cols_host, split=None):
+        """Output position of every level of the plan's categoricals under the column selection
+        `cols_host` (-1: not selected), device int64; the last selection is kept."""
+        key = np.asarray(cols_host).tobytes()
+        hit = self.__dict__.get("_pos_sel")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pos_h, sub_h = split if split is not None else self._split_col_subsets(cols_host)[:2]
+        pf = np.full(int(plan.pstart[-1]), -1, dtype=np.int64)
+        for a, i in enumerate(plan.cat_ids):
+            if len(sub_h[i]):
+                pf[int(plan.pstart[a]) + np.asarray(sub_h[i], dtype=np.int64)] = pos_h[i]
+        t = D.to_dev(pf)
+        self.__dict__["_pos_sel"] = (key, t)
+        return t
 
     def _sandwich_xtd_dev(self, d, rows, cols_host):
         """(X' diag(d) X, X' d) restricted to rows / cols, both float64 on the device, from ONE
@@ -484,6 +532,17 @@ class SplitMatrix(MatrixBase):
         Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
         colsum: optional list (one slot per block) that receives X_block' d[rows] (restricted to
         the block's columns) wherever it falls out of the sandwich for free."""
+        if cols_host is not None and len(cols_host) >= FULL_THEN_SELECT * self.shape[1] \
+                and len(cols_host) > 0:
+            pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
+            cs_full = [None] * len(self.matrices) if colsum is not None else None
+            full = self._sandwich_dev(d, rows, None, None, cs_full)
+            if colsum is not None:
+                for i, c in enumerate(cs_full):
+                    if c is not None:
+                        colsum[i] = c if sub_d[i] is None else c[sub_d[i].to(torch.int64)]
+            cd = self._cols_dev64(cols_host)
+            return full.index_select(0, cd).index_select(1, cd)
         parts = self._parts()
         if parts is not None:
             return self._sandwich_parts(parts, d, rows, cols_host, colsum)
@@ -561,15 +620,22 @@ class SplitMatrix(MatrixBase):
         cat_diag = {}
         diag_scattered = set()
         plan = self._cat_pairs_plan() if CAT_PAIRS_FUSED else None
-        if (plan is not None and plan.n_pairs > 0 and N_STREAMS == 1 and cols_host is None
-                and all(sub_d[i] is None and not empty[i] for i in plan.cat_ids)
-                and d.dtype in (torch.float32, torch.float64)):
+        if (plan is not None and plan.n_pairs > 0 and N_STREAMS == 1
+                and d.dtype in (torch.float32, torch.float64)
+                and d.dtype == D.torch_dtype(self.dtype)):
             cl = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in plan.cat_ids]
-            tables = xsplit.multi_cat_pairs(plan, cl, d, rows, out)
+            # column restriction: the full tables are accumulated, the scatter drops the
+            # unselected levels (position -1)
+            pos_sel = None if cols_host is None else self._pairs_pos_sel(plan, cols_host)
+            tables = xsplit.multi_cat_pairs(plan, cl, d, rows, out, pos=pos_sel)
             for i, j, toff, li, lj, stride in plan.pairs:
                 if i == j:
-                    cat_diag[i] = tables[toff:toff + (li - 1) * stride + 1:stride].to(d.dtype)
-                    diag_scattered.add(i)
+                    if not empty[i]:
+                        full = tables[toff:toff + (li - 1) * stride + 1:stride]
+                        if sub_d[i] is not None and colsum is not None:
+                            full = full[sub_d[i].to(torch.int64)]
+                        cat_diag[i] = full.to(d.dtype)
+                        diag_scattered.add(i)
                 else:
                     done.add((i, j))
         # the other categorical x categorical tables: the diagonal of a categorical block is the
@@ -625,7 +691,7 @@ class SplitMatrix(MatrixBase):
 
         check_sandwich_compatible(self, d)
         rows_d = D.idx_dev(normalize_index(rows, self.shape[0]))
-        cols_n = normalize_index(cols, self.shape[1])
+        cols_n = collapse_identity(normalize_index(cols, self.shape[1]), self.shape[1])
         plan = self._sandwich_plan(cols_n)      # index uploads happen here, outside the capture
         return CapturedProduct(lambda dd: self._sandwich_dev(dd, rows_d, cols_n, plan), d)
 
@@ -637,7 +703,7 @@ class SplitMatrix(MatrixBase):
             d = np.asarray(d)
         check_sandwich_compatible(self, d)
         rows_n = normalize_index(rows, self.shape[0])
-        cols_n = normalize_index(cols, self.shape[1])
+        cols_n = collapse_identity(normalize_index(cols, self.shape[1]), self.shape[1])
         out = self._sandwich_dev(D.to_dev(d), D.idx_dev(rows_n), cols_n)
         return out if on_dev else D.to_host(out)
 
@@ -652,27 +718,37 @@ class SplitMatrix(MatrixBase):
         if v.ndim > 1 and any(isinstance(m, CategoricalMatrix) for m in self.matrices):
             raise NotImplementedError(
                 "CategoricalMatrix.matvec is only implemented for 1d arrays.")
-        cols_n = normalize_index(cols, self.shape[1])
-        _, sub_cols, _ = self._split_col_subsets(cols_n)
+        cols_n = collapse_identity(normalize_index(cols, self.shape[1]), self.shape[1])
         tdt = D.torch_dtype(self.dtype)
         v_dev = D.to_dev(v, tdt)
+        if cols_n is not None and len(cols_n) >= FULL_THEN_SELECT_MV * self.shape[1] and len(cols_n) > 0:
+            cd = self._cols_dev64(cols_n)           # X[:, cols] v[cols] = X (v with zeros elsewhere)
+            vm = torch.zeros_like(v_dev)
+            vm[cd] = v_dev[cd]
+            v_dev, cols_n = vm, None
+        _, sub_d, _ = self._sandwich_plan(cols_n)
         idx_d = self._full_dev_indices()
         if v_dev.ndim == 1:
             res = D.zeros((self.shape[0],), tdt)
             fused = set()
-            plan = self._cat_hist_plan() if (CAT_PAIRS_FUSED and cols_n is None) else None
+            plan = self._cat_hist_plan() if CAT_PAIRS_FUSED else None
             if plan is not None:
                 # all categorical blocks in ONE pass (one gather + one launch per block before:
-                # 20 categoricals 0.33 ms for 0.18 GB)
+                # 20 categoricals 0.33 ms for 0.18 GB); a column selection becomes zeros in the
+                # coefficient vector these blocks read
                 cl = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
                       for i in plan.cat_ids]
-                xsplit.multi_cat_matvec(plan, cl, v_dev, res)
+                vm = v_dev
+                if cols_n is not None:
+                    cd = self._cols_dev64(cols_n)
+                    vm = torch.zeros_like(v_dev)
+                    vm[cd] = v_dev[cd]
+                xsplit.multi_cat_matvec(plan, cl, vm, res)
                 fused = set(plan.cat_ids)
-            for bi, (mat, idx, sc) in enumerate(zip(self.matrices, idx_d, sub_cols)):
-                if (sc is not None and len(sc) == 0) or bi in fused:
+            for bi, (mat, idx, scd) in enumerate(zip(self.matrices, idx_d, sub_d)):
+                if (scd is not None and D.nlen(scd) == 0) or bi in fused:
                     continue
                 vb = v_dev[idx]
-                scd = D.idx_dev(sc)
                 if isinstance(mat, CategoricalMatrix):
                     mat._matvec_dev(vb, scd, res)
                 else:
@@ -685,10 +761,9 @@ class SplitMatrix(MatrixBase):
             from .ext import sparse as xs
 
             res = D.zeros((self.shape[0], v_dev.shape[1]), tdt)
-            for mat, idx, sc in zip(self.matrices, idx_d, sub_cols):
-                if sc is not None and len(sc) == 0:
+            for mat, idx, scd in zip(self.matrices, idx_d, sub_d):
+                if scd is not None and D.nlen(scd) == 0:
                     continue
-                scd = D.idx_dev(sc)
                 if scd is not None and D.nlen(scd) == mat.shape[1]:
                     scd = None
                 vb = v_dev[idx]
@@ -716,8 +791,11 @@ class SplitMatrix(MatrixBase):
             raise NotImplementedError(
                 "CategoricalMatrix.transpose_matvec is only implemented for 1d arrays.")
         rows_n = normalize_index(rows, self.shape[0])
-        cols_n = normalize_index(cols, self.shape[1])
-        pos, sub_cols, n_cols = self._split_col_subsets(cols_n)
+        cols_n = collapse_identity(normalize_index(cols, self.shape[1]), self.shape[1])
+        select = None
+        if cols_n is not None and len(cols_n) >= FULL_THEN_SELECT_MV * self.shape[1] and len(cols_n) > 0:
+            select, cols_n = cols_n, None           # all columns, the selection picked at the end
+        pos_d, sub_d, n_cols = self._sandwich_plan(cols_n)     # device index arrays (last selection cached)
         tdt = D.torch_dtype(self.dtype)
         v_dev = D.to_dev(v, tdt)
         rd = D.idx_dev(rows_n)
@@ -725,25 +803,27 @@ class SplitMatrix(MatrixBase):
             rd = None
         if v_dev.ndim == 1:
             res = D.zeros((n_cols,), tdt)
-            pos_d = self._full_dev_indices() if cols_n is None else self._dev_idx(pos)
             empty_rows = rows_n is not None and len(rows_n) == 0
             fused = set()
-            plan = self._cat_hist_plan() if (CAT_PAIRS_FUSED and cols_n is None and not empty_rows
+            plan = self._cat_hist_plan() if (CAT_PAIRS_FUSED and not empty_rows and n_cols > 0
                                              and not _cm.DETERMINISTIC) else None
             if plan is not None and plan.n_pairs > 0:
                 # every categorical block's histogram from ONE pass over the codes (one launch per
-                # block was ~35 us each: 20 categoricals 0.69 ms for 0.18 GB)
+                # block was ~35 us each: 20 categoricals 0.69 ms for 0.18 GB); a column selection
+                # picks its entries out of the full-length result
                 cl = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
                       for i in plan.cat_ids]
-                tgt = res if tdt == torch.float64 else D.zeros((n_cols,), torch.float64)
+                direct = cols_n is None and tdt == torch.float64
+                tgt = res if direct else D.zeros((self.shape[1],), torch.float64)
                 xsplit.multi_cat_pairs(plan, cl, v_dev, rd, tgt, vector=True)
-                if tgt is not res:
+                if not direct:
+                    if cols_n is not None:
+                        tgt = tgt[self._cols_dev64(cols_n)]
                     res += tgt.to(tdt)
                 fused = {i for i, *_ in plan.pairs}
-            for bi, (mat, pd, sc) in enumerate(zip(self.matrices, pos_d, sub_cols)):
-                if empty_rows or (sc is not None and len(sc) == 0) or bi in fused:
+            for bi, (mat, pd, scd) in enumerate(zip(self.matrices, pos_d, sub_d)):
+                if empty_rows or (scd is not None and D.nlen(scd) == 0) or bi in fused:
                     continue
-                scd = D.idx_dev(sc)
                 if isinstance(mat, CategoricalMatrix):
                     full = D.zeros((mat.shape[1],), tdt)
                     mat._transpose_matvec_dev(v_dev, rd, scd, full)
@@ -758,18 +838,18 @@ class SplitMatrix(MatrixBase):
             from .ext import sparse as xs
 
             res = D.zeros((n_cols, v_dev.shape[1]), tdt)
-            pos_d = self._full_dev_indices() if cols_n is None else self._dev_idx(pos)
             empty_rows = rows_n is not None and len(rows_n) == 0
-            for mat, pd, sc in zip(self.matrices, pos_d, sub_cols):
-                if empty_rows or (sc is not None and len(sc) == 0):
+            for mat, pd, scd in zip(self.matrices, pos_d, sub_d):
+                if empty_rows or (scd is not None and D.nlen(scd) == 0):
                     continue
-                scd = D.idx_dev(sc)
                 if scd is not None and D.nlen(scd) == mat.shape[1]:
                     scd = None
                 if isinstance(mat, DenseMatrix):
                     res[pd] += xd.dense_matvec_multi(mat._dev(), v_dev, rd, scd, True)
                 else:
                     res[pd] += xs.csr_matvec_multi(mat._dev(), v_dev, rd, scd, True)
+        if select is not None:
+            res, cols_n = res[self._cols_dev64(select)], select
         if not on_dev:
             res = D.to_host(res)
             if np.issubdtype(v.dtype, np.floating):

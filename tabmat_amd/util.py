@@ -42,6 +42,16 @@ def normalize_index(arr, length: int) -> Optional[np.ndarray]:
     return out
 
 
+def collapse_identity(idx: Optional[np.ndarray], length: int) -> Optional[np.ndarray]:
+    """A column selection that lists every column in order (glum passes its active set as
+    `cols=np.arange(p)` when nothing is excluded) is the unrestricted product: None, so that the
+    call takes the unrestricted kernels.  O(len) on the host, meant for COLUMN indices."""
+    if idx is not None and idx.size == length and length > 0 and idx[0] == 0 \
+            and idx[-1] == length - 1 and bool((idx[1:] > idx[:-1]).all()):
+        return None
+    return idx
+
+
 def _first_dim_mismatch(out, expected: int) -> None:
     if out is not None and out.shape[0] != expected:
         raise ValueError(
