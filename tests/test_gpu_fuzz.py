@@ -17,7 +17,9 @@ def _random_split(rng, dtype):
 
     n = int(rng.choice([1, 7, 64, 129, 1000, 4096, 5003, 20000]))
     blocks, dense_parts = [], []
-    kinds = rng.permutation(["dense", "sparse", "cat", "cat", "sparse", "dense"])[: rng.integers(1, 6)]
+    kinds = list(rng.permutation(["dense", "sparse", "cat", "cat", "sparse", "dense"])[: rng.integers(1, 6)])
+    if rng.random() < 0.3:          # a categorical-heavy design (fused pair tables, fused matvec)
+        kinds += ["cat"] * int(rng.integers(2, 12))
     for kind in kinds:
         if kind == "dense":
             k = int(rng.choice([1, 3, 16, 17, 64, 128, 130]))
@@ -85,6 +87,13 @@ def test_random_split_products(seed):
     close(X.sandwich(d, rows, cols), Er.T @ (d64[rows, None] * Er))
     close(X.matvec(v, cols), E[:, cols] @ v64[cols])
     close(X.transpose_matvec(w, rows, cols), Er.T @ w64[rows])
+    # a narrow selection (below the share from which the unrestricted product + selection is used)
+    few_c = np.sort(rng.choice(p, size=max(1, p // 5), replace=False)).astype(np.int32)
+    Ec = E[:, few_c]
+    close(X.sandwich(d, None, few_c), Ec.T @ (d64[:, None] * Ec))
+    close(X.sandwich(d, rows, few_c), Ec[rows].T @ (d64[rows, None] * Ec[rows]))
+    close(X.transpose_matvec(w, None, few_c), Ec.T @ w64)
+    close(X.sandwich(d, cols=np.arange(p)), E.T @ (d64[:, None] * E))
     # a short row list (row-list kernels: cost proportional to len(rows)), with repeats allowed
     few = rng.choice(n, size=max(1, n // 9), replace=False).astype(np.int64)
     Ef = E[few]
