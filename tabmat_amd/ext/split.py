@@ -202,13 +202,20 @@ class CatPairsPlan:
                         stride = width
                         desc.append([off, L[i], L[j], stride, pstart[i], pstart[j], 0, 0])
                     self.pairs.append((self.cat_ids[a], self.cat_ids[b], int(off), L[a], L[b], int(stride)))
-        self.bundles = D.to_dev(rows_w.reshape(-1))
-        self.wg_map = D.to_dev(np.asarray(wg_map if wg_map else [0], dtype=np.int32))
         self.n_wg = len(wg_map)
-        self.desc = D.to_dev(np.asarray(desc, dtype=np.int64).reshape(-1, 8))
+        self.n_pairs = len(desc)
+        # host copies (the layout is checked on the CPU: tests/test_abi_and_host_logic.py)
+        self.h_bundles = rows_w
+        self.h_wg_map = np.asarray(wg_map if wg_map else [0], dtype=np.int32)
+        self.h_desc = np.asarray(desc, dtype=np.int64).reshape(-1, 8)
+        if pos_arrays is None:             # layout only
+            self.covered = {(min(i, j), max(i, j)) for i, j, *_ in self.pairs}
+            return
+        self.bundles = D.to_dev(rows_w.reshape(-1))
+        self.wg_map = D.to_dev(self.h_wg_map)
+        self.desc = D.to_dev(self.h_desc)
         self.pos = torch.cat([p.to(torch.int64) for p in pos_arrays]) if pos_arrays else \
             D.zeros((0,), torch.int64)
-        self.n_pairs = len(desc)
         self.covered = {(min(i, j), max(i, j)) for i, j, *_ in self.pairs}
         self._cat_tab = (None, None)
 

@@ -298,3 +298,68 @@ def test_slab_ell_round_trip(wide):
             assert (b1 - b0) // 64 == (longest + U - 1) // U   # padded to the longest run only
     assert gptr[-1] == len(vals) and n_real == A.nnz
     np.testing.assert_array_equal(B, A.toarray())
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("diag_only", [False, True])
+def test_cat_pairs_plan_layout(seed, diag_only):
+    """The bundling of the categorical x categorical tables (tabmat_amd/ext/split.py::CatPairsPlan):
+    every table that fits a tile appears exactly once, tiles stay within the LDS budget and the slot
+    count, tables of one bundle do not overlap, the workgroup map is consistent."""
+    from tabmat_amd._lib import lib
+
+    cap = int(lib().tm_multi_cat_pairs_max_bins())
+    slots = int(lib().tm_multi_cat_pairs_max_slots())
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([1, 2, 3, 7, 20, 45, 100]))
+    pool = [1, 2, 3, 5, 12, 50, 100, 127, 128, 129, 300, 2000, cap, cap + 1, 40_000]
+    L = [int(rng.choice(pool)) for _ in range(k)]
+    plan = xsplit.CatPairsPlan([(10 + i, L[i]) for i in range(k)], None, diag_only=diag_only)
+    B, desc = plan.h_bundles, plan.h_desc
+    assert plan.n_bundles == 0 or B.shape[0] == plan.n_bundles
+    assert plan.slots <= slots and plan.bins <= cap
+    seen = {}
+    for (bi, bj, off, li, lj, stride), q in zip(plan.pairs, desc):
+        a, b = bi - 10, bj - 10
+        assert a <= b and (li, lj) == (L[a], L[b]) and (a, b) not in seen
+        seen[(a, b)] = (off, stride)
+        assert q[0] == off and q[1] == li and q[2] == lj and q[3] == stride and q[6] == int(a == b)
+    if diag_only:
+        assert set(seen) == {(a, a) for a in range(k) if L[a] <= cap}
+    else:
+        for a in range(k):
+            assert ((a, a) in seen) == (L[a] <= cap)
+            for b in range(a + 1, k):
+                assert ((a, b) in seen) == (L[a] * L[b] <= cap), (L[a], L[b])
+    # per bundle: slot counts, tile size, disjoint tables
+    wg = plan.h_wg_map
+    for y in range(plan.n_bundles):
+        na, nb, mode, width, wg0, parts, bins = (int(x) for x in B[y][:7])
+        assert 1 <= na <= slots and 1 <= nb <= slots and bins <= plan.bins <= cap and parts >= 1
+        assert (wg[wg0:wg0 + parts] == y).all() and (wg0 == 0 or wg[wg0 - 1] == y - 1)
+        A = [(int(B[y][8 + 2 * s]), int(B[y][9 + 2 * s])) for s in range(na)]
+        Bs = [(int(B[y][8 + 2 * slots + 2 * s]), int(B[y][9 + 2 * slots + 2 * s])) for s in range(nb)]
+        used = np.zeros(bins, dtype=np.int32)
+        for s, (a, ya) in enumerate(A):
+            for t, (b, xb) in enumerate(Bs):
+                if (mode == 1 and t < s) or (mode == 2 and t != s):
+                    continue
+                rows_ = ya + np.arange(L[a])[:, None] * width
+                cols_ = (xb + np.arange(L[b])[None, :]) if mode != 2 else np.zeros((1, 1), dtype=int)
+                if mode == 2:
+                    idx = (ya + np.arange(L[a]) * width)
+                elif mode == 1 and s == t:
+                    idx = (rows_ + cols_).ravel()
+                else:
+                    idx = (rows_ + cols_).ravel()
+                assert idx.min() >= 0 and idx.max() < bins
+                used[idx] += 1
+                # the scatter descriptor addresses the same bins
+                off, stride = seen[(min(a, b), max(a, b))] if a != b else seen[(a, a)]
+                if a == b:
+                    d_idx = off - y * plan.bins + np.arange(L[a]) * stride
+                    assert np.isin(d_idx, idx).all()
+                else:
+                    assert off - y * plan.bins == ya + xb and stride == width
+        assert used.max() <= 1
+    assert len(wg) == plan.n_wg or plan.n_wg == 0
