@@ -450,6 +450,24 @@ int tm_multi_cat_matvec_f64(const int64_t *cat_tab, int n_cats, const int64_t *p
                             int64_t n, double *out, void *stream);
 
 /* =====================================================================================
+ * A narrow column selection (`cols=`, a solver's active set) as one row-major dense block T, on
+ * which the unrestricted kernels then run (the reference's restricted loops, ext/dense.pyx:24-54,
+ * ext/sparse.pyx:17-77 / 211-260 with `cols`, cost in proportion to the selection):
+ *   tm_csr_densify_cols_*: T[r, colmap[c]] += value for every stored entry (r, c) of the CSR block
+ *     with colmap[c] >= 0 (colmap: device int32 [m], target column of T or -1); T zeroed by the caller.
+ *   tm_dense_gather_cols_*: T[r, t0 + q] = X[r, cols[q]], X (n, m) C- or F-ordered (order_f).
+ * T: device, row stride ld elements.
+ * ===================================================================================== */
+int tm_csr_densify_cols_f32(const float *data, const int32_t *indices, const int64_t *indptr, int64_t n,
+                            const int32_t *colmap, float *T, int64_t ld, void *stream);
+int tm_csr_densify_cols_f64(const double *data, const int32_t *indices, const int64_t *indptr, int64_t n,
+                            const int32_t *colmap, double *T, int64_t ld, void *stream);
+int tm_dense_gather_cols_f32(const float *X, int64_t n, int64_t m, int order_f, const int32_t *cols,
+                             int64_t n_sel, float *T, int64_t ld, int64_t t0, void *stream);
+int tm_dense_gather_cols_f64(const double *X, int64_t n, int64_t m, int order_f, const int32_t *cols,
+                             int64_t n_sel, double *T, int64_t ld, int64_t t0, void *stream);
+
+/* =====================================================================================
  * Assembly helper for SplitMatrix.sandwich (split_matrix.py:336-354): scatter a block
  * result into the float64 p x p output at the block's global column positions,
  *   out[ri[a], ci[b]] = src[a, b]  (and the transpose when mirror != 0);

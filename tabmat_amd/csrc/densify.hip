@@ -1,0 +1,69 @@
+// A narrow column selection of a SplitMatrix sandwich (`cols=`: a solver's active set) as ONE
+// row-major dense block: the selected columns of the dense blocks are gathered, the selected
+// columns of the sparse blocks are written out densely, and the tuned unrestricted kernels (MFMA
+// syrk, fused categorical x dense) run on the result -- the reference's restricted loops
+// (ext/dense.pyx:24-54, ext/sparse.pyx:17-77 and 211-260 with `cols`) cost in proportion to the
+// selection, which the generic restricted kernels here do not (they stream everything and drop).
+#include "common.hpp"
+
+namespace tmh {
+
+// T[r, colmap[c]] += value for every stored entry (r, c) whose column is selected (colmap >= 0).
+// 8 lanes per row.
+template <typename F>
+__global__ __launch_bounds__(256) void csr_densify_cols_kernel(
+    const F *__restrict__ data, const int32_t *__restrict__ indices,
+    const int64_t *__restrict__ indptr, int64_t n, const int32_t *__restrict__ colmap,
+    F *__restrict__ T, int64_t ld) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    if (r >= n) return;
+    const int g = threadIdx.x & 7;
+    const int64_t e1 = indptr[r + 1];
+    for (int64_t e = indptr[r] + g; e < e1; e += 8) {
+        const int t = colmap[indices[e]];
+        if (t >= 0) atomic_add(T + r * ld + t, data[e]);     // (duplicate entries add up)
+    }
+}
+
+// T[r, t0 + q] = X[r, cols[q]] for a C- or F-ordered dense block (16 rows x 16 selected columns
+// per 256-thread block)
+template <typename F>
+__global__ __launch_bounds__(256) void dense_gather_cols_kernel(
+    const F *__restrict__ X, int64_t n, int64_t m, int order_f, const int32_t *__restrict__ cols,
+    int64_t n_sel, F *__restrict__ T, int64_t ld, int64_t t0) {
+    const int64_t q = (int64_t)blockIdx.y * 16 + (threadIdx.x & 15);
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= n_sel || r >= n) return;
+    const int64_t c = cols[q];
+    T[r * ld + t0 + q] = order_f ? X[c * n + r] : X[r * m + c];
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+extern "C" {
+#define TM_DENSIFY(SUF, F)                                                                              \
+    int tm_csr_densify_cols_##SUF(const F *data, const int32_t *indices, const int64_t *indptr,         \
+                                  int64_t n, const int32_t *colmap, F *T, int64_t ld, void *stream) {   \
+        if (n <= 0) return TM_OK;                                                                       \
+        hipStream_t st = as_stream(stream);                                                             \
+        hipLaunchKernelGGL((csr_densify_cols_kernel<F>), dim3((unsigned)ceil_div(n * 8, 256)),          \
+                           dim3(256), 0, st, data, indices, indptr, n, colmap, T, ld);                  \
+        TM_LAUNCH_CHECK();                                                                              \
+        return TM_OK;                                                                                   \
+    }                                                                                                   \
+    int tm_dense_gather_cols_##SUF(const F *X, int64_t n, int64_t m, int order_f, const int32_t *cols,  \
+                                   int64_t n_sel, F *T, int64_t ld, int64_t t0, void *stream) {         \
+        if (n <= 0 || n_sel <= 0) return TM_OK;                                                         \
+        hipStream_t st = as_stream(stream);                                                             \
+        hipLaunchKernelGGL((dense_gather_cols_kernel<F>),                                               \
+                           dim3((unsigned)ceil_div(n, 16), (unsigned)ceil_div(n_sel, 16)), dim3(256),   \
+                           0, st, X, n, m, order_f, cols, n_sel, T, ld, t0);                            \
+        TM_LAUNCH_CHECK();                                                                              \
+        return TM_OK;                                                                                   \
+    }
+TM_DENSIFY(f32, float)
+TM_DENSIFY(f64, double)
+#undef TM_DENSIFY
+}  // extern "C"

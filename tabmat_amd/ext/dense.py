@@ -73,3 +73,10 @@ def transpose_square_dot_weights(X: DenseDev, weights, shift):
     call(f"tm_dense_col_sq_dev_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(weights),
          D.p(shift), D.p(out), D.stream_ptr())
     return out
+
+
+def dense_gather_cols(X: DenseDev, cols, T, t0: int):
+    """T[:, t0 + q] = X[:, cols[q]] (cols: int32 device tensor); T: (n, ld) row-major device tensor."""
+    D.same_float("dense_gather_cols", X.buf, T)
+    call(f"tm_dense_gather_cols_{D.fsuf(T)}", D.p(X.buf), X.n, X.m, int(X.order_f), D.p(cols),
+         D.nlen(cols), D.p(T), T.shape[1], int(t0), D.stream_ptr())

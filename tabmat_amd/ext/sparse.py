@@ -273,3 +273,11 @@ def transpose_square_dot_weights(A: CsrDev, weights):
     call(f"tm_csr_col_sq_{D.fsuf(A.data)}", D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n, A.m,
          D.p(weights), D.p(out), D.stream_ptr())
     return out
+
+
+def csr_densify_cols(A: CsrDev, colmap, T):
+    """T[r, colmap[c]] += value for the stored entries of the selected columns (colmap: int32 device
+    tensor [A.m], -1 = not selected); T: (n, ld) row-major device tensor, zeroed by the caller."""
+    D.same_float("csr_densify_cols", A.data, T)
+    call(f"tm_csr_densify_cols_{D.fsuf(T)}", D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n,
+         D.p(colmap), D.p(T), T.shape[1], D.stream_ptr())

@@ -57,6 +57,12 @@ FULL_THEN_SELECT = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT", "0.5"))
 # unrestricted kernels are never slower (cfg4 shape, 2M rows, 5 % of the columns: 0.88 / 0.99 ms
 # restricted, 0.55 / 0.60 ms unrestricted + selection), so they always take this form
 FULL_THEN_SELECT_MV = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT_MV", "0.0"))
+# a NARROW selection (below FULL_THEN_SELECT, at most NARROW_COLS selected dense + sparse columns -- one
+# syrk panel):
+# those columns are gathered / written out densely into one row-major block and the unrestricted
+# kernels run on [that block | the categorical blocks] -- cost in proportion to the selection, as
+# in the reference, instead of the full K2 / K3 passes of the generic restricted kernels
+NARROW_COLS = int(os.environ.get("TABMAT_AMD_NARROW_COLS", "128"))
 # Entry indices inside one sparse block's twins are 32-bit: a SplitMatrix whose sparse block holds
 # this many nonzeros or more is worked on in ROW PARTS (the sandwich is a sum over rows), each with
 # twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
@@ -527,6 +533,91 @@ class SplitMatrix(MatrixBase):
             out = D.zeros((n_cols, n_cols), torch.float64)
         return out
 
+    def _narrow_plan(self, cols_host):
+        """Bookkeeping of the dense-block form of a narrow column selection (see NARROW_COLS), or
+        None when it does not apply.  The last selection is cached."""
+        key = np.asarray(cols_host).tobytes()
+        hit = self.__dict__.get("_narrow_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        nar = None
+        pos_h, sub_h, n_cols = self._split_col_subsets(cols_host)
+        mats = self.matrices
+        noncat = [b for b, mb in enumerate(mats) if not isinstance(mb, CategoricalMatrix)]
+        cat = [b for b, mb in enumerate(mats) if isinstance(mb, CategoricalMatrix)]
+        w = sum(len(sub_h[b]) for b in noncat)
+        itemsize = np.dtype(self.dtype).itemsize
+        if (noncat and 0 < w <= NARROW_COLS and self.shape[0] > 0
+                and all(isinstance(mats[b], (DenseMatrix, SparseMatrix)) and mats[b].dtype == self.dtype
+                        for b in noncat)
+                and any(len(sub_h[b]) < mats[b].shape[1] for b in noncat)
+                and self.shape[0] * (w + 1) * itemsize * 4 < torch.cuda.mem_get_info()[0]):
+            w_pad = w + (w & 1)               # even width: 16-byte rows for the categorical x dense kernel
+            t0, parts = 0, []
+            sel = np.zeros(n_cols, dtype=np.int64)
+            for b in noncat:
+                s = len(sub_h[b])
+                if s == 0:
+                    continue
+                sc = np.asarray(sub_h[b], dtype=np.int32)
+                if isinstance(mats[b], SparseMatrix):
+                    cmap = np.full(mats[b].shape[1], -1, dtype=np.int32)
+                    cmap[sc] = t0 + np.arange(s, dtype=np.int32)
+                    parts.append((b, t0, s, D.to_dev(cmap)))
+                else:
+                    parts.append((b, t0, s, D.to_dev(sc)))
+                sel[np.asarray(pos_h[b], dtype=np.int64)] = t0 + np.arange(s)
+                t0 += s
+            off, cat_off, cat_sub = w_pad, {}, {}
+            for i in cat:
+                cat_off[i] = off
+                if len(sub_h[i]):
+                    sel[np.asarray(pos_h[i], dtype=np.int64)] = off + np.asarray(sub_h[i], dtype=np.int64)
+                    cat_sub[i] = D.idx_dev(sub_h[i], torch.int64)
+                off += mats[i].shape[1]
+            indices = [np.arange(w_pad)] + [cat_off[i] + np.arange(mats[i].shape[1]) for i in cat]
+            nar = dict(w=w, w_pad=w_pad, parts=parts, cat=cat, cat_sub=cat_sub, indices=indices,
+                       sel=D.to_dev(sel), tmp=None, n_cols=n_cols)
+        self.__dict__["_narrow_cache"] = (key, nar)
+        return nar
+
+    def _sandwich_narrow(self, nar, d, rows, colsum):
+        """The sandwich under a narrow column selection: the selected dense / sparse columns as one
+        dense block T, the unrestricted product of [T | categorical blocks], the selected rows and
+        columns of that (small) result."""
+        from .ext import dense as xd
+        from .ext import sparse as xs
+        from .ext._types import DenseDev
+
+        n = self.shape[0]
+        T = torch.zeros((n, nar["w_pad"]), dtype=d.dtype, device=d.device)
+        for b, t0, s, idx in nar["parts"]:
+            mb = self.matrices[b]
+            if isinstance(mb, SparseMatrix):
+                xs.csr_densify_cols(mb._dev(), idx, T)
+            else:
+                xd.dense_gather_cols(mb._dev(), idx, T, t0)
+        tmp = nar["tmp"]
+        if tmp is None:
+            tmp = nar["tmp"] = SplitMatrix([DenseMatrix(T)] + [self.matrices[i] for i in nar["cat"]],
+                                           nar["indices"])
+        dm = tmp.matrices[0]
+        dm._devblk = DenseDev(T, n, nar["w_pad"], 0)
+        try:
+            cs_tmp = [None] * len(tmp.matrices) if colsum is not None else None
+            full = tmp._sandwich_dev(d, rows, None, None, cs_tmp)
+        finally:
+            dm._devblk = None                 # T is released with this call
+        if colsum is not None:
+            if cs_tmp[0] is not None:
+                for b, t0, s, _ in nar["parts"]:
+                    colsum[b] = cs_tmp[0][t0:t0 + s]
+            for k, i in enumerate(nar["cat"]):
+                if cs_tmp[1 + k] is not None and i in nar["cat_sub"]:
+                    colsum[i] = cs_tmp[1 + k][nar["cat_sub"][i]]
+        sel = nar["sel"]
+        return full.index_select(0, sel).index_select(1, sel)
+
     def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None):
         """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
         Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
@@ -546,6 +637,10 @@ class SplitMatrix(MatrixBase):
         parts = self._parts()
         if parts is not None:
             return self._sandwich_parts(parts, d, rows, cols_host, colsum)
+        if cols_host is not None and plan is None and NARROW_COLS > 0:
+            nar = self._narrow_plan(cols_host)
+            if nar is not None and d.dtype == D.torch_dtype(self.dtype):
+                return self._sandwich_narrow(nar, d, rows, colsum)
         pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
         out = D.zeros((n_cols, n_cols), torch.float64)
         mats = self.matrices

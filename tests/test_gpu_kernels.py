@@ -734,3 +734,51 @@ def test_sparse_sandwich_direct(n, m, dens, dtype):
         got = sm.sandwich(d, rows=rows, cols=cols)
         want = orc.sparse_sandwich(sps.csc_matrix(S), sps.csr_matrix(S), d, rows, cols)
         assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_narrow_column_selection_dense_block_form(dtype, order):
+    """A narrow `cols=` selection runs as [selected dense + sparse columns written out as one dense
+    block | categorical blocks] (tm_csr_densify_cols_*, tm_dense_gather_cols_*): against the oracle,
+    with rows, with selections that leave out whole blocks, and through StandardizedMatrix."""
+    import tabmat_amd as tm
+    import tabmat_amd.split_matrix as smod
+    from oracle import oracle as orc
+
+    n = 12_345
+    specs, idx = cs.mixed_specs(n, 40, 90, (30, 7, 120), seed=5, dtype=dtype, order=order,
+                                missing=True, drop_first=True)
+    X = to_tm_split(specs, idx, dtype)
+    blocks = [cs.to_oracle_block(s) for s in specs]
+    p = X.shape[1]
+    rng = np.random.default_rng(3)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 8)] = 0
+    rows = np.sort(rng.choice(n, n // 3, replace=False))
+    tol = 1e-10 if dtype == np.float64 else 3e-5
+    sels = [np.sort(rng.choice(p, 17, replace=False)), np.arange(3, 40, 5), np.array([p - 1]),
+            np.sort(rng.choice(p, p // 3, replace=False)), np.arange(130, p)]
+    for cols in sels:
+        for r in (None, rows):
+            got = X.sandwich(d, rows=r, cols=cols)
+            want = orc.split_sandwich(blocks, idx, d, r, cols)
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    # same numbers as the generic restricted kernels
+    cols = sels[0]
+    a = X.sandwich(d, cols=cols)
+    old, smod.NARROW_COLS = smod.NARROW_COLS, 0
+    try:
+        b = X.sandwich(d, cols=cols)
+    finally:
+        smod.NARROW_COLS = old
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+    # the standardized view (inner sandwich + column sums from the same pass)
+    shift, mult = rng.standard_normal(p), rng.random(p) + 0.5
+    E = orc.split_toarray(blocks, idx) * mult + shift
+    for r in (None, rows):
+        got = tm.StandardizedMatrix(X, shift, mult).sandwich(d, r, cols)
+        Er = E[:, cols] if r is None else E[np.ix_(r, cols)]
+        dr = d.astype(np.float64) if r is None else d[r].astype(np.float64)
+        want = Er.T @ (dr[:, None] * Er)
+        assert np.abs(np.asarray(got) - want).max() <= (1e-9 if dtype == np.float64 else 5e-3) * max(1.0, np.abs(want).max())
