@@ -363,3 +363,44 @@ def test_cat_pairs_plan_layout(seed, diag_only):
                     assert off - y * plan.bins == ya + xb and stride == width
         assert used.max() <= 1
     assert len(wg) == plan.n_wg or plan.n_wg == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_split_col_subsets_table_form_equals_merge_loop(seed):
+    """The table-lookup form of split_col_subsets (strictly increasing selections) and the merge
+    loop it replaces (ext/split.pyx:157-209) give the same lists; unsorted / repeated selections
+    fall back to the loop; the identity selection collapses to None."""
+    from tabmat_amd.util import collapse_identity
+
+    rng = np.random.default_rng(100 + seed)
+    p = int(rng.choice([1, 5, 64, 300]))
+    perm = rng.permutation(p)
+    k = int(rng.integers(1, min(p, 6) + 1))
+    cuts = np.sort(rng.choice(np.arange(1, p), size=k - 1, replace=False)) if p > 1 and k > 1 else []
+    indices = [np.sort(part).astype(np.int64) for part in np.split(perm, cuts)]
+
+    class Fake:
+        pass
+
+    f = Fake()
+    f.indices = indices
+    g = Fake()
+    g.indices = indices
+    g.__dict__["_col_maps"] = None          # forces the merge loop
+    for size in {1, max(1, p // 3), p}:
+        cols = np.sort(rng.choice(p, size=size, replace=False)).astype(np.int32)
+        a = xsplit.split_col_subsets(f, cols)
+        b = xsplit.split_col_subsets(g, cols)
+        assert a[2] == b[2]
+        for x, y in zip(a[0] + a[1], b[0] + b[1]):
+            assert np.array_equal(x, y)
+    rep = np.array([0, 0], dtype=np.int32) if p > 0 else None
+    if rep is not None:
+        a, b = xsplit.split_col_subsets(f, rep), xsplit.split_col_subsets(g, rep)
+        for x, y in zip(a[0] + a[1], b[0] + b[1]):
+            assert np.array_equal(x, y)
+    assert collapse_identity(np.arange(p, dtype=np.int32), p) is None
+    assert collapse_identity(None, p) is None
+    if p > 1:
+        assert collapse_identity(np.arange(p, dtype=np.int32)[::-1].copy(), p) is not None
+        assert collapse_identity(np.arange(p - 1, dtype=np.int32), p) is not None

@@ -81,8 +81,22 @@ def test_cfg4_split_sandwich_10M():
             counts = torch.bincount(m._dev().to(torch.int64), minlength=m.shape[1]).to(torch.float64)
             ii = torch.as_tensor(idx, device="cuda")
             assert torch.equal(Sones[ii, ii], counts)
-    # true oracle comparison on a random row subset via rows=
+    # column selections at full size: a narrow one (dense-block form of the selected columns), a
+    # wide one (unrestricted product + selection) and the identity must all be sub-blocks of S1
     rng = np.random.default_rng(0)
+    for share in (0.04, 0.7):
+        cols = np.sort(rng.choice(p, size=int(share * p), replace=False)).astype(np.int32)
+        ct = torch.as_tensor(cols.astype(np.int64), device="cuda")
+        Sc = X.sandwich(d1, cols=cols)
+        want = S1[ct][:, ct]
+        assert float((Sc - want).abs().max() / want.abs().max()) < 1e-12
+        assert float((X.transpose_matvec(d1, cols=cols) - tmv[ct]).abs().max() / tmv.abs().max()) < 1e-12
+        vm = torch.zeros(p, dtype=torch.float64, device="cuda")
+        vm[ct] = 1.0
+        assert float((X.matvec(ones, cols=cols) - X.matvec(vm)).abs().max()) < 1e-9
+    assert torch.equal(X.sandwich(d1, cols=np.arange(p)), S1) or \
+        float((X.sandwich(d1, cols=np.arange(p)) - S1).abs().max() / S1.abs().max()) < 1e-12
+    # true oracle comparison on a random row subset via rows=
     rows = np.sort(rng.choice(n, size=20_000, replace=False)).astype(np.int32)
     rows_t = torch.as_tensor(rows.astype(np.int64), device="cuda")
     sub = X.sandwich(d1, rows=rows)
