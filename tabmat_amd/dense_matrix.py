@@ -93,6 +93,12 @@ class DenseMatrix(MatrixBase):
             self._devblk_c = twin
         return twin
 
+    def _values_finite(self) -> bool:
+        """True when the block holds no inf / nan (checked once; see SplitMatrix.matvec)."""
+        if getattr(self, "_finite", None) is None:
+            self._finite = bool(torch.isfinite(self._dev().buf).all().item())
+        return self._finite
+
     def to_device(self):
         """Upload now (otherwise the first product does it)."""
         self._dev_c()

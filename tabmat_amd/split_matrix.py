@@ -348,6 +348,11 @@ class SplitMatrix(MatrixBase):
         self.__dict__["_plan_cache"] = (key, (pos_d, sub_d, n_cols))    # inside a graph capture)
         return pos_d, sub_d, n_cols
 
+    def _blocks_finite(self) -> bool:
+        """No stored inf / nan in any dense or sparse block (checked once per block)."""
+        return all(mb._values_finite() for mb in self.matrices
+                   if isinstance(mb, (DenseMatrix, SparseMatrix)))
+
     def _cols_dev64(self, cols_host):
         """The column selection as an int64 device tensor (last selection cached)."""
         key = np.asarray(cols_host).tobytes()
@@ -816,7 +821,8 @@ class SplitMatrix(MatrixBase):
         cols_n = collapse_identity(normalize_index(cols, self.shape[1]), self.shape[1])
         tdt = D.torch_dtype(self.dtype)
         v_dev = D.to_dev(v, tdt)
-        if cols_n is not None and len(cols_n) >= FULL_THEN_SELECT_MV * self.shape[1] and len(cols_n) > 0:
+        if cols_n is not None and len(cols_n) >= FULL_THEN_SELECT_MV * self.shape[1] and len(cols_n) > 0 \
+                and self._blocks_finite():      # (0 x inf of an excluded column would leak a NaN)
             cd = self._cols_dev64(cols_n)           # X[:, cols] v[cols] = X (v with zeros elsewhere)
             vm = torch.zeros_like(v_dev)
             vm[cd] = v_dev[cd]

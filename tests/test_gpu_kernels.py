@@ -782,3 +782,22 @@ def test_narrow_column_selection_dense_block_form(dtype, order):
         dr = d.astype(np.float64) if r is None else d[r].astype(np.float64)
         want = Er.T @ (dr[:, None] * Er)
         assert np.abs(np.asarray(got) - want).max() <= (1e-9 if dtype == np.float64 else 5e-3) * max(1.0, np.abs(want).max())
+
+
+def test_matvec_column_selection_does_not_touch_excluded_inf_columns():
+    """matvec with `cols` runs as X (v with zeros on the excluded columns) only when the blocks
+    hold no inf / nan: an excluded column with an inf must not leak 0 x inf = nan."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(0)
+    n = 5000
+    A = rng.standard_normal((n, 6))
+    A[17, 2] = np.inf
+    S = sps.random(n, 9, density=0.2, format="csc", random_state=rng)
+    X = tm.SplitMatrix([tm.DenseMatrix(A), tm.SparseMatrix(S), tm.CategoricalMatrix(rng.integers(0, 4, n))])
+    cols = np.array([0, 1, 3, 4, 5, 6, 8, 15, 16])
+    v = rng.standard_normal(X.shape[1])
+    got = X.matvec(v, cols=cols)
+    E = np.hstack([A, S.toarray(), np.eye(4)[X.matrices[2].indices]])
+    want = E[:, cols] @ v[cols]
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-12 * max(1, np.abs(want).max())
