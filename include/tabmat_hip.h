@@ -455,6 +455,9 @@ int tm_multi_cat_matvec_f64(const int64_t *cat_tab, int n_cats, const int64_t *p
  * ext/sparse.pyx:17-77 / 211-260 with `cols`, cost in proportion to the selection):
  *   tm_csr_densify_cols_*: T[r, colmap[c]] += value for every stored entry (r, c) of the CSR block
  *     with colmap[c] >= 0 (colmap: device int32 [m], target column of T or -1); T zeroed by the caller.
+ *   tm_csc_densify_cols_*: the same from the CSC form (rows / vals: the entries sorted by column):
+ *     seg: device int64 [n_sel][2] = {first entry, end} of every selected column, tcol: device int32
+ *     [n_sel] its column of T; max_len: the longest selected column (sizes the launch).
  *   tm_dense_gather_cols_*: T[r, t0 + q] = X[r, cols[q]], X (n, m) C- or F-ordered (order_f).
  * T: device, row stride ld elements.
  * ===================================================================================== */
@@ -462,6 +465,10 @@ int tm_csr_densify_cols_f32(const float *data, const int32_t *indices, const int
                             const int32_t *colmap, float *T, int64_t ld, void *stream);
 int tm_csr_densify_cols_f64(const double *data, const int32_t *indices, const int64_t *indptr, int64_t n,
                             const int32_t *colmap, double *T, int64_t ld, void *stream);
+int tm_csc_densify_cols_f32(const int32_t *rows, const float *vals, const int64_t *seg, const int32_t *tcol,
+                            int64_t n_sel, int64_t max_len, float *T, int64_t ld, void *stream);
+int tm_csc_densify_cols_f64(const int32_t *rows, const double *vals, const int64_t *seg, const int32_t *tcol,
+                            int64_t n_sel, int64_t max_len, double *T, int64_t ld, void *stream);
 int tm_dense_gather_cols_f32(const float *X, int64_t n, int64_t m, int order_f, const int32_t *cols,
                              int64_t n_sel, float *T, int64_t ld, int64_t t0, void *stream);
 int tm_dense_gather_cols_f64(const double *X, int64_t n, int64_t m, int order_f, const int32_t *cols,

@@ -3,7 +3,7 @@ import os, sys, time, torch
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tabmat_amd import synth
-N = 2_000_000
+N = int(os.environ.get("TM_ROWS", "2000000"))
 X = synth.mixed_split(N)
 p = X.shape[1]
 d = torch.rand(N, dtype=torch.float64, device="cuda")

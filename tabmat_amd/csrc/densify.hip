@@ -25,6 +25,20 @@ __global__ __launch_bounds__(256) void csr_densify_cols_kernel(
     }
 }
 
+// The same from the CSC form (rows / values sorted by column, CsrDev.csc_blocks): only the entries
+// of the selected columns are touched.  seg[q] = {first entry, end} of selected column q, tcol[q]
+// its column of T.
+template <typename F>
+__global__ __launch_bounds__(256) void csc_densify_cols_kernel(
+    const int32_t *__restrict__ rows, const F *__restrict__ vals, const int64_t *__restrict__ seg,
+    const int32_t *__restrict__ tcol, F *__restrict__ T, int64_t ld) {
+    const int64_t e0 = seg[2 * blockIdx.y], e1 = seg[2 * blockIdx.y + 1];
+    const int t = tcol[blockIdx.y];
+    for (int64_t e = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e1;
+         e += (int64_t)gridDim.x * blockDim.x)
+        atomic_add(T + (int64_t)rows[e] * ld + t, vals[e]);
+}
+
 // T[r, t0 + q] = X[r, cols[q]] for a C- or F-ordered dense block (16 rows x 16 selected columns
 // per 256-thread block)
 template <typename F>
@@ -50,6 +64,17 @@ extern "C" {
         hipStream_t st = as_stream(stream);                                                             \
         hipLaunchKernelGGL((csr_densify_cols_kernel<F>), dim3((unsigned)ceil_div(n * 8, 256)),          \
                            dim3(256), 0, st, data, indices, indptr, n, colmap, T, ld);                  \
+        TM_LAUNCH_CHECK();                                                                              \
+        return TM_OK;                                                                                   \
+    }                                                                                                   \
+    int tm_csc_densify_cols_##SUF(const int32_t *rows, const F *vals, const int64_t *seg,               \
+                                  const int32_t *tcol, int64_t n_sel, int64_t max_len, F *T,            \
+                                  int64_t ld, void *stream) {                                           \
+        if (n_sel <= 0 || max_len <= 0) return TM_OK;                                                   \
+        hipStream_t st = as_stream(stream);                                                             \
+        const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(ceil_div(max_len, 1024), 1024));      \
+        hipLaunchKernelGGL((csc_densify_cols_kernel<F>), dim3((unsigned)gx, (unsigned)n_sel),           \
+                           dim3(256), 0, st, rows, vals, seg, tcol, T, ld);                             \
         TM_LAUNCH_CHECK();                                                                              \
         return TM_OK;                                                                                   \
     }                                                                                                   \

@@ -281,3 +281,11 @@ def csr_densify_cols(A: CsrDev, colmap, T):
     D.same_float("csr_densify_cols", A.data, T)
     call(f"tm_csr_densify_cols_{D.fsuf(T)}", D.p(A.data), D.p(A.indices), D.p(A.indptr), A.n,
          D.p(colmap), D.p(T), T.shape[1], D.stream_ptr())
+
+
+def csc_densify_cols(rows, vals, seg, tcol, max_len, T):
+    """The same from the CSC form (CsrDev.csc_blocks): seg int64 [n_sel, 2] entry ranges of the
+    selected columns, tcol int32 [n_sel] their columns of T."""
+    D.same_float("csc_densify_cols", vals, T)
+    call(f"tm_csc_densify_cols_{D.fsuf(T)}", D.p(rows), D.p(vals), D.p(seg), D.p(tcol),
+         int(tcol.numel()), int(max_len), D.p(T), T.shape[1], D.stream_ptr())

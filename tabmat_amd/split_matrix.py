@@ -566,9 +566,14 @@ class SplitMatrix(MatrixBase):
                     continue
                 sc = np.asarray(sub_h[b], dtype=np.int32)
                 if isinstance(mats[b], SparseMatrix):
-                    cmap = np.full(mats[b].shape[1], -1, dtype=np.int32)
-                    cmap[sc] = t0 + np.arange(s, dtype=np.int32)
-                    parts.append((b, t0, s, D.to_dev(cmap)))
+                    # from the CSC form (built once per block, a device sort): only the selected
+                    # columns' entries are read -- 1.4 -> 0.1 ms at cfg4 / 5 % against a CSR pass
+                    rws, vls, bstart, _, col_bptr = mats[b]._dev().csc_blocks()
+                    cd = D.idx_dev(sc, torch.int64)
+                    seg = torch.stack([bstart[col_bptr[cd]], bstart[col_bptr[cd + 1]]], dim=1).contiguous()
+                    mx = int((seg[:, 1] - seg[:, 0]).max().item()) if s else 0
+                    tcol = D.to_dev(t0 + np.arange(s, dtype=np.int32))
+                    parts.append((b, t0, s, (rws, vls, seg, tcol, mx)))
                 else:
                     parts.append((b, t0, s, D.to_dev(sc)))
                 sel[np.asarray(pos_h[b], dtype=np.int64)] = t0 + np.arange(s)
@@ -599,7 +604,7 @@ class SplitMatrix(MatrixBase):
         for b, t0, s, idx in nar["parts"]:
             mb = self.matrices[b]
             if isinstance(mb, SparseMatrix):
-                xs.csr_densify_cols(mb._dev(), idx, T)
+                xs.csc_densify_cols(*idx, T)
             else:
                 xd.dense_gather_cols(mb._dev(), idx, T, t0)
         tmp = nar["tmp"]

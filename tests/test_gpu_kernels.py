@@ -801,3 +801,41 @@ def test_matvec_column_selection_does_not_touch_excluded_inf_columns():
     E = np.hstack([A, S.toarray(), np.eye(4)[X.matrices[2].indices]])
     want = E[:, cols] @ v[cols]
     assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-12 * max(1, np.abs(want).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_densify_entry_points(dtype):
+    """tm_csr_densify_cols_* / tm_csc_densify_cols_* / tm_dense_gather_cols_* against numpy."""
+    import torch
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext import sparse as xs
+    from tabmat_amd.ext._types import CsrDev, DenseDev
+
+    rng = np.random.default_rng(4)
+    n, m = 3001, 77
+    S = sps.random(n, m, density=0.07, format="csr", random_state=rng).astype(dtype)
+    A = CsrDev.from_scipy(S)
+    sel = np.sort(rng.choice(m, 9, replace=False)).astype(np.int32)
+    want = S.toarray()[:, sel]
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    T = torch.zeros((n, 12), dtype=tdt, device="cuda")
+    cmap = np.full(m, -1, dtype=np.int32)
+    cmap[sel] = 2 + np.arange(9, dtype=np.int32)
+    xs.csr_densify_cols(A, D.to_dev(cmap), T)
+    got = T.cpu().numpy()
+    assert np.array_equal(got[:, 2:11], want) and not got[:, :2].any() and not got[:, 11:].any()
+    T.zero_()
+    rws, vls, bstart, _, col_bptr = A.csc_blocks()
+    cd = D.idx_dev(sel, torch.int64)
+    seg = torch.stack([bstart[col_bptr[cd]], bstart[col_bptr[cd + 1]]], dim=1).contiguous()
+    xs.csc_densify_cols(rws, vls, seg, D.to_dev(2 + np.arange(9, dtype=np.int32)),
+                        int((seg[:, 1] - seg[:, 0]).max().item()), T)
+    assert np.array_equal(T.cpu().numpy()[:, 2:11], want)
+    X = rng.standard_normal((n, 20)).astype(dtype)
+    pick = np.array([0, 3, 4, 19], dtype=np.int32)
+    for arr in (X, np.asfortranarray(X)):
+        T.zero_()
+        xd.dense_gather_cols(DenseDev.from_host(arr), D.to_dev(pick), T, 5)
+        got = T.cpu().numpy()
+        assert np.array_equal(got[:, 5:9], X[:, pick]) and not got[:, :5].any() and not got[:, 9:].any()
