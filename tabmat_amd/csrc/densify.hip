@@ -52,6 +52,27 @@ __global__ __launch_bounds__(256) void dense_gather_cols_kernel(
     T[r * ld + t0 + q] = order_f ? X[c * n + r] : X[r * m + c];
 }
 
+// F-ordered source: 64 consecutive rows of a column are one 512-byte read; the 64 x 32 tile is
+// turned in LDS so that T is written in 32-element row segments.
+template <typename F>
+__global__ __launch_bounds__(256) void dense_gather_cols_f_kernel(
+    const F *__restrict__ X, int64_t n, const int32_t *__restrict__ cols, int64_t n_sel,
+    F *__restrict__ T, int64_t ld, int64_t t0) {
+    __shared__ F tile[64][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, q0 = (int64_t)blockIdx.y * 32;
+    const int rl = threadIdx.x & 63;
+    for (int qq = threadIdx.x >> 6; qq < 32; qq += 4) {
+        F v = F(0);
+        if (q0 + qq < n_sel && r0 + rl < n) v = X[(int64_t)cols[q0 + qq] * n + r0 + rl];
+        tile[rl][qq] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int rr = e >> 5, qq = e & 31;
+        if (r0 + rr < n && q0 + qq < n_sel) T[(r0 + rr) * ld + t0 + q0 + qq] = tile[rr][qq];
+    }
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -82,9 +103,14 @@ extern "C" {
                                    int64_t n_sel, F *T, int64_t ld, int64_t t0, void *stream) {         \
         if (n <= 0 || n_sel <= 0) return TM_OK;                                                         \
         hipStream_t st = as_stream(stream);                                                             \
-        hipLaunchKernelGGL((dense_gather_cols_kernel<F>),                                               \
-                           dim3((unsigned)ceil_div(n, 16), (unsigned)ceil_div(n_sel, 16)), dim3(256),   \
-                           0, st, X, n, m, order_f, cols, n_sel, T, ld, t0);                            \
+        if (order_f)                                                                                    \
+            hipLaunchKernelGGL((dense_gather_cols_f_kernel<F>),                                         \
+                               dim3((unsigned)ceil_div(n, 64), (unsigned)ceil_div(n_sel, 32)),          \
+                               dim3(256), 0, st, X, n, cols, n_sel, T, ld, t0);                         \
+        else                                                                                            \
+            hipLaunchKernelGGL((dense_gather_cols_kernel<F>),                                           \
+                               dim3((unsigned)ceil_div(n, 16), (unsigned)ceil_div(n_sel, 16)),          \
+                               dim3(256), 0, st, X, n, m, order_f, cols, n_sel, T, ld, t0);             \
         TM_LAUNCH_CHECK();                                                                              \
         return TM_OK;                                                                                   \
     }
