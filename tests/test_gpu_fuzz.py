@@ -19,7 +19,7 @@ def _random_split(rng, dtype):
     blocks, dense_parts = [], []
     kinds = list(rng.permutation(["dense", "sparse", "cat", "cat", "sparse", "dense"])[: rng.integers(1, 6)])
     if rng.random() < 0.3:          # a categorical-heavy design (fused pair tables, fused matvec)
-        kinds += ["cat"] * int(rng.integers(2, 12))
+        kinds += ["cat_small"] * int(rng.integers(2, 12))   # (few levels each: E stays small)
     for kind in kinds:
         if kind == "dense":
             k = int(rng.choice([1, 3, 16, 17, 64, 128, 130]))
@@ -35,7 +35,7 @@ def _random_split(rng, dtype):
             blocks.append(tm.SparseMatrix(S))
             dense_parts.append(S.toarray().astype(np.float64))
         else:
-            ncat = int(rng.choice([1, 2, 5, 40, 300, 700, 5000]))
+            ncat = int(rng.choice([2, 3, 5, 12, 40] if kind == "cat_small" else [1, 2, 5, 40, 300, 700, 5000]))
             drop = bool(rng.random() < 0.4)
             codes = rng.integers(0, ncat, n)
             missing = rng.random() < 0.3
