@@ -527,6 +527,10 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
             __hip_atomic_store(my_prog + blockIdx.z, w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (pseen was read at the top of the iteration: the round trip is hidden; a neighbour that
             // is not resident must not hang us: bounded spin)
+            // The value stays opaque until HERE: the compiler otherwise evaluates `pseen < w` right
+            // behind the load, and that s_waitcnt vmcnt(0) at the top of the iteration also waits
+            // for the stream loads and LDS-DMA pieces issued just before it.
+            asm volatile("" : "+v"(pseen));
             int spin = 0;
             for (; waiting && pseen < w && spin < 2048; ++spin) {
                 __builtin_amdgcn_s_sleep(8);
