@@ -33,6 +33,8 @@ ELL_MAX_PAD = 8.0
 # sparse x dense term whose row-list form pays two LDS atomics per nonzero).
 PART_NNZ = int(os.environ.get("TABMAT_AMD_PART_NNZ", str(2**31 - 2**24)))   # see split_matrix._parts
 SORTED_K3_NNZ_PER_ROW = 6.0      # below: sparse x dense on the column-sorted kernel (wide blocks)
+# largest column selection of a sparse self sandwich that is written out as a dense block (one syrk panel)
+NARROW_COLS = int(os.environ.get("TABMAT_AMD_NARROW_COLS", "128"))
 ROW_LIST_FRACTION = 0.5
 ROW_LIST_FRACTION_K3 = 0.25
 
@@ -249,6 +251,21 @@ class SparseMatrix(MatrixBase):
             self.__dict__["_parts_cache"] = parts
         return parts
 
+    def _narrow_pays(self, w: int) -> bool:
+        """Host cost model (fitted on scripts/dev/time_sparse_cols.py, MI355X): the dense-block form
+        of a w-column selection (zero + write + syrk of an n x w block, one atomic per selected
+        entry) against the unrestricted self sandwich (per (row, tile) visit or per pair)."""
+        n, mcols = self.shape
+        nnz = float(self._dev().data.numel())
+        per_row = nnz / max(n, 1)
+        pairs = n * per_row * (per_row + 1) / 2
+        nch = -(-mcols // 128)
+        t_full = max(31e-12 * (nch * (nch + 1) / 2) * n, 1.6e-12 * pairs)
+        if getattr(self, "_direct_pays", None):
+            t_full = pairs / 22e9
+        t_narrow = 0.2e-3 + n * w * 4.5e-12 + nnz * w / max(mcols, 1) * 40e-12
+        return t_narrow < 0.8 * t_full
+
     def _sandwich_dev(self, d, rows, cols):
         parts = self._row_parts()
         if parts is not None:
@@ -268,6 +285,29 @@ class SparseMatrix(MatrixBase):
                 out = D.zeros((k, k), d.dtype)
             return out
         A = self._dev()
+        if getattr(self, "_direct_pays", None) is None:
+            self._direct_pays = xs.direct_sandwich_pays(A)
+        w = D.nlen(cols) if cols is not None else 0
+        if (0 < w <= NARROW_COLS and 2 * w < self.shape[1] and self.shape[0] > 0 and A.data.numel() > 0
+                and self._narrow_pays(w)
+                and self.shape[0] * w * A.data.element_size() * 4 < torch.cuda.mem_get_info()[0]):
+            # a narrow column selection (a solver's active set): the selected columns written out
+            # as one row-major dense block from the CSC form (only their entries are read), then
+            # the MFMA syrk -- cost in proportion to the selection (ext/sparse.pyx:17-77 with `cols`)
+            from .ext import dense as xd
+            from .ext._types import DenseDev
+
+            rws, vls, bstart, _, col_bptr = A.csc_blocks()
+            mx = getattr(self, "_max_col_len", None)
+            if mx is None:
+                ends = bstart[col_bptr]
+                mx = self._max_col_len = int((ends[1:] - ends[:-1]).max().item())
+            cd = cols.to(torch.int64)
+            seg = torch.stack([bstart[col_bptr[cd]], bstart[col_bptr[cd + 1]]], dim=1).contiguous()
+            T = torch.zeros((self.shape[0], w), dtype=A.data.dtype, device=A.data.device)
+            xs.csc_densify_cols(rws, vls, seg, torch.arange(w, dtype=torch.int32, device=A.data.device),
+                                mx, T)
+            return xd.dense_sandwich(DenseDev(T, self.shape[0], w, 0), d, rows, None)
         pays = getattr(self, "_direct_pays", None)
         if pays is None:
             pays = self._direct_pays = xs.direct_sandwich_pays(A)

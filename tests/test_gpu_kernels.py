@@ -839,3 +839,37 @@ def test_densify_entry_points(dtype):
         xd.dense_gather_cols(DenseDev.from_host(arr), D.to_dev(pick), T, 5)
         got = T.cpu().numpy()
         assert np.array_equal(got[:, 5:9], X[:, pick]) and not got[:, :5].any() and not got[:, 9:].any()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_narrow_column_selection(dtype):
+    """SparseMatrix.sandwich with a narrow `cols` (dense-block form from the CSC twin) vs the oracle,
+    with and without rows, and equal to the generic path."""
+    import tabmat_amd as tm
+    import tabmat_amd.sparse_matrix as spm
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(9)
+    n, m = 20_011, 700
+    S = sps.random(n, m, density=0.03, format="csc", random_state=rng).astype(dtype)
+    X = tm.SparseMatrix(S)
+    X._narrow_pays = lambda w: True        # (the host cost model would send this small block the usual way)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 10)] = 0
+    rows = np.sort(rng.choice(n, n // 4, replace=False))
+    tol = 1e-10 if dtype == np.float64 else 3e-5
+    assert not tm.SparseMatrix(S)._narrow_pays(23)     # 20k rows: the full product is cheaper
+    for cols in (np.sort(rng.choice(m, 23, replace=False)), np.array([5]), np.arange(100, 228)):
+        for r in (None, rows):
+            got = X.sandwich(d, rows=r, cols=cols)
+            want = orc.sparse_sandwich(S, S.tocsr(), d, r, cols)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    cols = np.sort(rng.choice(m, 40, replace=False))
+    a = X.sandwich(d, cols=cols)
+    old, spm.NARROW_COLS = spm.NARROW_COLS, 0
+    try:
+        b = X.sandwich(d, cols=cols)
+    finally:
+        spm.NARROW_COLS = old
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
