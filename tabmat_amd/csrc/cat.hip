@@ -620,12 +620,19 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
 
     struct Regs { vec_t x[NI]; F dk; int code[NC]; };
     auto load = [&](int64_t k0, Regs &R) {
+        // (row list: all row ids first, then the row loads -- a row id fetched inside the loop was
+        // waited for before the next one went out)
+        int64_t kr[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) kr[i] = min(k0 + 4 * i + q, n - 1);
+        if (rows) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) kr[i] = (int64_t)rows[kr[i]];
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int64_t p = min(k0 + 4 * i + q, n - 1);
-            const int64_t k = rows ? (int64_t)rows[p] : p;
             // (streamed once: nontemporal loads keep the dense block out of the L2 -- 2.01 -> 1.71 ms at cfg4)
-            R.x[i] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(M + k * m + jc));
+            R.x[i] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(M + kr[i] * m + jc));
         }
         const int64_t k = k0 + lr;
         const int64_t kp = min(k, n - 1);
