@@ -109,6 +109,18 @@ def test_random_split_products(seed):
         want = Es[np.ix_(rows, cols)].T @ (d64[rows, None] * Es[np.ix_(rows, cols)])
         scale = max(1.0, float(np.abs(want).max()))
         assert float(np.abs(np.asarray(got) - want).max()) / scale < (tol if dtype == np.float64 else 5e-3)
+        # matvec / transpose_matvec of the standardized view, device vectors, with a selection
+        import torch
+        Sm = tm.StandardizedMatrix(X, shift, mult)
+        vd = torch.as_tensor(v, device="cuda")
+        wd = torch.as_tensor(w, device="cuda")
+        mtol = tol if dtype == np.float64 else 5e-3
+        got = Sm.matvec(vd, cols=cols).cpu().numpy()
+        want = Es[:, cols] @ v64[cols]
+        assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) < mtol
+        got = Sm.transpose_matvec(wd, rows=rows, cols=few_c).cpu().numpy()
+        want = Es[np.ix_(rows, few_c)].T @ w64[rows]
+        assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) < mtol
         # ... and under the narrow selection (dense-block form of the selected columns)
         got = tm.StandardizedMatrix(X, shift, mult).sandwich(d, rows, few_c)
         Esf = Es[np.ix_(rows, few_c)]
