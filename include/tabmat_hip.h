@@ -79,6 +79,16 @@ int tm_event_destroy(void *event);
 int tm_event_record(void *event, void *stream);
 int tm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
 
+/* ---- tuning knobs: integer settings that pick between launch geometries of one kernel (the
+ * defaults are the measured optima; a profile run compares geometries inside one process).
+ * Keys in use: "k2_waves" (8 / 12 / 16 waves per workgroup of the chunked sparse sandwich),
+ * "catdense_waves" / "catsparse_waves" (waves of the fused categorical cross terms), "co_grid"
+ * (workgroups of the co-resident syrk), "wg_log" (device pointer to a placement log: uint64
+ * {count, capacity, 0, 0} followed by records {XCC_ID << 32 | HW_ID, start, end, kernel tag} that
+ * the instrumented kernels append per workgroup, s_memrealtime ticks; 0 = off). ---- */
+int tm_tune_set(const char *h_key, int64_t value);
+int tm_tune_get(const char *h_key, int64_t dflt, int64_t *value);
+
 /* ---- in-library timing of an op's MAIN kernel (events on the launch stream) ---- */
 int tm_profile_enable(int on);
 int tm_profile_last_ms(float *ms); /* duration of the last recorded main kernel; synchronises */
@@ -97,6 +107,15 @@ int tm_dense_sandwich_f32(const float *X, int64_t n, int64_t m, int order_f, con
 int tm_dense_sandwich_f64(const double *X, int64_t n, int64_t m, int order_f, const double *d,
                           const int32_t *rows, int64_t n_rows, const int32_t *cols,
                           int64_t n_cols, double *out, void *stream);
+
+/* The same product for an unrestricted, 16-byte aligned, C-ordered f64 block of an even number
+ * m <= 128 of columns, as a kernel sized to SHARE its compute units with an LDS- or HBM-bound
+ * partner that runs on another stream (27.8 KB of LDS, <= 168 registers, work items handed out
+ * through an atomic counter): the dense term of SplitMatrix.sandwich (split_matrix.py:337-354,
+ * ext/dense_helpers-tmpl.cpp:266-311) overlapped with the sparse / categorical terms.
+ * colsum (length m, may be NULL) receives X' d from the same pass (standardized_mat.py:149-150). */
+int tm_dense_sandwich_co_f64(const double *X, int64_t n, int64_t m, const double *d, double *out,
+                             double *colsum, void *stream);
 
 /* out[Ci] += sum_{Cj} X[rows[Ci], cols[Cj]] * v[cols[Cj]]   (v has length m).
  * Replaces _dense{C,F}_matvec (ext/dense_helpers-tmpl.cpp:385-417; ext/dense.pyx:76-101) and,

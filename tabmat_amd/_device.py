@@ -45,7 +45,11 @@ def same_float(fn: str, *tensors) -> None:
     takes bare pointers, so a float32 operand behind a _f64 entry point would be read out of
     bounds.  The reference raises TypeError for mixed dtypes (util.py:62-67,
     sparse_matrix.py:218-223)."""
-    dts = {t.dtype for t in tensors if t is not None and t.is_floating_point()}
+    for t in tensors:
+        if t is not None and not t.is_floating_point():
+            # an integer d / v behind a raw pointer would be reinterpreted as floats
+            raise TypeError(f"{fn}: operands need to be np.float64 or np.float32 arrays, got {t.dtype}")
+    dts = {t.dtype for t in tensors if t is not None}
     if len(dts) > 1:
         raise TypeError(f"{fn}: all floating-point operands need the same dtype, either "
                         f"np.float64 or np.float32; got {sorted(str(d) for d in dts)}")

@@ -221,8 +221,10 @@ class CategoricalMatrix(MatrixBase):
                 self._dev_codes[D.idx_dev(arg[0], torch.int64)]
             return CategoricalMatrix(codes.contiguous(), categories=self.categories,
                                      drop_first=self.drop_first, dtype=self.dtype,
-                                     column_name=self._colname,
-                                     cat_missing_method=self._missing_method, _validated=True)
+                                     column_name=self._colname, term_name=self._term,
+                                     column_name_format=self._colname_format,
+                                     cat_missing_method=self._missing_method,
+                                     cat_missing_name=self._missing_category, _validated=True)
         if full:
             if isinstance(row, np.ndarray):
                 row = row.ravel()

@@ -588,7 +588,9 @@ constexpr int MCW_VEC = 2;
 template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
-    int64_t rows_per_block, F *__restrict__ ws, int64_t stride, const int32_t *__restrict__ rows) {
+    int64_t rows_per_block, F *__restrict__ ws, int64_t stride, const int32_t *__restrict__ rows,
+    WgLogBuf *__restrict__ wglog) {
+    const unsigned long long t_begin = wg_log_begin(wglog);
     // rows != NULL: `n` is the length of the row list and every position is mapped through it
     // (cost proportional to the list; the reference's `for k in rows`, ext/split.pyx:32-80)
     // VEC = 2 columns per lane for both types (16-byte loads for f64, 8-byte loads for f32): the
@@ -686,6 +688,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0) wg_log_end(wglog, t_begin, WG_CAT_DENSE);
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
     for (int b = threadIdx.x; b < nel; b += blockDim.x) {
         const int c = b % TJ;
@@ -829,7 +832,8 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ vals,
     const unsigned *__restrict__ koff, const unsigned char *__restrict__ ecol,
     const int64_t *__restrict__ gptr, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
-    int group_cols, int64_t n, F *__restrict__ ws, int64_t stride) {
+    int group_cols, int64_t n, F *__restrict__ ws, int64_t stride, WgLogBuf *__restrict__ wglog) {
+    const unsigned long long t_begin = wg_log_begin(wglog);
     constexpr int SR = 128;              // slab rows (tm_slab_rows)
     constexpr int NQ = 4;                // prefetched 64-entry chunks per block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -925,6 +929,7 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
         for (int64_t e = base + NQ * 64 + lane; e < end; e += 64) scatter(koff[e], vals[e], (int)ecol[e]);
     }
     __syncthreads();
+    if (threadIdx.x == 0) wg_log_end(wglog, t_begin, WG_CAT_SPARSE);
     F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
     for (int b = threadIdx.x; b < cs.total * group_cols; b += blockDim.x)
         dst[b] = (F)tile[(b / group_cols) * tstr + (b % group_cols)];
@@ -989,8 +994,10 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
                 TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
                 prof_begin(st);
-                hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(1024), lds_w, st,
-                                   cs, d, M, n, m, rpb, ws, stride, rows);
+                // 16 waves own a CU; 12 leave registers for the co-resident syrk (syrk_co.hip)
+                const int nw = (int)std::min<int64_t>(16, std::max<int64_t>(4, tune("catdense_waves", 16)));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(nw * 64), lds_w, st,
+                                   cs, d, M, n, m, rpb, ws, stride, rows, wg_log_ptr());
                 prof_end(st);
                 TM_LAUNCH_CHECK();
                 return TM_OK;
@@ -1101,7 +1108,9 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
         return TM_EUNSUPPORTED;
     }
     // per-wave staging of the slab's d and codes when it fits next to the tile
-    const size_t stage_bytes = (size_t)16 * slab_rows * (sizeof(F) + sizeof(int32_t) * (size_t)n_cats);
+    // (16 waves own a CU; 12 leave registers and LDS for the co-resident syrk, syrk_co.hip)
+    const int nw = (int)std::min<int64_t>(16, std::max<int64_t>(4, tune("catsparse_waves", 16)));
+    const size_t stage_bytes = (size_t)nw * slab_rows * (sizeof(F) + sizeof(int32_t) * (size_t)n_cats);
     const bool stage = tile_bytes + stage_bytes <= 150 * 1024;
     const size_t lds = tile_bytes + (stage ? stage_bytes : 0);
     const int n_groups = (int)ceil_div(m, group_cols);
@@ -1130,8 +1139,9 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kpf),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
-        hipLaunchKernelGGL(kpf, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs, d,
-                           vals, koff, ecol, gptr, n_groups, n_slabs, spb, group_cols, n, ws, stride);
+        hipLaunchKernelGGL(kpf, dim3((unsigned)nblk, (unsigned)n_groups), dim3(nw * 64), lds, st, cs, d,
+                           vals, koff, ecol, gptr, n_groups, n_slabs, spb, group_cols, n, ws, stride,
+                           wg_log_ptr());
         prof_end(st);
         TM_LAUNCH_CHECK();
     } else {
@@ -1140,7 +1150,7 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(nw * 64), lds, st, cs,
                            d, vals, koff, ecol, gptr, n_groups, n_slabs, spb, slab_rows, group_cols,
                            n, ws, stride);
         prof_end(st);

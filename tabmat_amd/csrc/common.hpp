@@ -49,6 +49,17 @@ int get_workspace(size_t bytes, void **ptr, hipStream_t st);
 void prof_begin(hipStream_t st);
 void prof_end(hipStream_t st);
 
+// integer tuning knob set with tm_tune_set (default when unset)
+int64_t tune(const char *key, int64_t dflt);
+
+// K1c (syrk_co.hip): X' diag(d) X of an unrestricted C-ordered f64 block of an even number of
+// columns <= 128; colsum (may be NULL) receives X' d.  syrk_co_ok() says whether a block qualifies.
+int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out,
+                double *colsum, hipStream_t st);
+inline bool syrk_co_ok(const void *X, int64_t m) {
+    return m > 0 && m <= 128 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -129,6 +140,38 @@ __device__ __forceinline__ double dpp_bcast8(double v, double x4) {
 template <int K>
 __device__ __forceinline__ float dpp_bcast8(float v, float x4) {
     return __int_as_float(dpp_bcast8_i32<K>(__float_as_int(v), __float_as_int(x4)));
+}
+
+// Placement log (tm_tune_set("wg_log", device pointer to a WgLogBuf; 0 = off): the instrumented
+// kernels append one record per workgroup -- which compute unit it ran on and when.  This is the
+// evidence that kernels launched on different streams shared compute units
+// (scripts/dev/coresidency.py, profiles/r3_coresidency.txt).
+struct WgLog {
+    unsigned long long hw, t0, t1, tag;   // XCC_ID << 32 | HW_ID, s_memrealtime start / end, kernel tag
+};
+struct WgLogBuf {
+    unsigned long long count, cap, pad0, pad1;
+    WgLog e[1];
+};
+enum WgTag { WG_SYRK_CO = 1, WG_K2 = 2, WG_CAT_DENSE = 3, WG_CAT_SPARSE = 4, WG_K3 = 5 };
+inline WgLogBuf *wg_log_ptr() { return reinterpret_cast<WgLogBuf *>((uintptr_t)tune("wg_log", 0)); }
+__device__ __forceinline__ unsigned long long wg_log_begin(const WgLogBuf *b) {
+    return b ? wall_clock64() : 0ull;
+}
+// (call from ONE thread of the workgroup)
+__device__ __forceinline__ void wg_log_end(WgLogBuf *b, unsigned long long t_begin, int tag) {
+    if (!b) return;
+    const unsigned long long i = atomicAdd(&b->count, 1ull);
+    if (i >= b->cap) return;
+    // HW_ID (hwreg 4): wave / simd / cu / sh / se ids; XCC_ID (hwreg 20): the die
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    WgLog r;
+    r.hw = ((unsigned long long)xcc << 32) | hw;
+    r.t0 = t_begin;
+    r.t1 = wall_clock64();
+    r.tag = (unsigned long long)tag;
+    b->e[i] = r;
 }
 
 // column of a categorical code: code - drop_first, negative = contributes nothing

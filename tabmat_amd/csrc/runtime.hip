@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <map>
+#include <string>
 #include <mutex>
 #include <utility>
 
@@ -24,6 +25,18 @@ void set_error(const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     set_error("HIP error %d (%s) at %s:%d in `%s`", (int)e, hipGetErrorString(e), file, line, what);
     return (int)e > 0 ? (int)e : TM_EINVAL;
+}
+
+// Tuning knobs (tm_tune_set): small integer settings that pick between launch geometries of the
+// same kernel.  Defaults are the measured optima; the knobs exist so that a profile run can
+// compare geometries inside one process.
+static std::map<std::string, int64_t> g_tune;
+static std::mutex g_tune_mu;
+
+int64_t tune(const char *key, int64_t dflt) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tune.find(key);
+    return it == g_tune.end() ? dflt : it->second;
 }
 
 struct Workspace {
@@ -190,6 +203,19 @@ int tm_workspace_generation(int64_t *generation) {
     TM_REQUIRE(generation != nullptr, "generation is NULL");
     std::lock_guard<std::mutex> lk(g_ws_mu);
     *generation = g_ws_generation;
+    return TM_OK;
+}
+
+int tm_tune_set(const char *h_key, int64_t value) {
+    TM_REQUIRE(h_key != nullptr, "key is NULL");
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune[h_key] = value;
+    return TM_OK;
+}
+
+int tm_tune_get(const char *h_key, int64_t dflt, int64_t *value) {
+    TM_REQUIRE(h_key != nullptr && value != nullptr, "NULL argument");
+    *value = tune(h_key, dflt);
     return TM_OK;
 }
 

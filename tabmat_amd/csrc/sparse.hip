@@ -450,11 +450,13 @@ __device__ __forceinline__ float k2_bcast(float v, float x4) {
 // row and 128-column chunk (5 % density); a block with 1-2 nonzeros per row and chunk (wide and
 // sparse: 2048 columns at 1.25 %) would fill 3 % of the lanes of its 8 ds_adds per 8 rows -- with
 // S = 2 the same pairs take 2 ds_adds per 32 rows.
-template <typename F, int TS, int S>
-__global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
+template <typename F, int TS, int S, int NW = K2_WAVES>
+__global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
-    int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws, int pairs) {
+    int64_t nnz1, int nb_diag, int nb_off, int max_nb, F *__restrict__ ws, int pairs,
+    WgLogBuf *__restrict__ wglog) {
+    const unsigned long long t_begin = wg_log_begin(wglog);
     // pairs = 1: row-restricted form.  `cptr` is then a table [nch][n][2] of {start, end} of the
     // SELECTED rows (ascending) in every chunk, d the selected weights, n their number: the same
     // pipeline walks a row list at a cost proportional to its length (the reference's
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
         }
         return e;
     };
-    const int gstep = K2_WAVES * RG;
+    const int gstep = NW * RG;
     const int gw = wave * RG;
     Grp ea[K2_ED], eb[K2_ED];      // two register sets: the loop is unrolled by two turns
     Ptr ps[K2_NP];
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void sparse_sandwich_chunked_kernel(
     if (I == J) run_tile(std::true_type{});
     else run_tile(std::false_type{});
     __syncthreads();
+    if (threadIdx.x == 0) wg_log_end(wglog, t_begin, WG_K2);
     F *dst = ws + ((int64_t)part * max_nb + blk) * (TS * TS);
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) {
         const int r = b / TS, c = b % TS;
@@ -1070,9 +1073,15 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     // measured at 2M rows (profiles/r2_microbench.txt): 8 slots win above ~4.5 nonzeros per row and
     // chunk, 2 slots below ~0.9
     const int slots = force_s ? force_s : (per_chunk > 4.5 ? 8 : per_chunk > 0.9 ? 4 : 2);
-    auto kern = slots == 8   ? &sparse_sandwich_chunked_kernel<F, TS, 8>
+    // waves per workgroup: 16 when the kernel has the CU to itself; 8 / 12 leave registers for a
+    // co-resident MFMA kernel on the same CU (tm_tune_set("k2_waves", ...), S = 8 only)
+    const int nw = slots == 8 ? (int)tune("k2_waves", K2_WAVES) : K2_WAVES;
+    auto kern = slots == 8   ? (nw == 8    ? &sparse_sandwich_chunked_kernel<F, TS, 8, 8>
+                                : nw == 12 ? &sparse_sandwich_chunked_kernel<F, TS, 8, 12>
+                                           : &sparse_sandwich_chunked_kernel<F, TS, 8>)
                 : slots == 4 ? &sparse_sandwich_chunked_kernel<F, TS, 4>
                              : &sparse_sandwich_chunked_kernel<F, TS, 2>;
+    const int threads = (slots == 8 && (nw == 8 || nw == 12) ? nw : K2_WAVES) * 64;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // every tile's partials are reduced over nblk slots: tiles with fewer workgroups leave theirs 0
@@ -1080,8 +1089,9 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
         TM_HIP(hipMemsetAsync(ws, 0, sizeof(F) * (size_t)n_parts * (size_t)nblk * TS * TS, st));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nchunk * nb_diag + n_off * nb_off)),
-                       dim3(K2_WAVES * 64), lds, st, data, ind, cptr, nchunk, d, n, nnz - 1, nb_diag,
-                       nb_off, (int)nblk, ws, pairs);
+                       dim3(threads), lds, st, data, ind, cptr, nchunk, d, n, nnz - 1, nb_diag,
+                       nb_off, (int)nblk, ws, pairs,
+                       wg_log_ptr());
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, (int)nblk, n_parts, tmp,

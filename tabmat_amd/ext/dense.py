@@ -80,3 +80,24 @@ def dense_gather_cols(X: DenseDev, cols, T, t0: int):
     D.same_float("dense_gather_cols", X.buf, T)
     call(f"tm_dense_gather_cols_{D.fsuf(T)}", D.p(X.buf), X.n, X.m, int(X.order_f), D.p(cols),
          D.nlen(cols), D.p(T), T.shape[1], int(t0), D.stream_ptr())
+
+
+def dense_sandwich_co(X: DenseDev, d, want_colsum=False):
+    """X' diag(d) X of an unrestricted C-ordered float64 block of an even number of columns
+    <= 128 with the kernel that is sized to share its compute units with a partner running on
+    another stream (tm_dense_sandwich_co_f64; reference: the dense term of
+    split_matrix.py:337-354).  Returns out, or (out, X' d) with want_colsum."""
+    import torch
+
+    out = D.out_buf((X.m, X.m), torch.float64)
+    cs = D.out_buf((X.m,), torch.float64) if want_colsum else None
+    D.same_float("dense_sandwich_co", X.buf, d, out)
+    call("tm_dense_sandwich_co_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(out), D.p(cs), D.stream_ptr())
+    return (out, cs) if want_colsum else out
+
+
+def co_supported(X: DenseDev, d) -> bool:
+    import torch
+
+    return (not X.order_f and X.buf.dtype == torch.float64 and d.dtype == torch.float64
+            and X.m <= 128 and X.m % 2 == 0 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0)

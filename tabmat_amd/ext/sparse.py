@@ -169,14 +169,17 @@ def _row_table(A: CsrDev, rows, d, as_set: bool):
 
     cm_data, cm_ind, cptr = A.chunk_major()
     # the table depends on `rows` only: the self sandwich and the cross term of one call share it
+    # (keyed on the tensor AND its version counter: a caller that refills a static index buffer in
+    # place must not get the ranges of the old contents)
     cached = getattr(A, "_row_table", None)
-    if cached is not None and cached[0]() is rows:
-        _, r64, dup, tabs = cached
+    stamp = (rows.data_ptr(), rows._version, int(rows.numel()))
+    if cached is not None and cached[0]() is rows and cached[4] == stamp:
+        _, r64, dup, tabs, _ = cached
     else:
         r64 = torch.sort(rows.to(torch.int64)).values
         dup = bool((r64[1:] == r64[:-1]).any().item()) if r64.numel() > 1 else False
         tabs = {}
-        A._row_table = (weakref.ref(rows), r64, dup, tabs)
+        A._row_table = (weakref.ref(rows), r64, dup, tabs, stamp)
     key = bool(as_set and dup)
     if key not in tabs:
         rr = torch.unique_consecutive(r64) if key else r64

@@ -44,6 +44,16 @@ N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
 # (9.4 vs 9.1 ms at cfg4) -- the f64 MFMAs and the gather's f64 FMAs share the DP pipe, the
 # matrix work does not hide in the gather's LDS waits.
 FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
+# TABMAT_AMD_OVERLAP=1: the dense self sandwich as a GUEST kernel on a side stream
+# (tm_dense_sandwich_co_f64): it shares the compute units with the categorical cross terms and the
+# sparse self sandwich, which are launched with 12 instead of 16 waves so that its registers fit.
+# Measured (profiles/r3_coresidency.txt): the workgroups DO share compute units (placement log:
+# every guest workgroup beside a partner workgroup on its CU), but the pair gains 0.2-0.3 ms at
+# best -- v_mfma_f64 runs at the vector f64 rate on gfx950 and queues in the same VALU issue slots
+# as the partners' instructions -- and the step is no faster than with the same kernel run in
+# line (16.06 vs 16.05 ms).  Off by default; kept as the measurement harness for that result.
+OVERLAP = os.environ.get("TABMAT_AMD_OVERLAP", "0") == "1"
+OVERLAP_KNOBS = {"k2_waves": 12, "catdense_waves": 12, "catsparse_waves": 12}
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
 DIAG_FROM_PAIRS = True
 # all small categorical x categorical tables + diagonals in one launch (tm_multi_cat_pairs_*)
@@ -102,6 +112,35 @@ class _StreamFan:
         if self.k > 1:
             for s in self.used:
                 self.main.wait_stream(s)
+
+
+class _Guest:
+    """The side stream of the co-resident dense syrk: fork() makes it wait for everything the
+    current stream has queued so far, join() makes the current stream wait for it."""
+
+    _streams: dict = {}
+
+    def __init__(self):
+        dev = torch.cuda.current_device()
+        st = _Guest._streams.get(dev)
+        if st is None:
+            st = _Guest._streams[dev] = torch.cuda.Stream()
+        self.side = st
+        self.main = torch.cuda.current_stream()
+
+    def fork(self):
+        self.side.wait_stream(self.main)
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
+def _set_knobs(values):
+    from ._lib import call
+
+    for k, v in values.items():
+        call("tm_tune_set", k.encode(), int(v))
 
 
 def as_tabmat(a):
@@ -657,6 +696,40 @@ class SplitMatrix(MatrixBase):
         empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
         done = set()
         fan = _StreamFan(N_STREAMS)
+        self_done = set()
+        guest = None
+        if (OVERLAP and rows is None and N_STREAMS == 1 and d.dtype == torch.float64
+                and sum(1 for e in empty if not e) > 1):
+            from .ext import dense as xd
+            for i, mi in enumerate(mats):
+                if not (isinstance(mi, DenseMatrix) and sub_d[i] is None and not empty[i]):
+                    continue
+                Bd = mi._dev_c()
+                if mi.dtype != np.float64 or not xd.co_supported(Bd, d):
+                    continue
+                guest = _Guest()
+                with guest.fork():
+                    res = xd.dense_sandwich_co(Bd, d, want_colsum=colsum is not None)
+                    if colsum is not None:
+                        res, colsum[i] = res
+                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+                self_done.add(i)
+                break
+        if guest is not None:
+            _set_knobs(OVERLAP_KNOBS)
+        try:
+            return self._sandwich_terms(d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done,
+                                        fan, self_done)
+        finally:
+            if guest is not None:
+                _set_knobs({k: 16 for k in OVERLAP_KNOBS})
+                guest.join()
+
+    def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done, fan,
+                        self_done):
+        """The block products of one sandwich on the current stream (everything but a dense self
+        term that `_sandwich_dev` gave to the guest stream)."""
+        mats = self.matrices
         # ---- fused categorical cross terms: one pass over the dense / sparse block serves
         #      every categorical block (tm_multi_cat_*), instead of one pass per pair
         cat_ids = [i for i, m in enumerate(mats) if isinstance(m, CategoricalMatrix) and not empty[i]
@@ -699,7 +772,6 @@ class SplitMatrix(MatrixBase):
                             res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
                             xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                         done.add((min(i, w), max(i, w)))
-        self_done = set()
         if FUSE_SYRK and rows is None and d.dtype == torch.float64:
             from .ext import sparse as xs
             for i, mi in enumerate(mats):
@@ -724,7 +796,10 @@ class SplitMatrix(MatrixBase):
         #      categoricals has k (k - 1) / 2 of them, one launch each was ~30 us apiece
         cat_diag = {}
         diag_scattered = set()
-        plan = self._cat_pairs_plan() if CAT_PAIRS_FUSED else None
+        # TABMAT_AMD_DETERMINISTIC: the diagonals must come from the fixed-order histogram
+        # (csrc/cat_det.hip), not from LDS-atomic tables -- no fused plan, no row-sum shortcut
+        det = _cm.DETERMINISTIC
+        plan = self._cat_pairs_plan() if CAT_PAIRS_FUSED and not det else None
         if (plan is not None and plan.n_pairs > 0 and N_STREAMS == 1
                 and d.dtype in (torch.float32, torch.float64)
                 and d.dtype == D.torch_dtype(self.dtype)):
@@ -758,10 +833,12 @@ class SplitMatrix(MatrixBase):
                     res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
                     xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
                     done.add((i, j))
-                    if DIAG_FROM_PAIRS and complete[j] and i not in cat_diag:
+                    if DIAG_FROM_PAIRS and not det and complete[j] and i not in cat_diag:
                         cat_diag[i] = res.sum(dim=1)
-                    if DIAG_FROM_PAIRS and complete[i] and j not in cat_diag:
+                    if DIAG_FROM_PAIRS and not det and complete[i] and j not in cat_diag:
                         cat_diag[j] = res.sum(dim=0)
+        # self terms first, then the remaining cross terms: the guest syrk shares its compute units
+        # with the sparse self sandwich (K2), not with the sparse x dense gather (K3)
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
@@ -778,6 +855,9 @@ class SplitMatrix(MatrixBase):
                 else:
                     res = mi._sandwich_dev(d, rows, sub_d[i])
                     xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+        for i, mi in enumerate(mats):
+            if empty[i]:
+                continue
             for j in range(i + 1, len(mats)):
                 if empty[j] or (i, j) in done:
                     continue

@@ -115,7 +115,12 @@ def device_row_index(row, n: int):
     if r.dtype == bool:
         r = np.flatnonzero(r)
     r = r.astype(np.int64)
-    return ("index", np.where(r < 0, r + n, r))
+    r = np.where(r < 0, r + n, r)
+    if r.size and (int(r.min()) < 0 or int(r.max()) >= n):
+        # the host path raises from numpy; on the device this would be a silent out-of-bounds gather
+        bad = int(r[(r < 0) | (r >= n)][0])
+        raise IndexError(f"index {bad if bad < n else bad} is out of bounds for axis 0 with size {n}")
+    return ("index", r)
 
 
 def check_indexer(indexer):

@@ -404,3 +404,41 @@ def test_split_col_subsets_table_form_equals_merge_loop(seed):
     if p > 1:
         assert collapse_identity(np.arange(p, dtype=np.int32)[::-1].copy(), p) is not None
         assert collapse_identity(np.arange(p - 1, dtype=np.int32), p) is not None
+
+
+def test_device_row_index_checks_bounds():
+    """Row ids handed to device gathers are range-checked on the host (numpy raises IndexError on
+    the reference's host path; a device gather would read out of bounds silently)."""
+    from tabmat_amd.util import device_row_index
+
+    kind, idx = device_row_index(np.array([0, -1, 3]), 5)
+    assert kind == "index" and idx.tolist() == [0, 4, 3]
+    assert device_row_index(slice(1, 4), 5) == ("slice", 1, 4)
+    for bad in ([5], [-6], [0, 7, 1]):
+        with pytest.raises(IndexError):
+            device_row_index(np.array(bad), 5)
+    kind, idx = device_row_index(np.array([True, False, True, False, False]), 5)
+    assert idx.tolist() == [0, 2]
+
+
+def test_same_float_rejects_integer_operands():
+    """A raw pointer to an integer d / v must never reach a tm_*_f32 / _f64 entry point."""
+    from tabmat_amd import _device as D
+
+    x = torch.zeros(4, dtype=torch.float64)
+    D.same_float("op", x, torch.ones(4, dtype=torch.float64), None)
+    with pytest.raises(TypeError):
+        D.same_float("op", x, torch.ones(4, dtype=torch.int64))
+    with pytest.raises(TypeError):
+        D.same_float("op", x, torch.ones(4, dtype=torch.int32))
+    with pytest.raises(TypeError):
+        D.same_float("op", x, torch.ones(4, dtype=torch.float32))
+
+
+def test_tuning_knobs_round_trip():
+    v = C.c_int64(0)
+    _lib.call("tm_tune_get", b"no_such_knob", 7, C.byref(v))
+    assert v.value == 7
+    _lib.call("tm_tune_set", b"unit_test_knob", 12)
+    _lib.call("tm_tune_get", b"unit_test_knob", 7, C.byref(v))
+    assert v.value == 12
