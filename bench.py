@@ -53,7 +53,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
-    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg2", "cfg3"])
+    ap.add_argument("--workload", default="cfg4",
+                    choices=["cfg4", "cfg2", "cfg3", "cfg1", "dense", "sparse", "sparse_narrow",
+                             "sparse_wide", "one_cat", "two_cat", "dense_cat", "dense_smallcat"],
+                    help="cfg1-4: BASELINE.json configs[0..3]; the others: the reference's own "
+                         "benchmark designs (benchmark/generate_matrices.py:90-100)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (SplitMatrix.sandwich_graph) "
                          "instead of launching every kernel eagerly; single-GPU only")
@@ -77,6 +81,10 @@ def build_workload(name, n, seed):
         return synth.dense_block(n, 256, torch.float32, seed), torch.float32
     if name == "cfg3":
         return synth.cat_block(n if n != 10_000_000 else 50_000_000, 10_000, seed), torch.float64
+    if name == "cfg1":
+        return synth.dense_block(n if n != 10_000_000 else 100_000, 64, torch.float64, seed), torch.float64
+    if name in synth.REFERENCE_DESIGNS:
+        return synth.reference_design(name, None if n == 10_000_000 else n, seed), torch.float64
     raise ValueError(name)
 
 
@@ -195,33 +203,79 @@ def op_flops(mat, name):
     return None
 
 
-def cpu_baseline(workload, rows, seed):
-    """Time the CPU oracle ("port") on a bounded sample: the first `rows` rows of the same
-    recipe, all host cores (OpenMP).  Returns the JSON object or None."""
+# Reference CPU timings measured in the survey container (8 host cores, the
+# reference's ext/ built with its own scalar non-xsimd fallback) -- context printed next to
+# cpu_baseline; other hardware, other sizes, never a denominator.
+REFERENCE_CPU_SURVEY = {
+    "cfg1": "DenseMatrix.sandwich f64 100k x 64, full size: 13.2 ms (62 GFLOP/s)",
+    "cfg2": "DenseMatrix.sandwich f32 1M x 256 (1/10 of the rows): 1.38 s (95 GFLOP/s)",
+    "cfg3": "CategoricalMatrix 5M x 10k (1/10 of the rows): sandwich 17 ms, transpose_matvec 4 ms, matvec 22 ms",
+    "cfg4": "SplitMatrix dense128 + CSC512@5% + cats(1000,300,50), 1M rows, p=1990: sandwich 4.40 s, "
+            "matvec 0.137 s, transpose_matvec 0.200 s",
+    "dense_cat": "the reference's illustrative CLI output (benchmark/main.py:274-277, hardware unstated): "
+                 "sandwich 0.159682 s on 3M x (5 + 1000 + 1000)",
+}
+
+
+def _host_blocks(mat, rows):
+    """Oracle blocks of the first `rows` rows of a device matrix (pulled back from HBM), with the
+    column indices of every block."""
+    from scipy import sparse as sps
+
+    import tabmat_amd as tm
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _cases as cs
+
+    mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
+    idx = [np.asarray(i) for i in mat.indices] if isinstance(mat, tm.SplitMatrix) else \
+        [np.arange(mat.shape[1])]
+    specs = []
+    for m in mats:
+        if isinstance(m, tm.DenseMatrix):
+            specs.append(("dense", m._dev().as_2d()[:rows].cpu().numpy()))
+        elif isinstance(m, tm.SparseMatrix):
+            c = m._dev()
+            ptr = c.indptr[:rows + 1].cpu().numpy()
+            e = int(ptr[-1])
+            S = sps.csr_matrix((c.data[:e].cpu().numpy(), c.indices[:e].cpu().numpy(), ptr),
+                               shape=(rows, c.m))
+            specs.append(("sparse", S.tocsc()))
+        else:
+            specs.append(("cat", m._dev()[:rows].cpu().numpy(), m.shape[1] + int(m.drop_first),
+                          m.drop_first))
+    return [cs.to_oracle_block(sp) for sp in specs], idx
+
+
+def cpu_baseline(workload, rows, mat, d):
+    """Time the CPU oracle ("port") on a bounded sample: the first `rows` rows of the SAME data
+    (pulled back from HBM), all host cores (OpenMP).  Returns the JSON object or None."""
     try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import _cases as cs
         from oracle import oracle as orc
+
+        blocks, idx = _host_blocks(mat, rows)
     except Exception as e:  # oracle not built
         return {"error": f"oracle unavailable: {e}"}
+    import tabmat_amd as tm
+
     threads = orc.num_threads()
-    if workload == "cfg4":
-        specs, idx = cs.mixed_specs(rows, 128, 512, (256, 96, 32), seed=seed)
-        blocks = [cs.to_oracle_block(s) for s in specs]
-        d = np.random.default_rng(seed).random(rows)
-        nnz = blocks[1].csc.nnz
-        alg_bytes = rows * 128 * 8 + nnz * 12 + (rows + 1) * 8 + 3 * rows * 4 + rows * 8 + 1024 * 1024 * 8
-        fn = lambda: orc.split_sandwich(blocks, idx, d)
-    elif workload == "cfg2":
-        X = np.random.default_rng(seed).standard_normal((rows, 256), dtype=np.float32)
-        d = np.random.default_rng(seed + 1).random(rows, dtype=np.float32)
-        alg_bytes = rows * 256 * 4 + rows * 4 + 256 * 256 * 4
-        fn = lambda: orc.dense_sandwich(X, d, None, None)
+    dh = d[:rows].cpu().numpy()
+    isz = dh.dtype.itemsize
+    alg_bytes = rows * isz
+    for b in blocks:
+        if b.kind == "sparse":
+            alg_bytes += b.csc.nnz * (isz + 4) + (rows + 1) * 8
+        elif b.kind == "dense":
+            alg_bytes += b.X.size * isz
+        else:
+            alg_bytes += rows * 4
+    p = mat.shape[1]
+    if isinstance(mat, tm.SplitMatrix):
+        alg_bytes += p * p * 8
+        fn = lambda: orc.split_sandwich(blocks, idx, dh)
     else:
-        codes = np.random.default_rng(seed).integers(0, 10_000, rows).astype(np.int32)
-        d = np.random.default_rng(seed + 1).random(rows)
-        alg_bytes = rows * 12 + 10_000 * 8
-        fn = lambda: orc.sandwich_categorical(codes, d, None, 10_000)
+        alg_bytes += (p if blocks[0].kind == "cat" else p * p) * isz
+        fn = lambda: orc.block_sandwich(blocks[0], dh, None, None)
     fn()  # warm (threads, page faults)
     best = float("inf")
     t_all = time.time()
@@ -236,8 +290,9 @@ def cpu_baseline(workload, rows, seed):
         "unit": "GB/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": f"{workload} recipe, first {rows} rows, min of <=3 runs, {best * 1e3:.1f} ms",
+        "sample": f"{workload}: first {rows} rows of the same data, min of <=3 runs, {best * 1e3:.1f} ms",
         "seconds": round(best, 4),
+        "reference_cpu_survey": REFERENCE_CPU_SURVEY.get(workload),
     }
 
 
@@ -456,7 +511,12 @@ def main():
             "cfg4": f"SplitMatrix.sandwich: dense128 + csr512@5% + cats(256,96,32), {n_local} rows/GPU, p={p}, float64 (BASELINE configs[3])",
             "cfg2": f"DenseMatrix.sandwich float32 {n_local}x256 (BASELINE configs[1])",
             "cfg3": f"CategoricalMatrix.sandwich {n_local} rows x 10k categories float64 (BASELINE configs[2])",
+            "cfg1": f"DenseMatrix.sandwich float64 {n_local}x64 (BASELINE configs[0])",
         }
+        if args.workload not in wl_names:
+            wl_names[args.workload] = (f"reference benchmark design '{args.workload}' "
+                                       f"(benchmark/generate_matrices.py:90-100): {type(mat).__name__} "
+                                       f"{n_local} x {p}, float64")
         result = {
             "metric": METRIC,
             "value": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
@@ -486,8 +546,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,
-                                         "cfg3": 50_000_000}[args.workload]
-            result["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_rows, n_local), 3)
+                                         "cfg3": 50_000_000}.get(args.workload, 1_000_000)
+            result["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_rows, n_local), mat, d)
         if args.breakdown:
             for k, v in sorted(bd.items(), key=lambda kv: -kv[1]):
                 print(f"  {k:24s} {v:9.4f} ms", file=sys.stderr)

@@ -33,7 +33,8 @@ def bucket_rows(rows: Optional[np.ndarray], lo: int, hi: int) -> Optional[np.nda
     return sel.astype(np.int32)
 
 
-def shard(mat, world_size: Optional[int] = None, rank: Optional[int] = None, group=None):
+def shard(mat, world_size: Optional[int] = None, rank: Optional[int] = None, group=None,
+          always_reduce: bool = False):
     """Row shard of `mat` (any MatrixBase, e.g. a SplitMatrix) for this rank: every block is cut
     to the rank's contiguous row range (shard_bounds) -- on the device when the block already
     lives in HBM (DenseMatrix / SparseMatrix / CategoricalMatrix.__getitem__), so a matrix built
@@ -45,7 +46,7 @@ def shard(mat, world_size: Optional[int] = None, rank: Optional[int] = None, gro
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = mat.shape[0]
     lo, hi = shard_bounds(n, world_size, rank)
-    return RowShardedMatrix(mat[lo:hi], group, bounds=(lo, hi), n_global=n)
+    return RowShardedMatrix(mat[lo:hi], group, bounds=(lo, hi), n_global=n, always_reduce=always_reduce)
 
 
 class RowShardedMatrix:
@@ -56,8 +57,10 @@ class RowShardedMatrix:
     def __init__(self, local, group=None,
                  local_sandwich: Optional[Callable] = None,
                  local_transpose_matvec: Optional[Callable] = None,
-                 bounds: Optional[tuple] = None, n_global: Optional[int] = None):
+                 bounds: Optional[tuple] = None, n_global: Optional[int] = None,
+                 always_reduce: bool = False):
         self.local = local
+        self.always_reduce = always_reduce   # issue the collective at world size 1 too (tests)
         self.group = group
         self.bounds = bounds            # (lo, hi) of this shard in the global row numbering
         self.n_global = n_global
@@ -73,12 +76,20 @@ class RowShardedMatrix:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def _all_reduce(self, x):
-        if not dist.is_initialized() or self.world_size == 1:
+        """Sum over the ranks.  A device result stays on the device (RCCL reduces it in place, ordered
+        after the kernels on the current stream); a numpy result (numpy in -> numpy out convention)
+        goes through a device buffer when the group's backend is nccl -- RCCL cannot reduce host
+        memory -- and through a host tensor on gloo."""
+        if not dist.is_initialized() or (self.world_size == 1 and not self.always_reduce):
             return x
         if isinstance(x, torch.Tensor):
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
             return x
         t = torch.from_numpy(np.ascontiguousarray(x))
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.numpy()
 

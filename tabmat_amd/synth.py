@@ -75,6 +75,35 @@ def mixed_split(n: int, k_dense: int = 128, k_sparse: int = 512, cats=(256, 96, 
     return SplitMatrix(blocks)
 
 
+# The reference's own benchmark designs (src/tabmat/benchmark/generate_matrices.py:90-100):
+# uniform random dense values, uniformly drawn category codes, scipy.sparse.random's default
+# density of 1 %.  Same shapes and block order; generated in HBM.
+REFERENCE_DESIGNS = {
+    "dense": dict(n=4_000_000, dense=10),
+    "sparse": dict(n=400_000, sparse=100),
+    "sparse_narrow": dict(n=3_000_000, sparse=3),
+    "sparse_wide": dict(n=40_000, sparse=10_000),
+    "one_cat": dict(n=1_000_000, cats=(100_000,)),
+    "two_cat": dict(n=1_000_000, cats=(1_000, 1_000)),
+    "dense_cat": dict(n=3_000_000, cats=(1_000, 1_000), dense=5),
+    "dense_smallcat": dict(n=3_000_000, cats=(10, 1_000), dense=5),
+}
+
+
+def reference_design(name: str, n: int | None = None, seed: int = 0):
+    """One of the reference's benchmark matrices as a tabmat_amd object (n overrides the rows)."""
+    spec = REFERENCE_DESIGNS[name]
+    n = int(n or spec["n"])
+    blocks = [cat_block(n, c, seed + 10 + i) for i, c in enumerate(spec.get("cats", ()))]
+    if "dense" in spec:
+        g = _gen(seed)
+        blocks.append(DenseMatrix(torch.rand((n, spec["dense"]), dtype=torch.float64, device=g.device,
+                                             generator=g)))
+    if "sparse" in spec:
+        blocks.append(sparse_block(n, spec["sparse"], 0.01, torch.float64, seed + 1))
+    return blocks[0] if len(blocks) == 1 else SplitMatrix(blocks)
+
+
 def algorithmic_bytes(mat) -> int:
     """Bytes of every operand read once + the output written once."""
     total = 0

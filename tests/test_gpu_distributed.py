@@ -22,14 +22,14 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q, device_resident):
+def _worker(rank, world, port, q, device_resident, backend="gloo", ndev=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(rank % ndev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import _cases as cs
         from _gpu_util import to_tm_split
@@ -47,7 +47,7 @@ def _worker(rank, world, port, q, device_resident):
         w = rng.standard_normal(n)
         v = rng.standard_normal(full.shape[1])
         rows_g = np.sort(rng.choice(n, n // 3, replace=False))
-        sh = shard(full)
+        sh = shard(full, always_reduce=True)     # world 1: the collective is issued all the same
         lo, hi = sh.bounds
         assert sh.local.shape[0] == hi - lo
         got = sh.sandwich_global(d)
@@ -91,3 +91,38 @@ def test_world2_hip_shards_match_single_rank_and_oracle(device_resident):
     for rank, errs, _ in res:
         for k, e in errs.items():
             assert e < 1e-10, (rank, k, e)
+
+
+def _run(world, device_resident, backend, ndev):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, device_resident, backend, ndev))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, errs, _ in res:
+        for k, e in errs.items():
+            assert e < 1e-10, (rank, k, e)
+    return res
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_world1():
+    """backend "nccl" (= RCCL) on one GPU: the communicator is created and the all-reduce of the
+    p x p device result and of the numpy-convention result run through RCCL (world size 1 -- the
+    code path that the 8-GPU job takes, minus the xGMI transfers)."""
+    res = _run(1, True, "nccl", 1)
+    assert res[0][2] == (0, 30_011)
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_world2_two_devices():
+    """Two ranks on two GPUs over RCCL, when the box has two."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
+    _run(2, True, "nccl", 2)

@@ -71,6 +71,16 @@ def test_cfg4_split_sandwich_10M():
     lhs = float(S1.sum())
     rhs = float((d1 * rs * rs).sum())
     assert abs(lhs - rhs) / abs(rhs) < 1e-11
+    # vector-level identity for random u: S u == X' (d * (X u)), the right side from the matvec /
+    # transpose_matvec kernels (independent of every sandwich kernel).  Unlike the scalar checksum
+    # this sees every entry of S with a random weight: an error confined to one tile of one block
+    # product of the UNRESTRICTED kernels (the ones bench.py times) shows up in the rows of that tile.
+    for seed in (11, 12, 13):
+        gu = torch.Generator(device="cuda").manual_seed(seed)
+        u = torch.randn(p, dtype=torch.float64, device="cuda", generator=gu)
+        lhs_v = S1 @ u
+        rhs_v = X.transpose_matvec(d1 * X.matvec(u))
+        assert float((lhs_v - rhs_v).abs().max() / lhs_v.abs().max()) < 1e-11
     # X' d from transpose_matvec == first-moment identity through a second sandwich-free path
     tmv = X.transpose_matvec(d1)
     assert abs(float(tmv.sum()) - float((d1 * rs).sum())) / abs(float(tmv.sum())) < 1e-11
@@ -96,6 +106,24 @@ def test_cfg4_split_sandwich_10M():
         assert float((X.matvec(ones, cols=cols) - X.matvec(vm)).abs().max()) < 1e-9
     assert torch.equal(X.sandwich(d1, cols=np.arange(p)), S1) or \
         float((X.sandwich(d1, cols=np.arange(p)) - S1).abs().max() / S1.abs().max()) < 1e-12
+    # true oracle comparison of the UNRESTRICTED path on contiguous device slices X[lo:hi] of 50k
+    # rows, taken at three offsets >= 2^31 bytes into the dense block (row 2^21 and beyond): the
+    # slices stay in HBM (device __getitem__), run the unrestricted kernels, and are compared with
+    # the oracle on the pulled-back rows -- one by one and summed.
+    tot_gpu, tot_ref = None, None
+    for lo in (2_200_000, 5_000_017, 9_949_999):
+        hi = lo + 50_000
+        assert lo * 128 * 8 >= 2 ** 31
+        Xs = X[lo:hi]
+        ds = d1[lo:hi].contiguous()
+        got = Xs.sandwich(ds).cpu().numpy()
+        rows_t = torch.arange(lo, hi, device="cuda")
+        blocks = [cs.to_oracle_block(sp) for sp in _subset_specs(X, rows_t)]
+        ref = _orc().split_sandwich(blocks, [np.asarray(i) for i in X.indices], ds.cpu().numpy())
+        assert rel_err(got, ref) < 1e-10
+        tot_gpu = got if tot_gpu is None else tot_gpu + got
+        tot_ref = ref if tot_ref is None else tot_ref + ref
+    assert rel_err(tot_gpu, tot_ref) < 1e-10
     # true oracle comparison on a random row subset via rows=
     rows = np.sort(rng.choice(n, size=20_000, replace=False)).astype(np.int32)
     rows_t = torch.as_tensor(rows.astype(np.int64), device="cuda")
