@@ -263,15 +263,18 @@ int tm_csr_dense_sandwich_lg_f64(const double *vals, const uint32_t *koff, const
                                  const double *B, int64_t r, const double *d, int unconditional,
                                  double *out, void *stream);
 
-/* The same pass fused with the dense self sandwich (ext/dense.pyx:19-44 dense_sandwich ->
- * ext/dense_helpers-tmpl.cpp:266-311): B must be exactly 128 columns wide (row stride 128), C-ordered
- * and 16-byte aligned, A must have more than 256 columns (m > 256, a multiple of 16).  out: (m, 128)
- * = A^T diag(d) B as above; out_self: (128, 128) = B^T diag(d) B, both triangles, overwritten.
- * The dense block is read ONCE for both products; the self sandwich runs on the matrix cores in the
- * gaps of the gather (csrc/sparse_lg.hip).  All rows take part (no row restriction). */
-int tm_csr_dense_sandwich_lg_syrk_f64(const double *vals, const uint32_t *koff, const uint32_t *xkoff,
-                                      int64_t n, int64_t m, const double *B, const double *d,
-                                      double *out, double *out_self, void *stream);
+/* The same pass, additionally colsum (length m, kernel column order -- the caller applies the same
+ * permutation as to the rows of out) = A^T d: `value * d` is formed for every stream slot anyway, so
+ * StandardizedMatrix.sandwich needs no second pass over the sparse block (the reference calls
+ * transpose_matvec, standardized_mat.py:149-150). */
+int tm_csr_dense_sandwich_lg_xtd_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,
+                                     const float *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                     const float *B, int64_t r, const float *d, int unconditional,
+                                     float *out, float *colsum, void *stream);
+int tm_csr_dense_sandwich_lg_xtd_f64(const double *vals, const uint32_t *koff, const int64_t *xptr,
+                                     const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                     const double *B, int64_t r, const double *d, int unconditional,
+                                     double *out, double *colsum, void *stream);
 
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */

@@ -46,11 +46,8 @@ constexpr unsigned LG_KMASK = 0xFFFFFu;
 template <typename F>
 struct LgLds {
     static constexpr int ROWB = LG_W * (int)sizeof(F);      // bytes of a slab row
-    // LDS row stride: 16 elements more than a row, so that the four rows of an MFMA fragment
-    // (lane -> row 4s + (lane >> 4), 16 consecutive elements) fall into different banks (fused
-    // syrk below); the 1 KiB / 512 B gather reads are contiguous and do not care.
-    // (f64 only: an f32 copy piece of 1 KiB holds two rows and the LDS-DMA writes them contiguously)
-    static constexpr int RSB = ROWB + (sizeof(F) == 8 ? 128 : 0);
+    // LDS row stride = the row itself: the 1 KiB / 512 B gather reads are contiguous
+    static constexpr int RSB = ROWB;
     static constexpr int BUFB = (LG_R + 1) * RSB;           // [zero row][LG_R rows]
     static constexpr int DL_OFF = 2 * BUFB;
     static constexpr int DLN = LG_R + 2;                       // [0][d of LG_R rows][pad]
@@ -123,29 +120,18 @@ __device__ __forceinline__ void lg_fmac(float &acc, float a, float x) {
 // instructions per wave and slab, 3.3 ms of the kernel's 6.1 ms with all arithmetic and all LDS
 // traffic removed (profiles/r2_k3_ablation.txt).  Only the LAST slab of the matrix can hold rows
 // beyond n; it uses clamped offsets (tail_*).
-// NG = groups per wave: 1 -> 16 waves x 16 columns; 2 -> 8 waves x 32 columns (twice the registers
-// per wave, half the waves -- the geometry that leaves room for other work in the wave).
+// NG = groups per wave (1: 16 waves x 16 columns, the shipped geometry).
 //
-// SYRK = true (f64, NG = 2, B exactly 128 columns wide, at least two workgroups per slab range):
-// the SAME pass also computes the dense self sandwich  B^T diag(d) B  (K1, reference
-// ext/dense_helpers-tmpl.cpp:266-311) on the matrix cores: the slab is in LDS anyway, the MFMA
-// pipe is idle in the gather and the wave waits for LDS data most of the time.  The 128 columns
-// are cut into 8 VIRTUAL blocks of 16: pair p = columns 32p .. 32p + 31, virtual block 2p = its
-// even, 2p + 1 = its odd columns, so that ONE ds_read_b128 per lane fetches the fragments of two
-// blocks (lane -> row 4s + (lane >> 4), columns 32p + 2 (lane & 15), + 1).  The 36 lower-
-// triangular 16 x 16 tiles are dealt to 16 wave UNITS (unit = blockIdx.z * 8 + wave):
-//     units 0..3   pair (a, a):        tiles (2a, 2a), (2a+1, 2a), (2a+1, 2a+1)   -- one read
-//     units 4..15  pair (a, b), a > b, half h:  tiles (2a, 2b+h), (2a+1, 2b+h)     -- b128 + b64
-// One K = 4 step (4 slab rows) per column pair of the gather, 16 per slab: the MFMAs of step s
-// are issued right after the gather's LDS reads of that column pair (they run while the wave
-// would wait for the data anyway), the fragments of step s + 1 right after them.
-template <typename F, int UNC, int NG, bool SYRK>
+// CSUM = true: the column sums  A^T d  (length m, kernel column order) come out of the same pass --
+// `value * d` is formed for every slot anyway, one v_add per chunk accumulates it per lane, the 8
+// positions of a column are summed at the end.  StandardizedMatrix.sandwich then needs no second
+// pass over the sparse block (reference: standardized_mat.py:149-150 calls transpose_matvec).
+template <typename F, int UNC, int NG, bool CSUM>
 __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ xptr,
     const F *__restrict__ xvals, const unsigned *__restrict__ xkoff, int n_groups, int64_t n_slabs,
     int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r, int nB,
-    const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_syrk, int *__restrict__ prog) {
-    static_assert(!SYRK || (sizeof(F) == 8 && NG == 2), "fused syrk: f64, two groups per wave");
+    const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_csum, int *__restrict__ prog) {
     const uint4 *__restrict__ xent = reinterpret_cast<const uint4 *>(xkoff);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using L = LgLds<F>;
@@ -158,7 +144,7 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     constexpr int NV = SLABB / 16 / NTH;                   // 1 KiB pieces copied per wave
     constexpr int RPP = 1024 / ROWB;                       // slab rows per 1 KiB wave piece
     constexpr int RSB = L::RSB;
-    static_assert(RSB == 1152 || RSB == 512, "row stride");
+    static_assert(RSB == 1024 || RSB == 512, "row stride");
     typedef F vec_t __attribute__((ext_vector_type(VEC)));
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const int tid = threadIdx.x;
@@ -183,31 +169,12 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
             for (int u = 0; u < NRD; ++u)
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[q][j][u][e] = F(0);
-    // ---- fused syrk state (SYRK only) ----
-    typedef double sacc_t __attribute__((ext_vector_type(4)));
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    sacc_t sacc[3];
+    // ---- column sums of value * d per slot (CSUM only) ----
+    F csum[NG][LG_CHUNKS];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) sacc[t] = sacc_t{0, 0, 0, 0};
-    const int unit = blockIdx.z * NWV + wave;              // 0 .. 15 hold tiles
-    const bool uact = SYRK && unit < 16;
-    const bool udiag = unit < 4;
-    unsigned foffA = 0, foffB = 0;                         // fragment byte offsets inside a slab buffer
-    if constexpr (SYRK) {
-        const int uc = unit < 16 ? unit : 15;
-        int pa = uc, pb = uc, ph = 0;
-        if (!udiag) {
-            const int idx = (uc - 4) >> 1;                 // (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
-            ph = (uc - 4) & 1;
-            pa = idx < 1 ? 1 : (idx < 3 ? 2 : 3);
-            pb = idx - pa * (pa - 1) / 2;
-        }
-        const unsigned rowoff = (unsigned)(RSB + (lane >> 4) * RSB);    // data rows start after the zero row
-        foffA = rowoff + (unsigned)((32 * pa + 2 * (lane & 15)) * 8);
-        foffB = rowoff + (unsigned)((32 * pb + 2 * (lane & 15) + ph) * 8);
-    }
-    d2_t fxa = d2_t{0, 0};
-    double fy = 0;
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int c = 0; c < LG_CHUNKS; ++c) csum[q][c] = F(0);
     // zero rows of both buffers, d = 0 for them
     for (int i = tid; i < 2 * ROWB / (int)sizeof(F); i += NTH) {
         const int b = i / (ROWB / (int)sizeof(F)), c = i % (ROWB / (int)sizeof(F));
@@ -307,46 +274,7 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         int pseen = 0x7fffffff;
         if (my_prog != nullptr && tid == 0 && gridDim.z > 1)
             pseen = __hip_atomic_load(my_prog + zn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (SYRK) fragments of K step s -> registers; the MFMAs of the step held in the registers
-        // per-iteration fragment bases, opaque to the optimiser: with the step offsets as
-        // IMMEDIATES of the ds_read (s * 4 * RSB <= 32256 from one of two bases) nothing is
-        // precomputed per step (the compiler otherwise keeps 16 x 3 addresses in registers)
-        unsigned fbA = slab_base + foffA, fbB = slab_base + foffB;
-        if constexpr (SYRK) asm volatile("" : "+v"(fbA), "+v"(fbB));
-        // d of all 64 slab rows in ONE register pair: lane 16 R + s holds d[4 s + R], so that step s
-        // finds its d (row 4 s + (lane >> 4)) with row_newbcast:s -- no LDS read per step
-        double dq = 0;
-        if constexpr (SYRK) dq = (double)dl[1 + 4 * (lane & 15) + (lane >> 4)];
-        auto frag_read = [&](int s) {
-            if constexpr (SYRK) {
-                const unsigned hi = s >= 8 ? 8u * 4u * RSB : 0u;       // second base for steps 8 .. 15
-                const unsigned off = (unsigned)((s & 7) * 4 * RSB);
-                fxa = *reinterpret_cast<const __attribute__((address_space(3))) d2_t *>(
-                    (lds_byte *)(uintptr_t)(fbA + hi) + off);
-                fy = *reinterpret_cast<const __attribute__((address_space(3))) double *>(
-                    (lds_byte *)(uintptr_t)(fbB + hi) + off);
-            }
-        };
-        auto kstep = [&](auto sc_) {
-            if constexpr (SYRK) {
-                constexpr int s = decltype(sc_)::value;
-                // x * d[row of the step] with the broadcast inside the FMA (acc = 0)
-                auto muld = [&](double x) {
-                    double r = 0.0;
-                    lg_fmac<s>(r, dq, x);
-                    return r;
-                };
-                const double x0d = muld(fxa[0]), x1d = muld(fxa[1]), yd = muld(fy);
-                const double a0 = udiag ? x0d : fxa[0], a1 = udiag ? x1d : fxa[1];
-                const double b0 = udiag ? fxa[0] : yd;
-                sacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, sacc[1], 0, 0, 0);
-                if (udiag) sacc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fxa[1], sacc[2], 0, 0, 0);
-                if constexpr (s + 1 < LG_R / 4) frag_read(s + 1);
-            }
-        };
-        frag_read(0);
-        if (!SYRK && !active) {         // a wave without columns still copies its share
+        if (!active) {                  // a wave without columns still copies its share
             if (more) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) issue_piece(buf ^ 1, i);
@@ -354,27 +282,20 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         } else {
             // one chunk: fold d into the values, redirect d == 0 rows to the zero row, then the
             // positions of columns j = 2c, 2c + 1 of both halves
-            // (SYRK) `mf(jl)`: the K = 4 step that belongs to column pair jl of this chunk
-            // `early_` = false: no early outs for empty chunks / column pairs, so that `mf` runs at
-            // exactly one place per column pair in straight-line code (the MFMA accumulators of the
-            // fused syrk must not meet at control-flow joins: the allocator then keeps copies).
-            auto do_chunk = [&](auto qc_, auto cc_, F v, unsigned kraw, auto early_, auto &&mf) {
+            auto do_chunk = [&](auto qc_, auto cc_, F v, unsigned kraw) {
                 constexpr int c = decltype(cc_)::value;
                 constexpr int q = decltype(qc_)::value;
-                constexpr bool EARLY = decltype(early_)::value;
                 const unsigned kk = kraw & LG_KMASK;
                 const unsigned long long real = __builtin_amdgcn_ballot_w64(kk != 0u);
                 const unsigned comb = ((unsigned)real | (unsigned)(real >> 32)) & 0xFFFFu;
-                if constexpr (EARLY) {
-                    if (comb == 0u) return;
-                }
-                // row = kk / RSB (1152 = 9 << 7: (x * 57) >> 9 is x / 9 exactly for x <= 9 * 64)
-                const F dk = dl[RSB == 1152 ? (((kk >> 7) * 57u) >> 9) : (kk >> 9)];
+                if (comb == 0u) return;
+                const F dk = dl[kk >> (RSB == 1024 ? 10 : 9)];          // row = kk / RSB
                 F a = v * dk;
+                if constexpr (CSUM) csum[q][c] += a;                     // (padding: v = 0, dk = d[-1] = 0)
                 unsigned kq = slab_base + (dk != F(0) ? kk : 0u);      // absolute LDS address
                 // DPP reads of a VGPR need two wait states after the VALU write
                 asm volatile("s_nop 1" : "+v"(a), "+v"(kq));
-                auto positions = [&](auto jlc, auto itc, auto cntc, auto &&inject) {
+                auto positions = [&](auto jlc, auto itc, auto cntc) {
                     constexpr int jl = decltype(jlc)::value;
                     constexpr int it = decltype(itc)::value;
                     constexpr int cnt = decltype(cntc)::value;
@@ -388,7 +309,6 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                                 const __attribute__((address_space(3))) vec_t *>(
                                 (lds_byte *)(uintptr_t)(addr + u * 512));
                     });
-                    inject();
                     static_for<cnt>([&](auto e) {
                         constexpr int SEL = jl * 8 + it + decltype(e)::value;
 #pragma unroll
@@ -398,28 +318,24 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                                 lg_fmac<SEL>(acc[q][2 * c + jl][u][qq], a, x[decltype(e)::value][u][qq]);
                     });
                 };
-                auto none = [] {};
                 static_for<2>([&](auto jlc) {
                     constexpr int jl = decltype(jlc)::value;
-                    if constexpr (EARLY) {
-                        if (!(comb & (1u << (jl * 8)))) return;   // neither half has a nonzero here
-                    }
-                    positions(jlc, std::integral_constant<int, 0>{}, std::integral_constant<int, UNC>{},
-                              [&] { mf(jlc); });
+                    if (!(comb & (1u << (jl * 8)))) return;       // neither half has a nonzero here
+                    positions(jlc, std::integral_constant<int, 0>{}, std::integral_constant<int, UNC>{});
                     if constexpr (UNC <= 2) {
                         if (comb & (1u << (jl * 8 + 2))) {
-                            positions(jlc, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, none);
+                            positions(jlc, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
                             if (comb & (1u << (jl * 8 + 4))) {
-                                positions(jlc, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, none);
+                                positions(jlc, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
                                 if (comb & (1u << (jl * 8 + 6)))
-                                    positions(jlc, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, none);
+                                    positions(jlc, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
                             }
                         }
                     } else {
                         if (comb & (1u << (jl * 8 + 4))) {
-                            positions(jlc, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, none);
+                            positions(jlc, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
                             if (comb & (1u << (jl * 8 + 6)))
-                                positions(jlc, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, none);
+                                positions(jlc, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
                         }
                     }
                 });
@@ -436,9 +352,7 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
             // round trip in the middle of the iteration of 63 % of the workgroups (6.0 -> 4.9 ms).
             static_for<NG>([&](auto qc_) {
             constexpr int q = decltype(qc_)::value;
-            if constexpr (!SYRK) {
-                if (!act[q]) return;
-            }
+            if (!act[q]) return;
             const int nrec = __builtin_amdgcn_readlane((int)pk[q][0], 0) >> 20 & 0xFFF;
             int64_t rec0 = 0;
             uint4 e = uint4{0u, 0u, 0u, 0u};
@@ -472,50 +386,25 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                 else
                     eval = __builtin_bit_cast(F, e.x);
             };
-            if constexpr (SYRK) {
-                // pass 0 in straight-line code with the K steps of the syrk inside; the overflow
-                // passes in a loop of their own (a second instantiation of the chunk code)
+            for (int pass = 0; pass <= nrec; ++pass) {
+                int ec, eslot;
+                F eval;
+                entry_of(pass, ec, eslot, eval);
                 static_for<LG_CHUNKS>([&](auto cc_) {
-                    constexpr int cq = q * LG_CHUNKS + decltype(cc_)::value;
+                    constexpr int c = decltype(cc_)::value;
                     F v;
                     unsigned k;
-                    round0(cc_, v, k);
-                    do_chunk(qc_, cc_, v, k, std::false_type{}, [&](auto jlc_) {
-                        kstep(std::integral_constant<int, 2 * cq + decltype(jlc_)::value>{});
-                    });
-                });
-                for (int pass = 1; pass <= nrec; ++pass) {
-                    int ec, eslot;
-                    F eval;
-                    entry_of(pass, ec, eslot, eval);
-                    static_for<LG_CHUNKS>([&](auto cc_) {
-                        constexpr int c = decltype(cc_)::value;
+                    if (pass == 0) {
+                        round0(cc_, v, k);
+                    } else {
                         const bool hit = ec == c && lane32 == eslot;
-                        if (ec == c)
-                            do_chunk(qc_, cc_, hit ? eval : F(0), hit ? e.z : 0u, std::true_type{}, [](auto) {});
-                    });
-                }
-            } else {
-                for (int pass = 0; pass <= nrec; ++pass) {
-                    int ec, eslot;
-                    F eval;
-                    entry_of(pass, ec, eslot, eval);
-                    static_for<LG_CHUNKS>([&](auto cc_) {
-                        constexpr int c = decltype(cc_)::value;
-                        F v;
-                        unsigned k;
-                        if (pass == 0) {
-                            round0(cc_, v, k);
-                        } else {
-                            const bool hit = ec == c && lane32 == eslot;
-                            v = hit ? eval : F(0);
-                            k = hit ? e.z : 0u;
-                        }
-                        // (one call site: a second instantiation of the chunk code for the overflow
-                        // passes costs 18 registers)
-                        if (pass == 0 || ec == c) do_chunk(qc_, cc_, v, k, std::true_type{}, [](auto) {});
-                    });
-                }
+                        v = hit ? eval : F(0);
+                        k = hit ? e.z : 0u;
+                    }
+                    // (one call site: a second instantiation of the chunk code for the overflow
+                    // passes costs 18 registers)
+                    if (pass == 0 || ec == c) do_chunk(qc_, cc_, v, k);
+                });
             }
             });
         }
@@ -542,16 +431,26 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         const unsigned tb = slab_base; slab_base = next_base; next_base = tb;
         const F *td = dl; dl = dl_next; dl_next = td;
     }
-    if constexpr (SYRK) {
-        if (uact) {
-            // ws_syrk layout: [block x][unit][3 tiles][16 x 16]; C/D layout of the MFMA:
-            // col = lane & 15, row = (lane >> 4) + 4 * reg
-            F *sd = ws_syrk + ((int64_t)blockIdx.x * 16 + unit) * (3 * 256);
+    if constexpr (CSUM) {
+        // slot h * 16 + (j & 1) * 8 + it of chunk c = position `it` of column 8 h + 2 c + (j & 1):
+        // sum over the 8 positions; lanes 0-15 and 32-47 hold the 32 distinct slots (16-31 / 48-63
+        // loaded the same ones).  One workgroup row of column sums per (block x): the dense part
+        // y = 0 writes them.
+        if (active && blockIdx.y == 0) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int q = 0; q < NG; ++q) {
+                if (!act[q]) continue;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    sd[t * 256 + ((lane >> 4) + 4 * rg) * 16 + (lane & 15)] = (F)sacc[t][rg];
+                for (int c = 0; c < LG_CHUNKS; ++c) {
+                    F v = csum[q][c];
+                    v += __shfl_xor(v, 1, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    if ((lane & 7) == 0 && (lane & 16) == 0)
+                        ws_csum[(int64_t)blockIdx.x * (n_groups * LG_C) + (group + q * NWV) * LG_C +
+                                8 * (lane >> 5) + 2 * c + ((lane >> 3) & 1)] = v;
+                }
+            }
         }
     }
     if (active) {
@@ -586,37 +485,20 @@ __global__ void lg_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t n
     out[e] = tmp[((j / LG_W) * m + i) * LG_W + (j % LG_W)];
 }
 
-// Fused syrk: out[ci][cj] (128 x 128, both triangles) from the per-workgroup unit tiles
-// [nblk][16 units][3][256], summed over the workgroups in a fixed order.
-__global__ __launch_bounds__(128) void lg_syrk_finish_kernel(const double *__restrict__ part, int nblk,
-                                                             double *__restrict__ out) {
-    const int ci = blockIdx.x, cj = threadIdx.x;
-    // column c: pair c >> 5, virtual block 2 * pair + (c & 1), index (c & 31) >> 1 inside it
-    int vi = 2 * (ci >> 5) + (ci & 1), ii = (ci & 31) >> 1;
-    int vj = 2 * (cj >> 5) + (cj & 1), ij = (cj & 31) >> 1;
-    if (vi < vj) {                       // the mirror: tile (vj, vi), element [ij][ii]
-        int t = vi; vi = vj; vj = t;
-        t = ii; ii = ij; ij = t;
-    }
-    const int pa = vi >> 1, pb = vj >> 1;
-    int unit, slot;
-    if (pa == pb) {
-        unit = pa;
-        slot = (vi & 1) + (vj & 1);      // (2a,2a) -> 0, (2a+1,2a) -> 1, (2a+1,2a+1) -> 2
-    } else {
-        unit = 4 + 2 * (pa * (pa - 1) / 2 + pb) + (vj & 1);
-        slot = vi & 1;
-    }
-    const double *p = part + ((int64_t)unit * 3 + slot) * 256 + ii * 16 + ij;
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += p[(int64_t)b * (16 * 3 * 256)];
-    out[ci * 128 + cj] = acc;
+// column sums: csum[c] = sum over the workgroups (fixed order) of their partial sums
+template <typename F>
+__global__ void lg_csum_kernel(const F *__restrict__ part, int nblk, int64_t m, F *__restrict__ csum) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)part[(int64_t)b * m + c];
+    csum[c] = (F)a;
 }
 
 template <typename F>
 static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *xptr, const F *xvals,
                             const unsigned *xkoff, int64_t n, int64_t m, const F *B, int64_t r,
-                            const F *d, int unc, F *out, F *out_self, hipStream_t st) {
+                            const F *d, int unc, F *out, F *colsum, hipStream_t st) {
     const int64_t nB = r;
     const int64_t total = m * nB;
     if (total == 0) return TM_OK;
@@ -633,15 +515,10 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     const int n_groups = (int)(m / LG_C);
     const int n_parts = (int)ceil_div(nB, LG_W);
     const int nz = (int)ceil_div(n_groups, LG_NW);
-    const bool fused = out_self != nullptr;
-    if (fused && (sizeof(F) != 8 || nB != LG_W || nz < 2)) {
-        set_error("tm_csr_dense_sandwich_lg_syrk: needs float64, exactly 128 dense columns and more "
-                  "than 256 sparse columns");
-        return TM_EUNSUPPORTED;
-    }
+    const bool want_csum = colsum != nullptr;
     if (n_slabs == 0) {
         TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
-        if (fused) TM_HIP(hipMemsetAsync(out_self, 0, sizeof(F) * (size_t)(nB * nB), st));
+        if (want_csum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(F) * (size_t)m, st));
         return TM_OK;
     }
     int64_t nblk = std::max<int64_t>(1, NUM_CU / ((int64_t)n_parts * nz));
@@ -651,40 +528,36 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     const int64_t stride = m * LG_W;  // per (part, block)
     const size_t tmp_bytes = (sizeof(F) * (size_t)(n_parts * stride) + 255) / 256 * 256;
     const size_t part_bytes = (sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 255) / 256 * 256;
-    const size_t syrk_bytes = (fused ? sizeof(F) * (size_t)(nblk * 16 * 3 * 256) : 0) + 256;
+    const size_t csum_bytes = ((want_csum ? sizeof(F) * (size_t)(nblk * m) : 0) + 255) / 256 * 256 + 256;
     // soft lockstep of the column-half workgroups (21.2 -> 18.1 GB of HBM traffic at cfg4, same
     // time); TABMAT_AMD_LG_LOCKSTEP=0 switches it off
     static const int lockstep = getenv("TABMAT_AMD_LG_LOCKSTEP") ? atoi(getenv("TABMAT_AMD_LG_LOCKSTEP")) : 1;
     const size_t prog_bytes = (sizeof(int) * (size_t)(n_parts * nblk * nz) + 255) / 256 * 256;
     void *wsv = nullptr;
-    int rc = get_workspace(tmp_bytes + part_bytes + syrk_bytes + prog_bytes + 256, &wsv, st);
+    int rc = get_workspace(tmp_bytes + part_bytes + csum_bytes + prog_bytes + 256, &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    F *ws_syrk = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes);
+    F *ws_csum = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes);
     int *prog = nullptr;
     if (lockstep && nz > 1) {
-        prog = reinterpret_cast<int *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes + syrk_bytes);
+        prog = reinterpret_cast<int *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes + csum_bytes);
         TM_HIP(hipMemsetAsync(prog, 0, prog_bytes, st));
     }
     const size_t lds = (size_t)LgLds<F>::TOTAL;
-    static const int ng = getenv("TABMAT_AMD_LG_NG") ? atoi(getenv("TABMAT_AMD_LG_NG")) : 1;
-    auto kern = ng == 2 ? &csr_dense_lg_kernel<F, 2, 2, false>
-                        : (unc >= 4 ? &csr_dense_lg_kernel<F, 4, 1, false>
-                                    : &csr_dense_lg_kernel<F, 2, 1, false>);
-    int threads = ng == 2 ? LG_THREADS / 2 : LG_THREADS;
-    if constexpr (sizeof(F) == 8) {
-        if (fused) {
-            kern = &csr_dense_lg_kernel<F, 2, 2, true>;
-            threads = LG_THREADS / 2;
-        }
-    }
+    // (groups with no columns at all leave their slots of the partial sums untouched)
+    if (want_csum) TM_HIP(hipMemsetAsync(ws_csum, 0, sizeof(F) * (size_t)(nblk * m), st));
+    // (f64 with 4 unconditional positions has no registers left for the column sums: UNC = 2 there)
+    auto kern = want_csum ? (unc >= 4 && sizeof(F) == 4 ? &csr_dense_lg_kernel<F, 4, 1, true>
+                                                        : &csr_dense_lg_kernel<F, 2, 1, true>)
+                          : (unc >= 4 ? &csr_dense_lg_kernel<F, 4, 1, false> : &csr_dense_lg_kernel<F, 2, 1, false>);
+    const int threads = LG_THREADS;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(threads),
                        lds, st, vals, koff, xptr, xvals, xkoff, n_groups, n_slabs, spb, B, n, r,
-                       (int)nB, d, ws, ws_syrk, prog);
+                       (int)nB, d, ws, ws_csum, prog);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
@@ -692,12 +565,10 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     hipLaunchKernelGGL((lg_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
                        tmp, m, nB, out);
     TM_LAUNCH_CHECK();
-    if constexpr (sizeof(F) == 8) {
-        if (fused) {
-            hipLaunchKernelGGL(lg_syrk_finish_kernel, dim3(128), dim3(128), 0, st, ws_syrk, (int)nblk,
-                               out_self);
-            TM_LAUNCH_CHECK();
-        }
+    if (want_csum) {
+        hipLaunchKernelGGL((lg_csum_kernel<F>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, ws_csum,
+                           (int)nblk, m, colsum);
+        TM_LAUNCH_CHECK();
     }
     return TM_OK;
 }
@@ -725,15 +596,28 @@ int tm_csr_dense_sandwich_lg_f64(const double *vals, const uint32_t *koff, const
     return tmh::run_csr_dense_lg<double>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d,
                                          unconditional, out, nullptr, tmh::as_stream(stream));
 }
-int tm_csr_dense_sandwich_lg_syrk_f64(const double *vals, const uint32_t *koff, const uint32_t *xkoff,
-                                      int64_t n, int64_t m, const double *B, const double *d,
-                                      double *out, double *out_self, void *stream) {
-    if (!out_self) {
-        tmh::set_error("tm_csr_dense_sandwich_lg_syrk_f64: out_self is NULL");
+/* the same pass, additionally colsum (length m, kernel column order) = A' d */
+int tm_csr_dense_sandwich_lg_xtd_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,
+                                     const float *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                     const float *B, int64_t r, const float *d, int unconditional,
+                                     float *out, float *colsum, void *stream) {
+    if (!colsum) {
+        tmh::set_error("tm_csr_dense_sandwich_lg_xtd: colsum is NULL");
         return TM_EINVAL;
     }
-    return tmh::run_csr_dense_lg<double>(vals, koff, nullptr, nullptr, xkoff, n, m, B, 128, d, 2, out,
-                                         out_self, tmh::as_stream(stream));
+    return tmh::run_csr_dense_lg<float>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d, unconditional,
+                                        out, colsum, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_lg_xtd_f64(const double *vals, const uint32_t *koff, const int64_t *xptr,
+                                     const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
+                                     const double *B, int64_t r, const double *d, int unconditional,
+                                     double *out, double *colsum, void *stream) {
+    if (!colsum) {
+        tmh::set_error("tm_csr_dense_sandwich_lg_xtd: colsum is NULL");
+        return TM_EINVAL;
+    }
+    return tmh::run_csr_dense_lg<double>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d,
+                                         unconditional, out, colsum, tmh::as_stream(stream));
 }
 
 }  // extern "C"

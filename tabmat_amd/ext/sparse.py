@@ -115,46 +115,26 @@ def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
     return out[A.inv]      # kernel rows are the density-sorted columns
 
 
-def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None):
+def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None, want_colsum=False):
     """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B of
-    more than 64 columns: lane-group twin, DPP-broadcast gather (csrc/sparse_lg.hip)."""
+    more than 64 columns: lane-group twin, DPP-broadcast gather (csrc/sparse_lg.hip).
+    want_colsum: returns (out, A' d) -- the column sums ride along in the same pass."""
     assert B.n == A.n and ell_supported(B)
     if A.m == 0 or B.m == 0 or A.n == 0:
-        return D.zeros((A.m, B.m), A.vals.dtype)
+        z = D.zeros((A.m, B.m), A.vals.dtype)
+        return (z, D.zeros((A.m,), A.vals.dtype)) if want_colsum else z
     out = D.out_buf((A.mk, B.m), A.vals.dtype)
     D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
+    u = int(A.unc if unc is None else unc)
+    if want_colsum:
+        cs = D.out_buf((A.mk,), A.vals.dtype)
+        call("tm_csr_dense_sandwich_lg_xtd_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
+             D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.p(cs),
+             D.stream_ptr())
+        return out[A.inv], cs[A.inv]
     call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
-         D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d),
-         int(A.unc if unc is None else unc), D.p(out), D.stream_ptr())
+         D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.stream_ptr())
     return out[A.inv]      # kernel rows are the density-sorted columns
-
-
-def lg_syrk_supported(A: SlabLg, B: DenseDev) -> bool:
-    """The fused sparse x dense + dense self sandwich needs float64, a C-ordered dense block of
-    exactly 128 columns and more than 256 (padded) sparse columns (tabmat_hip.h)."""
-    import torch
-
-    return (A is not None and A.vals.dtype == torch.float64 and B.buf.dtype == torch.float64
-            and B.m == 128 and A.mk > 256 and ell_supported(B))
-
-
-def csr_dense_sandwich_lg_syrk(A: SlabLg, B: DenseDev, d):
-    """ONE pass over the dense block for two blocks of the split sandwich: returns
-    (A^T diag(d) B  (m, 128),  B^T diag(d) B  (128, 128)).  Replaces csr_dense_sandwich
-    (ext/sparse.pyx:211-260) + dense_sandwich (ext/dense.pyx:19-44) of the same row weights; the
-    self sandwich runs on the matrix cores inside the gather kernel (csrc/sparse_lg.hip)."""
-    import torch
-
-    assert B.n == A.n and lg_syrk_supported(A, B)
-    D.same_float("csr_dense_sandwich_lg_syrk", A.vals, B.buf, d)
-    if not A.n:
-        return D.zeros((A.m, 128), torch.float64), D.zeros((128, 128), torch.float64)
-    out = D.out_buf((A.mk, 128), torch.float64)
-    out_self = D.out_buf((128, 128), torch.float64)
-    if A.n:
-        call("tm_csr_dense_sandwich_lg_syrk_f64", D.p(A.vals), D.p(A.koff), D.p(A.xkoff), A.n, A.mk,
-             D.p(B.buf), D.p(d), D.p(out), D.p(out_self), D.stream_ptr())
-    return out[A.inv], out_self
 
 
 def _row_table(A: CsrDev, rows, d, as_set: bool):

@@ -355,7 +355,9 @@ class SparseMatrix(MatrixBase):
                                  D.idx_dev(normalize_index(cols, self.shape[1])))
         return res if on_dev else D.to_host(res)
 
-    def _cross_sandwich_dev(self, other, d, rows, L_cols, R_cols):
+    def _cross_sandwich_dev(self, other, d, rows, L_cols, R_cols, colsum_box=None):
+        """colsum_box: a list that receives self[rows, L_cols]' d[rows] when the kernel that runs
+        produces it in the same pass (the lane-group K3; SplitMatrix._sandwich_xtd_dev)."""
         from .categorical_matrix import CategoricalMatrix
         from .dense_matrix import DenseMatrix
 
@@ -398,7 +400,10 @@ class SparseMatrix(MatrixBase):
                 ell = None
                 if lg is None and xs.ell_supported(Bd):
                     ell = self._ell(wide=Bd.m > 64)
-                if lg is not None:
+                if lg is not None and colsum_box is not None:
+                    res, cs = xs.csr_dense_sandwich_lg(lg, Bd, d, want_colsum=True)
+                    colsum_box.append(cs if L_cols is None else cs[L_cols.to(torch.int64)])
+                elif lg is not None:
                     res = xs.csr_dense_sandwich_lg(lg, Bd, d)
                 elif ell is not None:
                     res = xs.csr_dense_sandwich_ell(ell, Bd, d)

@@ -39,11 +39,6 @@ from .util import (
 # nothing overlaps but their tails, and interleaved workgroups of different kernels break the L2
 # pairing the kernels are laid out for.  Off by default; kept as the evidence for that choice.
 N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
-# One pass over the dense block for the sparse x dense cross term AND the dense self sandwich
-# (tm_csr_dense_sandwich_lg_syrk_f64).  Off by default: measured SLOWER than the two kernels
-# (9.4 vs 9.1 ms at cfg4) -- the f64 MFMAs and the gather's f64 FMAs share the DP pipe, the
-# matrix work does not hide in the gather's LDS waits.
-FUSE_SYRK = os.environ.get("TABMAT_AMD_FUSE_SYRK", "0") == "1"
 # TABMAT_AMD_OVERLAP=1: the dense self sandwich as a GUEST kernel on a side stream
 # (tm_dense_sandwich_co_f64): it shares the compute units with the categorical cross terms and the
 # sparse self sandwich, which are launched with 12 instead of 16 waves so that its registers fit.
@@ -729,6 +724,8 @@ class SplitMatrix(MatrixBase):
                         self_done):
         """The block products of one sandwich on the current stream (everything but a dense self
         term that `_sandwich_dev` gave to the guest stream)."""
+        from .ext import dense as xd
+
         mats = self.matrices
         # ---- fused categorical cross terms: one pass over the dense / sparse block serves
         #      every categorical block (tm_multi_cat_*), instead of one pass per pair
@@ -772,25 +769,6 @@ class SplitMatrix(MatrixBase):
                             res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
                             xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                         done.add((min(i, w), max(i, w)))
-        if FUSE_SYRK and rows is None and d.dtype == torch.float64:
-            from .ext import sparse as xs
-            for i, mi in enumerate(mats):
-                if not (isinstance(mi, DenseMatrix) and sub_d[i] is None and i not in self_done):
-                    continue
-                for j, mj in enumerate(mats):
-                    if not (isinstance(mj, SparseMatrix) and sub_d[j] is None) \
-                            or (min(i, j), max(i, j)) in done:
-                        continue
-                    Bd = mi._dev_c()
-                    lg = mj._lg() if Bd is not None else None
-                    if lg is None or not xs.lg_syrk_supported(lg, Bd):
-                        continue
-                    cross, selfb = xs.csr_dense_sandwich_lg_syrk(lg, Bd, d)     # (sparse, dense)
-                    xsplit.scatter_block(cross.contiguous(), pos_d[j], pos_d[i], out, mirror=True)
-                    xsplit.scatter_block(selfb, pos_d[i], pos_d[i], out)
-                    done.add((min(i, j), max(i, j)))
-                    self_done.add(i)
-                    break
         # ---- all categorical x categorical tables that fit an LDS tile, and the categorical
         #      diagonals, in ONE pass over the codes (tm_multi_cat_pairs_*): a design with k
         #      categoricals has k (k - 1) / 2 of them, one launch each was ~30 us apiece
@@ -852,6 +830,11 @@ class SplitMatrix(MatrixBase):
                         colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
                     if i not in diag_scattered:
                         xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
+                elif (colsum is not None and colsum[i] is None and isinstance(mi, DenseMatrix)
+                      and rows is None and sub_d[i] is None and xd.co_supported(mi._dev_c(), d)):
+                    # X_dense' d comes out of the syrk's A-side fragments (csrc/syrk_co.hip)
+                    res, colsum[i] = xd.dense_sandwich_co(mi._dev_c(), d, want_colsum=True)
+                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
                 else:
                     res = mi._sandwich_dev(d, rows, sub_d[i])
                     xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
@@ -862,7 +845,19 @@ class SplitMatrix(MatrixBase):
                 if empty[j] or (i, j) in done:
                     continue
                 with fan.lane():
-                    res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
+                    # sparse x dense: X_sparse' d rides along in the gather's stream loop
+                    si, di = (i, j) if isinstance(mi, SparseMatrix) else (j, i)
+                    if (colsum is not None and colsum[si] is None and isinstance(mats[si], SparseMatrix)
+                            and isinstance(mats[di], DenseMatrix)):
+                        box = []
+                        res = mats[si]._cross_sandwich_dev(mats[di], d, rows, sub_d[si], sub_d[di],
+                                                           colsum_box=box)
+                        if box:
+                            colsum[si] = box[0]
+                        if si != i:
+                            res = res.T
+                    else:
+                        res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
                     xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
         fan.join()
         return out

@@ -120,6 +120,13 @@ class StandardizedMatrix:
         if isinstance(mat, CategoricalMatrix):
             diag = mat._sandwich_diag_dev(d, rows_d, cols_d).to(torch.float64)
             return None, diag, diag           # one-hot entries are 0 / 1: C' d = diag(C' D C)
+        from .dense_matrix import DenseMatrix
+        from .ext import dense as xd
+
+        if (isinstance(mat, DenseMatrix) and rows_d is None and cols_d is None
+                and xd.co_supported(mat._dev_c(), d)):
+            inner, xtd = xd.dense_sandwich_co(mat._dev_c(), d, want_colsum=True)   # one pass
+            return inner, None, xtd
         inner = mat._sandwich_dev(d, rows_d, cols_d).to(torch.float64)
         xtd = mat._matvec_dev(d, rows_d, cols_d, None, True).to(torch.float64)
         return inner, None, xtd

@@ -8,7 +8,7 @@ import torch
 from scipy import sparse as sps
 
 import _cases as cs
-from _gpu_util import to_tm_split
+from _gpu_util import rel_err, to_tm_block, to_tm_split
 
 pytestmark = pytest.mark.gpu
 
@@ -162,3 +162,110 @@ def test_split_sandwich_yields_xtd_without_a_second_pass():
     full = mat.sandwich(d)
     # (LDS-atomic kernels sum in run-dependent order: equal up to rounding, not bitwise)
     assert float((inner - full).abs().max() / full.abs().max()) < 1e-13
+
+
+def _spy_xtd(mat, d):
+    """(inner, xtd, names of the C-ABI entry points called) of one _sandwich_xtd_dev."""
+    from tabmat_amd import _lib
+
+    import tabmat_amd.ext.categorical as xc
+    import tabmat_amd.ext.dense as xd
+    import tabmat_amd.ext.sparse as xs
+    import tabmat_amd.ext.split as xsp
+
+    seen = []
+    real_call = _lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return real_call(name, *a)
+
+    mods = [xc, xd, xs, xsp]
+    old = [m.call for m in mods]
+    for m in mods:
+        m.call = spy
+    try:
+        inner, xtd = mat._sandwich_xtd_dev(d, None, None)
+    finally:
+        for m, o in zip(mods, old):
+            m.call = o
+    return inner, xtd, seen
+
+
+@pytest.mark.parametrize("design", ["drop_first_everywhere", "no_categorical"])
+def test_xtd_in_one_pass_without_a_complete_categorical(design):
+    """X' d of the dense block comes out of the syrk's fragments
+    (tm_dense_sandwich_co_f64) and X' d of the sparse block out of the gather's stream loop
+    (tm_csr_dense_sandwich_lg_xtd_*): no transpose_matvec entry point runs even when no categorical
+    block is complete (reference: standardized_mat.py:149-150 makes a second pass)."""
+    import tabmat_amd as tm
+
+    n = 30_000
+    specs, idx = cs.mixed_specs(n, 96, 160, (9, 6), seed=4)
+    blocks = []
+    for sp in specs:
+        if sp[0] == "cat":
+            if design == "no_categorical":
+                continue
+            sp = (sp[0], sp[1], sp[2], True)          # drop_first on every categorical
+        blocks.append(to_tm_block(sp))
+    mat = tm.SplitMatrix(blocks)
+    assert not any(isinstance(m, tm.CategoricalMatrix) and not m.drop_first for m in mat.matrices)
+    d = torch.rand(n, dtype=torch.float64, device="cuda")
+    inner, xtd, seen = _spy_xtd(mat, d)
+    assert not any(s.startswith(("tm_dense_rmatvec", "tm_csr_rmatvec", "tm_dense_matvec",
+                                 "tm_csr_matvec")) for s in seen), seen
+    assert any(s == "tm_dense_sandwich_co_f64" for s in seen)
+    assert any(s.startswith("tm_csr_dense_sandwich_lg_xtd") for s in seen)
+    want = mat.transpose_matvec(d)
+    assert float((xtd - want).abs().max() / want.abs().max()) < 1e-12
+    full = mat.sandwich(d)
+    assert float((inner - full).abs().max() / full.abs().max()) < 1e-13
+    # and the standardized product built on it matches dense algebra
+    Xh = np.empty(mat.shape)
+    for m, ix in zip(mat.matrices, mat.indices):
+        Xh[:, ix] = m.toarray()
+    w = np.full(n, 1.0 / n)
+    std, means, stds = mat.standardize(w, True, True)
+    S = (Xh - means) / stds
+    dh = d.cpu().numpy()
+    got = std.sandwich(d).cpu().numpy()
+    want_s = (S.T * dh) @ S
+    assert np.abs(got - want_s).max() / np.abs(want_s).max() < 1e-10
+
+
+def test_k3_column_sums_vs_oracle():
+    """tm_csr_dense_sandwich_lg_xtd_*: both outputs against the oracle, f64 and f32, with overflow
+    entries (dense columns) and zero weights."""
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(9)
+    n, m, k = 9_001, 70, 128
+    dens = np.concatenate([np.full(60, 0.04), np.full(10, 0.3)])      # 10 columns overflow the round
+    mask = rng.random((n, m)) < dens
+    Sd = np.where(mask, rng.random((n, m)), 0.0)
+    B = rng.standard_normal((n, k))
+    d = rng.random(n)
+    d[::7] = 0.0
+    for dt, tol in ((np.float64, 1e-10), (np.float32, 2e-5)):
+        A = tm_sparse(Sd.astype(dt))
+        Bd = tm_dense(B.astype(dt))
+        lg = A._lg()
+        assert lg is not None
+        out, csum = xs.csr_dense_sandwich_lg(lg, Bd._dev_c(), torch.from_numpy(d.astype(dt)).cuda(),
+                                             want_colsum=True)
+        want = (Sd.T * d) @ B
+        assert rel_err(out.cpu().numpy(), want) < tol
+        assert rel_err(csum.cpu().numpy(), Sd.T @ d) < tol
+
+
+def tm_sparse(a):
+    import tabmat_amd as tm
+
+    return tm.SparseMatrix(sps.csc_matrix(a))
+
+
+def tm_dense(a):
+    import tabmat_amd as tm
+
+    return tm.DenseMatrix(a)

@@ -23,7 +23,7 @@ def _csr_cpu(S, dtype):
 def _decode(tw: SlabLg, itemsize):
     """(kernel column, row, value) triplets as the kernel reads them."""
     R, C, CH, SL = 64, 16, 4, 32
-    rowb = 1152 if itemsize == 8 else 512      # tm_lg_row_bytes: the padded LDS row stride (f64)
+    rowb = 1024 if itemsize == 8 else 512      # tm_lg_row_bytes: the LDS row stride
     G = tw.mk // C
     S = (tw.n + R - 1) // R
     vals, koff = tw.vals.numpy(), tw.koff.numpy().view(np.uint32)
