@@ -407,6 +407,23 @@ int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64
                                          const double *d, const double *M, int64_t M_ncol,
                                          const int32_t *rows, int64_t n_rows, double *out,
                                          void *stream);
+/* Row-list form of the fused categorical x sparse cross terms: cost proportional to n_sel (the
+ * reference works on self[rows], categorical_matrix.py:825-838).  cm_data / cm_indices: the
+ * chunk-major twin of tm_sparse_sandwich_chunked_*; row_ranges [n_chunks][n_sel][2] = {start, end} of
+ * every selected row in every 128-column chunk; rows [n_sel]: the selected ORIGINAL row ids (index
+ * the codes); d_sel [n_sel]: their weights.  out: stacked [sum(n_cols), m], overwritten. */
+int tm_multi_cat_sparse_sandwich_rows_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats,
+                                          const float *cm_data, const int32_t *cm_indices,
+                                          const int32_t *row_ranges, const int32_t *rows,
+                                          int64_t n_sel, int64_t m, const float *d_sel, float *out,
+                                          void *stream);
+int tm_multi_cat_sparse_sandwich_rows_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats,
+                                          const double *cm_data, const int32_t *cm_indices,
+                                          const int32_t *row_ranges, const int32_t *rows,
+                                          int64_t n_sel, int64_t m, const double *d_sel, double *out,
+                                          void *stream);
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

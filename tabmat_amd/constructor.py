@@ -3,8 +3,10 @@
 Mirrors the reference's `from_csc` / `from_df` / `from_pandas` (src/tabmat/constructor.py:29-212,
 297-308; constructor_util.py:11-49) — same parameters, thresholds, block order, column indices and
 names — so that `tabmat_amd.from_pandas(df)` is a drop-in for the object a GLM solver is handed.
-This is one-off host work; the blocks upload themselves to HBM on first use
-(`to_device()` forces it).  `from_formula` needs the third-party `formulaic` package and is out of
+`from_df` is one-off host work on a pandas frame; its blocks upload themselves to
+HBM on first use (`to_device()` forces it).  `from_csc` also takes storage that already lives in HBM
+(a device-resident SparseMatrix or raw CSC arrays on the device) and splits it there.
+`from_formula` needs the third-party `formulaic` package and is out of
 scope."""
 from __future__ import annotations
 
@@ -46,9 +48,88 @@ def _split_sparse_and_dense_parts(arg1: sps.csc_matrix, threshold: float = 0.1,
     return dense, sparse, dense_idx, sparse_idx
 
 
-def from_csc(mat: sps.csc_matrix, threshold=0.1, column_names=None, term_names=None):
-    """CSC matrix -> SplitMatrix([dense columns, sparse columns]) (constructor.py:297-308)."""
-    dense, sparse, dense_idx, sparse_idx = _split_sparse_and_dense_parts(mat, threshold)
+def _split_device_csr(csr, threshold: float, column_names=None, term_names=None):
+    """The same split for a block whose CSR twin already lives in HBM (CsrDev): the dense part
+    is written out as a row-major device array, the sparse part stays a CSR twin -- only the
+    per-column counts (m integers) visit the host, never the entries (SURVEY.md 8f-3;
+    constructor_util.py:11-49)."""
+    import torch
+
+    from .ext._types import CsrDev
+
+    if not 0 <= threshold <= 1:
+        raise ValueError("Threshold must be between 0 and 1.")
+    n, m = csr.n, csr.m
+    dev = csr.data.device
+    nnz = int(csr.data.numel())
+    cols64 = csr.indices.to(torch.int64)
+    col_cnt = torch.bincount(cols64, minlength=m) if nnz else torch.zeros(m, dtype=torch.int64, device=dev)
+    is_dense = (col_cnt.to(torch.float64) / max(n, 1)) > threshold
+    dense_idx = torch.nonzero(is_dense).ravel()
+    sparse_idx = torch.nonzero(~is_dense).ravel()
+    kd, ks = int(dense_idx.numel()), int(sparse_idx.numel())
+    new_id = torch.empty(m, dtype=torch.int64, device=dev)
+    new_id[dense_idx] = torch.arange(kd, device=dev)
+    new_id[sparse_idx] = torch.arange(ks, device=dev)
+    row_cnt = csr.indptr[1:] - csr.indptr[:-1]
+    rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), row_cnt)
+    to_dense = is_dense[cols64]
+    T = torch.zeros((n, kd), dtype=csr.data.dtype, device=dev)
+    if kd and nnz:
+        T[rows[to_dense], new_id[cols64[to_dense]]] = csr.data[to_dense]
+    keep = ~to_dense
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if nnz:
+        torch.cumsum(torch.bincount(rows[keep], minlength=n), dim=0, out=indptr[1:])
+    # (the column map is monotone on the kept columns: rows stay in canonical order)
+    sp = CsrDev(csr.data[keep].contiguous(), new_id[cols64[keep]].to(torch.int32).contiguous(), indptr, n, ks)
+    di, si = dense_idx.cpu().numpy(), sparse_idx.cpu().numpy()
+    cn = [None] * m if column_names is None else list(column_names)
+    tn = cn if term_names is None else list(term_names)
+    dense = DenseMatrix(T, column_names=[cn[i] for i in di], term_names=[tn[i] for i in di])
+    sparse = SparseMatrix.from_device(sp)
+    sparse._init_names([cn[i] for i in si], [tn[i] for i in si])
+    return dense, sparse, di, si
+
+
+def csc_arrays_to_csr_dev(data, indices, indptr, shape):
+    """CSC arrays (torch cuda tensors or numpy: values, row indices, column pointers) -> CsrDev in
+    HBM.  The entries must be canonical (rows ascending inside a column, no duplicates)."""
+    import torch
+
+    from . import _device as D
+    from .ext._types import CsrDev
+
+    n, m = int(shape[0]), int(shape[1])
+    data = D.to_dev(data)
+    rows = D.to_dev(indices).to(torch.int64)
+    ptr = D.to_dev(indptr).to(torch.int64)
+    dev = data.device
+    cols = torch.repeat_interleave(torch.arange(m, device=dev, dtype=torch.int32), ptr[1:] - ptr[:-1])
+    order = torch.sort(rows, stable=True).indices          # columns stay ascending inside a row
+    out_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if rows.numel():
+        torch.cumsum(torch.bincount(rows, minlength=n), dim=0, out=out_ptr[1:])
+    return CsrDev(data[order].contiguous(), cols[order].contiguous(), out_ptr, n, m)
+
+
+def from_csc(mat, threshold=0.1, column_names=None, term_names=None):
+    """CSC matrix -> SplitMatrix([dense columns, sparse columns]) (constructor.py:297-308).
+    `mat`: a scipy.sparse.csc_matrix (host ingest, blocks upload on first use), a SparseMatrix
+    whose storage already lives in HBM, or a tuple (data, indices, indptr, shape) of CSC arrays on
+    the device -- the last two are split ON the device, no entry visits the host."""
+    if isinstance(mat, tuple) and len(mat) == 4:
+        csr = csc_arrays_to_csr_dev(*mat)
+        dense, sparse, dense_idx, sparse_idx = _split_device_csr(csr, threshold, column_names, term_names)
+        return SplitMatrix([dense, sparse], [dense_idx, sparse_idx])
+    if isinstance(mat, SparseMatrix):
+        if mat._array is None and mat._devblk is not None:
+            dense, sparse, dense_idx, sparse_idx = _split_device_csr(
+                mat._dev(), threshold, column_names or mat._colnames, term_names or mat._terms)
+            return SplitMatrix([dense, sparse], [dense_idx, sparse_idx])
+        mat = mat._host()
+    dense, sparse, dense_idx, sparse_idx = _split_sparse_and_dense_parts(mat, threshold, column_names,
+                                                                         term_names)
     return SplitMatrix([dense, sparse], [dense_idx, sparse_idx])
 
 

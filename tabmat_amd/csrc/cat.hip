@@ -935,6 +935,63 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
         dst[b] = (F)tile[(b / group_cols) * tstr + (b % group_cols)];
 }
 
+// Row-list form of the fused categorical x sparse cross terms (the reference's cost for `rows=` is
+// proportional to len(rows): categorical_matrix.py:825-838 works on self[rows]): the selected rows'
+// entry lists come from the chunk-major twin through a {start, end} table [chunk][selected row]
+// (the table the row-list K2 uses), part = one 32-column group of a 128-column chunk, tile
+// [total levels][33] of doubles in LDS.  8 lanes per selected row walk its list in the group's
+// chunk and keep the entries of the group; codes and d are read once per row.
+template <typename F>
+__global__ __launch_bounds__(1024) void multi_cat_sparse_rows_kernel(
+    CatSet cs, const F *__restrict__ cm_data, const int32_t *__restrict__ cm_ind,
+    const int32_t *__restrict__ ranges, const int32_t *__restrict__ rows, const F *__restrict__ d_sel,
+    int64_t n_sel, int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
+    constexpr int GC = 32;                       // columns per group
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][GC + 1]
+    constexpr int tstr = GC + 1;
+    const int nel = cs.total * tstr;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
+    __syncthreads();
+    const int g = blockIdx.y;                    // 32-column group; chunk = g / 4
+    const int ch = g >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lr = lane >> 3, lt = lane & 7;
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t t1 = min(t0 + rows_per_block, n_sel);
+    const int32_t *rg = ranges + (int64_t)ch * n_sel * 2;
+    for (int64_t k0 = t0 + wave * 8; k0 < t1; k0 += (int64_t)nwave * 8) {
+        const int64_t k = k0 + lr;
+        if (k >= t1) continue;
+        const F dk = d_sel[k];
+        if (dk == F(0)) continue;                // rows with d == 0 contribute exactly nothing
+        const int e0 = rg[2 * k], e1 = rg[2 * k + 1];
+        if (e0 >= e1) continue;
+        const int64_t row = rows[k];
+        int off[MAX_CATS];
+#pragma unroll
+        for (int c = 0; c < MAX_CATS; ++c) {
+            off[c] = -1;
+            if (c < cs.n_cats) {
+                const int col = cs.codes[c][row] - cs.drop[c];
+                off[c] = col >= 0 ? (cs.off[c] + col) * tstr : -1;
+            }
+        }
+        for (int e = e0 + lt; e < e1; e += 8) {
+            const int col = cm_ind[e] - g * GC;
+            if (col < 0 || col >= GC) continue;
+            const lds_acc_t x = (lds_acc_t)(dk * cm_data[e]);
+#pragma unroll
+            for (int c = 0; c < MAX_CATS; ++c)
+                if (off[c] >= 0) atomic_add(&tile[off[c] + col], x);
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < cs.total * GC; b += blockDim.x)
+        dst[b] = (F)tile[(b / GC) * tstr + (b % GC)];
+}
+
 static int make_catset(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
                        int n_cats, CatSet *cs) {
     if (n_cats < 1 || n_cats > MAX_CATS) {
@@ -1085,6 +1142,12 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     TM_LAUNCH_CHECK();
     return TM_OK;
 }
+
+template <typename F>
+static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *h_ncols,
+                                     const int32_t *h_drop, int n_cats, const F *cm_data,
+                                     const int32_t *cm_ind, const int32_t *ranges, const int32_t *rows,
+                                     int64_t n_sel, int64_t m, const F *d_sel, F *out, hipStream_t st);
 
 template <typename F>
 static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_ncols,
@@ -1311,3 +1374,78 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
 }
 
 }  // extern "C"
+
+namespace tmh {
+template <typename F>
+static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *h_ncols,
+                                     const int32_t *h_drop, int n_cats, const F *cm_data,
+                                     const int32_t *cm_ind, const int32_t *ranges, const int32_t *rows,
+                                     int64_t n_sel, int64_t m, const F *d_sel, F *out, hipStream_t st) {
+    CatSet cs;
+    int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
+    if (rc) return rc;
+    const int64_t total = (int64_t)cs.total * m;
+    if (total == 0) return TM_OK;
+    if (n_sel == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    constexpr int GC = 32;
+    const size_t lds = ((sizeof(lds_acc_t) * (size_t)cs.total * (GC + 1) + 15) / 16) * 16;
+    if (lds > HIST_LDS_MAX) {
+        set_error("multi_cat_sparse_rows: %d stacked categories exceed the LDS tile", cs.total);
+        return TM_EUNSUPPORTED;
+    }
+    const int n_groups = (int)ceil_div(m, GC);
+    const int64_t stride = (int64_t)cs.total * GC;
+    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_groups);
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_sel, 2048)));
+    const int64_t rpb = ceil_div(n_sel, nblk);
+    nblk = ceil_div(n_sel, rpb);
+    const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_groups * stride) + 255) / 256) * 256;
+    void *wsv = nullptr;
+    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_groups * nblk * stride) + 256, &wsv, st);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    auto kern = &multi_cat_sparse_rows_kernel<F>;
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_groups), dim3(1024), lds, st, cs, cm_data,
+                       cm_ind, ranges, rows, d_sel, n_sel, rpb, ws, stride);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_groups, tmp, (int64_t)n_groups * stride, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((multi_cat_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                       st, tmp, (int64_t)cs.total, m, GC, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+}  // namespace tmh
+
+extern "C" {
+int tm_multi_cat_sparse_sandwich_rows_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats,
+                                          const float *cm_data, const int32_t *cm_indices,
+                                          const int32_t *row_ranges, const int32_t *rows,
+                                          int64_t n_sel, int64_t m, const float *d_sel, float *out,
+                                          void *stream) {
+    return tmh::run_multi_cat_sparse_rows<float>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+                                                 cm_indices, row_ranges, rows, n_sel, m, d_sel, out,
+                                                 tmh::as_stream(stream));
+}
+int tm_multi_cat_sparse_sandwich_rows_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats,
+                                          const double *cm_data, const int32_t *cm_indices,
+                                          const int32_t *row_ranges, const int32_t *rows,
+                                          int64_t n_sel, int64_t m, const double *d_sel, double *out,
+                                          void *stream) {
+    return tmh::run_multi_cat_sparse_rows<double>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+                                                  cm_indices, row_ranges, rows, n_sel, m, d_sel, out,
+                                                  tmh::as_stream(stream));
+}
+}  // extern "C"
+

@@ -59,6 +59,9 @@ int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *
 inline bool syrk_co_ok(const void *X, int64_t m) {
     return m > 0 && m <= 128 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
+// ... and pays: the kernel always works on the 36 tiles of a 128-column panel, so narrower blocks
+// stay with the syrk_kernel instantiations of 16 / 32 / 64 columns
+inline bool syrk_co_pays(int64_t m) { return m > 64; }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

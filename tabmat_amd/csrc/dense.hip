@@ -506,7 +506,8 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     if constexpr (sizeof(F) == 8) {
         // unrestricted C-ordered f64 block of <= 128 columns: the LDS-light kernel with fragment
         // prefetch and dynamic work items (syrk_co.hip; 3.2-3.4 ms against 3.6-3.7 ms at cfg4)
-        if (!order_f && rows == nullptr && cols == nullptr && syrk_co_ok(X, m) && tune("syrk_co", 1))
+        if (!order_f && rows == nullptr && cols == nullptr && syrk_co_ok(X, m) && syrk_co_pays(m) &&
+            tune("syrk_co", 1))
             return run_syrk_co(X, n, m, d, out, nullptr, st);
     }
     void *wsv = nullptr;

@@ -96,8 +96,12 @@ def dense_sandwich_co(X: DenseDev, d, want_colsum=False):
     return (out, cs) if want_colsum else out
 
 
-def co_supported(X: DenseDev, d) -> bool:
+def co_supported(X: DenseDev, d, any_width=False) -> bool:
+    """True when tm_dense_sandwich_co_f64 takes the block AND pays for it: the kernel always works on
+    a 128-column panel, so blocks of <= 64 columns stay with the narrow syrk instantiations (plus a
+    transpose_matvec where X'd is wanted) unless any_width is set."""
     import torch
 
     return (not X.order_f and X.buf.dtype == torch.float64 and d.dtype == torch.float64
-            and X.m <= 128 and X.m % 2 == 0 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0)
+            and X.m <= 128 and X.m % 2 == 0 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0
+            and (any_width or X.m > 64))

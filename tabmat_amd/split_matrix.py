@@ -49,6 +49,8 @@ N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
 # line (16.06 vs 16.05 ms).  Off by default; kept as the measurement harness for that result.
 OVERLAP = os.environ.get("TABMAT_AMD_OVERLAP", "0") == "1"
 OVERLAP_KNOBS = {"k2_waves": 12, "catdense_waves": 12, "catsparse_waves": 12}
+# row lists shorter than this share of n take the row-list form of the fused categorical x sparse term
+ROW_LIST_FRACTION_CATSPARSE = float(os.environ.get("TABMAT_AMD_ROW_LIST_CATSPARSE", "0.04"))
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
 DIAG_FROM_PAIRS = True
 # all small categorical x categorical tables + diagonals in one launch (tm_multi_cat_pairs_*)
@@ -510,6 +512,13 @@ class SplitMatrix(MatrixBase):
 
             oh, inv = self._onehot_slab(cat_ids)
             return xs.csr_dense_sandwich_slab(oh, mw._dev_c(), d_eff)[inv]
+        if (isinstance(mw, SparseMatrix) and total * 33 <= budget and rows is not None
+                and 0 < D.nlen(rows) <= ROW_LIST_FRACTION_CATSPARSE * self.shape[0]
+                and 0 < mw._dev().data.numel() < 2**31):
+            # short row list: only the selected rows' entries are read (the row kernel walks
+            # dependent loads per row: 0.35 ms at 10 % of 2M rows against 0.19 ms for the masked
+            # full pass, which it beats below ~5 %, profiles/r3_cols_rows.txt)
+            return xsplit.multi_cat_sparse_sandwich_rows(cats, d_rows, mw._dev(), rows)
         if (isinstance(mw, SparseMatrix) and total * 33 <= budget
                 and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
             return xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
@@ -622,6 +631,8 @@ class SplitMatrix(MatrixBase):
             indices = [np.arange(w_pad)] + [cat_off[i] + np.arange(mats[i].shape[1]) for i in cat]
             nar = dict(w=w, w_pad=w_pad, parts=parts, cat=cat, cat_sub=cat_sub, indices=indices,
                        sel=D.to_dev(sel), tmp=None, n_cols=n_cols)
+        elif noncat and w > NARROW_COLS and FULL_THEN_SELECT <= 1.0:
+            nar = "wide"
         self.__dict__["_narrow_cache"] = (key, nar)
         return nar
 
@@ -683,6 +694,20 @@ class SplitMatrix(MatrixBase):
             return self._sandwich_parts(parts, d, rows, cols_host, colsum)
         if cols_host is not None and plan is None and NARROW_COLS > 0:
             nar = self._narrow_plan(cols_host)
+            if nar == "wide":
+                # more selected dense + sparse columns than the dense-block form takes: the generic
+                # restricted kernels stream everything and cost the full product or more (3.35-3.7
+                # vs 3.5 ms at 2M rows, profiles/r3_cols_rows.txt) -- the tuned unrestricted
+                # product + selection is never slower, so the cost is monotone in the selection
+                cs_full = [None] * len(self.matrices) if colsum is not None else None
+                full = self._sandwich_dev(d, rows, None, None, cs_full)
+                if colsum is not None:
+                    _, sub_sel, _ = self._sandwich_plan(cols_host)
+                    for i, c in enumerate(cs_full):
+                        if c is not None:
+                            colsum[i] = c if sub_sel[i] is None else c[sub_sel[i].to(torch.int64)]
+                cd = self._cols_dev64(cols_host)
+                return full.index_select(0, cd).index_select(1, cd)
             if nar is not None and d.dtype == D.torch_dtype(self.dtype):
                 return self._sandwich_narrow(nar, d, rows, colsum)
         pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)

@@ -148,3 +148,42 @@ def test_excluded_rows_may_hold_inf_and_nan(frac):
     w = rng.standard_normal(n)
     gt = mat.transpose_matvec(w, rows)
     assert np.isfinite(gt).all() and rel_err(gt, ref.transpose_matvec(w, rows)) < 1e-10
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m", [31, 128, 300])
+@pytest.mark.parametrize("frac,kind", [(0.2, "sorted"), (0.03, "shuffled"), (0.1, "repeats")])
+def test_cat_sparse_row_list_kernel(frac, kind, m, dtype):
+    """tm_multi_cat_sparse_sandwich_rows_*: every categorical x sparse cross block over a short row
+    list (reference: categorical_matrix.py:825-838 on self[rows]) -- drop_first, missing codes,
+    zero weights, widths that do not fill a 32-column group."""
+    from oracle import oracle as orc
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import split as xsplit
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(m + int(frac * 1000))
+    n = 15_013
+    S = sps.random(n, m, density=0.07, format="csc", random_state=rng, dtype=np.float64)
+    S.data -= 0.4
+    S = S.astype(dtype)
+    d = rng.random(n).astype(dtype)
+    d[rng.integers(0, n, n // 8)] = 0
+    levels, drops = (13, 40, 5), (False, True, False)
+    codes = [rng.integers(0, L, n).astype(np.int32) for L in levels]
+    codes[2][rng.integers(0, n, n // 10)] = -1            # missing
+    rows = rng.choice(n, max(1, int(n * frac)), replace=False)
+    if kind == "sorted":
+        rows = np.sort(rows)
+    elif kind == "repeats":
+        rows = np.concatenate([rows, rows[: len(rows) // 4]])
+    cats = [(D.to_dev(c), L - int(dr), dr) for c, L, dr in zip(codes, levels, drops)]
+    sm = tm.SparseMatrix(S)
+    got = D.to_host(xsplit.multi_cat_sparse_sandwich_rows(cats, D.to_dev(d), sm._dev(), D.idx_dev(rows)))
+    uniq = np.unique(rows)                                 # a repeated row counts once (a row SET)
+    want = np.vstack([orc.sandwich_cat_sparse(c, L - int(dr), d.astype(np.float64), sps.csr_matrix(S).astype(np.float64),
+                                              uniq.astype(np.int32), None, None, dr)
+                      for c, L, dr in zip(codes, levels, drops)])
+    tol = 1e-10 if dtype == np.float64 else 3e-4
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() / max(np.abs(want).max(), 1e-300) < tol
