@@ -176,6 +176,29 @@ int tm_sparse_sandwich_chunked_f64(const double *cm_data, const int32_t *cm_indi
                                    const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                    const double *d, double *out, void *stream);
 
+/* The same product on a static BLOCK LIST (csrc/sparse_blocks.hip): every (row, tile) of the
+ * chunk-major twin is cut, once per matrix, into blocks of at most 8 x 8 entries -- block (a, b)
+ * pairs entries 8a .. 8a+7 of the row's list in chunk I with entries 8b .. 8b+7 of its list in chunk
+ * J (b <= a on diagonal tiles) -- so that rows with more than 8 entries in a chunk need no overhang
+ * phases in the kernel.  blocks: int32 [n_blocks][4] = {first A entry, first B entry, row,
+ * nA | nB << 8} (entry indices into cm_data / cm_indices), tile after tile in the order
+ * part = I (I + 1) / 2 + J.  Flag bits of the 4th word: 1 << 16 / 1 << 17 = the A / B side holds
+ * <= 4 entries next to a longer other side (lane t then takes entry t & 3 of it).  wg_tab: int32
+ * [n_wg][8], one record per workgroup = {part, slot, first block, end block, end of the FULL blocks,
+ * waves on the FULL list, first row, last row}: the host deals every tile's blocks to its workgroups
+ * in row order (slot = index of the workgroup inside its tile, < max_nb); inside a workgroup the
+ * FULL blocks (both sides > 4 entries: 8 DPP steps) come first, then the HALF ones (4 steps), and the
+ * workgroup's 16 waves are split between the two lists in proportion to their cost.
+ * n < 2^29, nnz < 2^31. */
+int tm_sparse_sandwich_blocks_f32(const float *cm_data, const int32_t *cm_indices, const int32_t *cptr,
+                                  int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                  const int32_t *wg_tab, int n_wg, int max_nb, const float *d, float *out,
+                                  void *stream);
+int tm_sparse_sandwich_blocks_f64(const double *cm_data, const int32_t *cm_indices, const int32_t *cptr,
+                                  int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                  const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
+                                  void *stream);
+
 /* out[nA x nB] = A[rows,A_cols]^T diag(d) B[rows,B_cols]; A sparse (CSR, n x m), B dense (n x r).
  * Replaces _csr_dense{C,F}_sandwich (ext/sparse_helpers-tmpl.cpp:23-146) as bound by
  * csr_dense_sandwich (ext/sparse.pyx:211-260). */

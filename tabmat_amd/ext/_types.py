@@ -99,6 +99,94 @@ class CsrDev:
             self._cm = cm
         return cm
 
+    def pair_blocks(self, n_wg: int = 256):
+        """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
+        tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
+        at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
+        tile (part = I (I + 1) / 2 + J); the blocks of a tile are dealt to its workgroups in row order
+        (workgroups in proportion to the block counts, ~n_wg in all); inside a workgroup the FULL
+        blocks (both sides > 4 entries: 8 DPP steps) come first, then the HALF ones (4 steps; flag
+        bits 16 / 17: the A / B side is the short one next to a long side, see csrc/sparse_blocks.hip).
+        wg_tab row: {part, slot, first block, end, end of the FULL blocks, waves on the FULL list,
+        first row, last row}.  Depends on the sparsity pattern only: built once, cached."""
+        pb = getattr(self, "_pb", None)
+        if pb is None:
+            _, _, cptr = self.chunk_major()
+            nch, n = int(cptr.shape[0]), self.n
+            dev = cptr.device
+            cnt = (cptr[:, 1:] - cptr[:, :-1]).to(torch.int64)            # entries per (chunk, row)
+            kb = torch.div(cnt + 7, 8, rounding_mode="floor")             # 8-entry pieces of a list
+            rows_all = torch.arange(n, device=dev, dtype=torch.int64)
+            per_row, counts = [], []
+            for I in range(nch):
+                for J in range(I + 1):
+                    nb_row = kb[I] * (kb[I] + 1) // 2 if I == J else kb[I] * kb[J]
+                    per_row.append(nb_row)
+                    counts.append(int(nb_row.sum().item()))
+            total_blocks = sum(counts)
+            if total_blocks >= 2**31:
+                raise ValueError("block list needs fewer than 2^31 blocks")
+            # every workgroup's entry range must stay below 2^31 bytes (32-bit byte offsets relative to
+            # the range's first entry)
+            nnz = int(self.data.numel())
+            min_nb = 1 + (nnz * 8) // (nch * 2**30)
+            # waves per list in proportion to the block counts: a HALF step issues fewer instructions
+            # than a FULL one (55 vs 88) but takes as long -- the kernel waits for its loads -- measured
+            # at 4M rows: 1.64 ms with equal weights, 1.89 ms with 49 : 88 (profiles/r3_k2_blocks.txt)
+            COST_FULL, COST_HALF, NW = 1.0, 1.0, 16
+            descs, tab, off, max_nb, part = [], [], 0, 1, -1
+            for I in range(nch):
+                for J in range(I + 1):
+                    part += 1
+                    c = counts[part]
+                    if c == 0:
+                        continue
+                    nb_row = per_row[part]
+                    row = torch.repeat_interleave(rows_all, nb_row)
+                    start = torch.cumsum(nb_row, 0) - nb_row
+                    idx = torch.arange(c, device=dev, dtype=torch.int64) - start[row]
+                    if I == J:                                            # (a, b), b <= a: idx = a (a + 1) / 2 + b
+                        a = torch.floor((torch.sqrt(8.0 * idx.to(torch.float64) + 1.0) - 1.0) * 0.5).to(torch.int64)
+                        a = torch.where((a + 1) * (a + 2) // 2 <= idx, a + 1, a)
+                        a = torch.where(a * (a + 1) // 2 > idx, a - 1, a)
+                        b = idx - a * (a + 1) // 2
+                    else:
+                        kj = kb[J][row]
+                        a = torch.div(idx, kj, rounding_mode="floor")
+                        b = idx - a * kj
+                    na = torch.clamp(cnt[I][row] - 8 * a, max=8)
+                    nb = torch.clamp(cnt[J][row] - 8 * b, max=8)
+                    full = (na > 4) & (nb > 4)
+                    flags = torch.where((na <= 4) & (nb > 4), 1 << 16, 0) | torch.where((na > 4) & (nb <= 4), 1 << 17, 0)
+                    desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
+                                        row, na | (nb << 8) | flags], dim=1).to(torch.int32)
+                    nb_p = max(min_nb, int(round(n_wg * c / max(total_blocks, 1))))
+                    nb_p = max(1, min(nb_p, -(-c // 256)))
+                    per = -(-c // nb_p)
+                    wg = torch.div(torch.arange(c, device=dev, dtype=torch.int64), per, rounding_mode="floor")
+                    key = wg * 2 + (~full).to(torch.int64)
+                    order = torch.sort(key, stable=True).indices          # row order kept inside a class
+                    cnts = torch.bincount(key, minlength=nb_p * 2).view(nb_p, 2).cpu().numpy()
+                    rows_h = row[torch.arange(0, c, per, device=dev)].cpu().numpy()
+                    rows_l = row[torch.clamp(torch.arange(per, c + per, per, device=dev) - 1, max=c - 1)].cpu().numpy()
+                    descs.append(desc[order])
+                    for sgl in range(nb_p):
+                        lo, hi = off + sgl * per, min(off + (sgl + 1) * per, off + c)
+                        if lo >= hi:
+                            continue
+                        nf, nh = int(cnts[sgl][0]), int(cnts[sgl][1])
+                        wf = NW if nh == 0 else 0 if nf == 0 else \
+                            min(NW - 1, max(1, int(round(NW * nf * COST_FULL / (nf * COST_FULL + nh * COST_HALF)))))
+                        tab.append((part, sgl, lo, hi, lo + nf, wf, int(rows_h[sgl]), int(rows_l[sgl])))
+                    max_nb = max(max_nb, nb_p)
+                    off += c
+                    del row, start, idx, a, b, na, nb, full, flags, desc, wg, key, order
+            blocks = torch.cat(descs).contiguous() if descs else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            del descs
+            wg_tab = torch.tensor(tab, dtype=torch.int32, device=dev).reshape(-1, 8).contiguous()
+            pb = self._pb = (blocks, wg_tab, max_nb)
+        return pb
+
     def csc_blocks(self):
         """(rows int32, vals, bstart int64, n_blocks, col_bptr int64): the CSC form of the block with
         every column's entries cut into blocks of at most tm_cat_det_block_rows() -- the input of

@@ -2,6 +2,8 @@
 a sparse block is kept on the device; see include/tabmat_hip.h."""
 from __future__ import annotations
 
+import os
+
 from .. import _device as D
 from .._lib import call
 from ._types import CsrDev, DenseDev, SlabCsc, SlabEll, SlabLg
@@ -204,6 +206,40 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     cm_data, cm_ind, cptr = A.chunk_major()
     call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr),
          A.n, A.m, int(cm_data.numel()), D.p(d), D.p(out), D.stream_ptr())
+    return out
+
+
+# the block-list form of the unrestricted sparse self sandwich (csrc/sparse_blocks.hip)
+K2_BLOCKS = os.environ.get("TABMAT_AMD_K2_BLOCKS", "1") != "0"
+
+
+def blocks_sandwich_pays(A: CsrDev) -> bool:
+    """The block list is built for the regime the 8-slot chunked kernel serves (more than ~4.5
+    nonzeros per row and 128-column chunk: rows regularly overflow 8 slots), when its 16 bytes per
+    block fit: ~1.4 blocks per (row, tile)."""
+    import torch
+
+    if not K2_BLOCKS or A.n == 0 or A.m == 0 or A.n >= 2**29:
+        return False
+    nnz = int(A.data.numel())
+    nch = -(-A.m // 128)
+    if not (0 < nnz < 2**31) or nnz / (A.n * nch) <= 4.5 or nch > 32:
+        return False
+    est = 16 * 2 * A.n * nch * (nch + 1) // 2          # bytes, generous
+    return est * 3 < torch.cuda.mem_get_info(A.data.device)[0] or getattr(A, "_pb", None) is not None
+
+
+def sparse_sandwich_blocks(A: CsrDev, d):
+    """ext/sparse.pyx:17-77, unrestricted, on the static block list (tm_sparse_sandwich_blocks_*)."""
+    if A.m == 0 or A.n == 0:
+        return D.zeros((A.m, A.m), A.dtype)
+    out = D.out_buf((A.m, A.m), A.dtype)
+    D.same_float("sparse_sandwich_blocks", A.data, d)
+    cm_data, cm_ind, cptr = A.chunk_major()
+    blocks, wg_tab, max_nb = A.pair_blocks()
+    call(f"tm_sparse_sandwich_blocks_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr), A.n, A.m,
+         int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
+         D.p(out), D.stream_ptr())
     return out
 
 

@@ -338,7 +338,10 @@ class SparseMatrix(MatrixBase):
                 r64 = rows.to(torch.int64)
                 dm[r64] = d[r64]
                 d = dm
-            res = xs.sparse_sandwich_chunked(A, d)
+            bl = getattr(self, "_blocks_pay", None)
+            if bl is None:
+                bl = self._blocks_pay = xs.blocks_sandwich_pays(A)
+            res = xs.sparse_sandwich_blocks(A, d) if bl else xs.sparse_sandwich_chunked(A, d)
             if cols is not None:
                 c64 = cols.to(torch.int64)
                 res = res[c64][:, c64].contiguous()

@@ -442,3 +442,59 @@ def test_tuning_knobs_round_trip():
     _lib.call("tm_tune_set", b"unit_test_knob", 12)
     _lib.call("tm_tune_get", b"unit_test_knob", 7, C.byref(v))
     assert v.value == 12
+
+
+@pytest.mark.parametrize("seed,m,dens", [(0, 128, 0.1), (1, 300, 0.12), (2, 513, 0.06), (3, 40, 0.9)])
+def test_pair_block_list_covers_every_pair_once(seed, m, dens):
+    """CsrDev.pair_blocks (the static block list of tm_sparse_sandwich_blocks_*): replaying the list
+    with the kernel's rules (8 x 8 blocks, b <= a triangle on diagonal tiles by COLUMN order, mirror)
+    must give A' diag(d) A exactly once per pair -- rows with more than 8 and more than 16 entries
+    in a 128-column chunk included."""
+    from tabmat_amd.ext._types import CsrDev
+
+    rng = np.random.default_rng(seed)
+    n = 257
+    A = sps.random(n, m, density=dens, format="csr", random_state=rng, dtype=np.float64)
+    A.sort_indices()
+    csr = CsrDev(torch.from_numpy(A.data.copy()), torch.from_numpy(A.indices.astype(np.int32)),
+                 torch.from_numpy(A.indptr.astype(np.int64)), n, m)
+    cm_data, cm_ind, cptr = csr.chunk_major()
+    blocks, wg_tab, max_nb = csr.pair_blocks(n_wg=24)
+    cm_data, cm_ind, blocks, wg_tab = cm_data.numpy(), cm_ind.numpy(), blocks.numpy(), wg_tab.numpy()
+    assert (cptr.numpy()[:, 1:] - cptr.numpy()[:, :-1]).max() > 8
+    d = rng.random(n)
+    nch = -(-m // 128)
+    out = np.zeros((nch * 128, nch * 128))
+    covered = np.zeros(len(blocks), dtype=int)
+    slots = {}
+    for part, slot, lo, hi, full_end, wfull, row_first, row_last in wg_tab:
+        assert slot < max_nb and (part, slot) not in slots
+        slots[(part, slot)] = 1
+        I = int((np.sqrt(8 * part + 1) - 1) / 2)
+        J = part - I * (I + 1) // 2
+        assert lo <= full_end <= hi and 0 <= wfull <= 16
+        assert (wfull == 16) == (full_end == hi) and (wfull == 0) == (full_end == lo)
+        for k in range(lo, hi):
+            covered[k] += 1
+            pa, pb, row, meta = blocks[k]
+            na, nb = meta & 255, (meta >> 8) & 255
+            rep_a, rep_b = bool(meta & (1 << 16)), bool(meta & (1 << 17))
+            assert 1 <= na <= 8 and 1 <= nb <= 8 and row_first <= row <= row_last
+            assert (k < full_end) == (na > 4 and nb > 4)
+            assert rep_a == (na <= 4 < nb) and rep_b == (nb <= 4 < na)
+            steps = 8 if k < full_end else 4
+            for t in range(8):                      # the kernel's lanes and DPP steps
+                ta, tb = (t & 3 if rep_a else t), (t & 3 if rep_b else t)
+                for s_ in range(steps):
+                    u = t ^ s_                       # lane whose B entry arrives
+                    ub = (u & 3) if rep_b else u
+                    if ta < na and ub < nb:
+                        ca, cb = cm_ind[pa + ta], cm_ind[pb + ub]
+                        assert ca // 128 == I and cb // 128 == J
+                        if I != J or cb <= ca:
+                            out[ca, cb] += d[row] * cm_data[pa + ta] * cm_data[pb + ub]
+    assert (covered == 1).all()
+    out = out[:m, :m]
+    full = np.tril(out) + np.tril(out, -1).T
+    want = (A.T.multiply(d)).dot(A).toarray()
+    assert np.abs(full - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
