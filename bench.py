@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (AMD datasheet; not in the guide's table)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 (MI355X_MICROARCH.md; 2:1-sparsity figures are never used)
 
 
 def _baseline_metric():
@@ -485,6 +486,15 @@ def main():
         dom_flops = op_flops(mat, dom)
         hbm_time = dom_bytes / (HBM_PEAK_GBS * 1e9)
         peak_tf = MFMA_F64_PEAK_TFLOPS if tdt == torch.float64 else MFMA_F32_PEAK_TFLOPS
+        mfma_note = None
+        if (dom_flops and tdt == torch.float32 and isinstance(mat, tm.DenseMatrix) and 128 < p <= 256
+                and p % 4 == 0):
+            # the f32 syrk of 129..256 columns runs as SIX bf16 piece products on the bf16 matrix cores
+            # (csrc/syrk_bf16.hip): priced against the dense bf16 peak with the flops it really issues
+            dom_flops *= 6.0
+            peak_tf = MFMA_BF16_PEAK_TFLOPS
+            mfma_note = ("f32 syrk as 6 bf16 piece products (3-piece split, f32 accumulation): achieved = "
+                         "6 x n k (k + 1) bf16 flop / kernel time, peak = dense bf16 MFMA")
         mfma_time = (dom_flops / (peak_tf * 1e12)) if dom_flops else 0.0
         if mfma_time > hbm_time:
             roof = {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 3),
@@ -503,7 +513,9 @@ def main():
         for name, ms in bd.items():
             fl = op_flops(mat, name)
             if fl:
-                mfma_frac = round(fl / (ms * 1e-3) / (peak_tf * 1e12), 4)
+                mfma_frac = round(fl * (6.0 if mfma_note else 1.0) / (ms * 1e-3) / (peak_tf * 1e12), 4)
+        if mfma_note:
+            roof["note"] = mfma_note
         roof["kernel"] = dom
         roof["kernel_ms"] = round(dom_ms, 4)
         roof["algorithmic_bytes_per_launch"] = int(dom_bytes)
@@ -540,7 +552,7 @@ def main():
             "hbm_frac_whole_job": round(alg_bytes / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             # whole step against max(HBM, MFMA): bytes / 8 TB/s vs flops / dense matrix peak of the dtype
             "mixed_roofline_ms": round(max(alg_bytes / world / (HBM_PEAK_GBS * 1e9),
-                                           flops / world / (peak_tf * 1e12)) * 1e3, 4),
+                                           flops * (6.0 if mfma_note else 1.0) / world / (peak_tf * 1e12)) * 1e3, 4),
             "mfma_frac_of_spec": mfma_frac,
             "sum_kernel_ms": round(sum(bd.values()), 4),
         }

@@ -117,6 +117,16 @@ int tm_dense_sandwich_f64(const double *X, int64_t n, int64_t m, int order_f, co
 int tm_dense_sandwich_co_f64(const double *X, int64_t n, int64_t m, const double *d, double *out,
                              double *colsum, void *stream);
 
+/* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered FLOAT32 block of m = 4 k <= 256 columns
+ * on the bf16 matrix cores: every element of diag(sqrt|d|) X is split into three bf16 pieces (24
+ * mantissa bits) and the six leading piece products are accumulated in f32 with
+ * v_mfma_f32_16x16x32_bf16 -- the accuracy of an f32 product accumulated in f32, at 16x the rate of
+ * the f32-input MFMA (which runs at the f32 vector rate on gfx950).  Negative weights flip the bf16
+ * sign bits of the A operand.  Replaces _denseC_sandwich<int, float> (ext/dense_helpers-tmpl.cpp:
+ * 266-311) for BASELINE configs[1] (10M x 256).  out (m, m) is overwritten. */
+int tm_dense_sandwich_bf16x3_f32(const float *X, int64_t n, int64_t m, const float *d, float *out,
+                                 void *stream);
+
 /* out[Ci] += sum_{Cj} X[rows[Ci], cols[Cj]] * v[cols[Cj]]   (v has length m).
  * Replaces _dense{C,F}_matvec (ext/dense_helpers-tmpl.cpp:385-417; ext/dense.pyx:76-101) and,
  * with rows == cols == NULL, the BLAS gemv of dense_matrix.py:212-217. */

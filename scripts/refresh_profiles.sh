@@ -4,7 +4,7 @@
 #   bench JSON lines for cfg4 / cfg2 / cfg3 (with in-run roofline.traffic), the rocprofv3 kernel
 #   stats of the cfg4 command, SQ counters of the three big kernels and their FETCH / WRITE sizes.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r2}
+TAG=${1:-r3}
 O=$R/gpurun_out/${TAG}_profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -63,6 +63,13 @@ inline bool syrk_co_ok(const void *X, int64_t m) {
 // stay with the syrk_kernel instantiations of 16 / 32 / 64 columns
 inline bool syrk_co_pays(int64_t m) { return m > 64; }
 
+// K1d (syrk_bf16.hip): X' diag(d) X of an unrestricted C-ordered f32 block of 4 k <= 256 columns on the
+// bf16 matrix cores (three-piece split, f32 accumulation); it pays above 128 columns.
+int run_syrk_bf16x3(const float *X, int64_t n, int64_t m, const float *d, float *out, hipStream_t st);
+inline bool syrk_bf16x3_ok(const void *X, int64_t m) {
+    return m > 0 && m <= 256 && m % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

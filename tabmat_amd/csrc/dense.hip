@@ -510,6 +510,13 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
             tune("syrk_co", 1))
             return run_syrk_co(X, n, m, d, out, nullptr, st);
     }
+    if constexpr (sizeof(F) == 4) {
+        // unrestricted C-ordered f32 block of 129 .. 256 columns: three-piece bf16 split on the bf16
+        // matrix cores (syrk_bf16.hip; 16x the rate of the f32-input MFMA, f32 accuracy)
+        if (!order_f && rows == nullptr && cols == nullptr && m > 128 && syrk_bf16x3_ok(X, m) &&
+            tune("syrk_bf16", 1))
+            return run_syrk_bf16x3(X, n, m, d, out, st);
+    }
     void *wsv = nullptr;
     const int direct_max = sizeof(F) == 4 ? 256 : 128;
     if (n_cols <= direct_max) {

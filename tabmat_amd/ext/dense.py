@@ -105,3 +105,15 @@ def co_supported(X: DenseDev, d, any_width=False) -> bool:
     return (not X.order_f and X.buf.dtype == torch.float64 and d.dtype == torch.float64
             and X.m <= 128 and X.m % 2 == 0 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0
             and (any_width or X.m > 64))
+
+
+def dense_sandwich_bf16x3(X: DenseDev, d):
+    """X' diag(d) X of an unrestricted C-ordered float32 block of 4 k <= 256 columns on the bf16
+    matrix cores (tm_dense_sandwich_bf16x3_f32: three-piece bf16 split, f32 accumulation)."""
+    import torch
+
+    assert not X.order_f and X.buf.dtype == torch.float32 and X.m % 4 == 0 and X.m <= 256
+    out = D.out_buf((X.m, X.m), torch.float32)
+    D.same_float("dense_sandwich_bf16x3", X.buf, d)
+    call("tm_dense_sandwich_bf16x3_f32", D.p(X.buf), X.n, X.m, D.p(d), D.p(out), D.stream_ptr())
+    return out
