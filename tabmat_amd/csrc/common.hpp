@@ -48,6 +48,7 @@ int get_workspace(size_t bytes, void **ptr, hipStream_t st);
 // kernel's duration without a profiler attached.
 void prof_begin(hipStream_t st);
 void prof_end(hipStream_t st);
+void prof_hold(bool on);      // keep the recorded pair on the current kernel while a nested op launches
 
 // integer tuning knob set with tm_tune_set (default when unset)
 int64_t tune(const char *key, int64_t dflt);

@@ -92,9 +92,12 @@ int get_workspace(size_t bytes, void **ptr, hipStream_t st) {
 static bool g_prof_on = false;
 static hipEvent_t g_prof_a = nullptr, g_prof_b = nullptr;
 static bool g_prof_valid = false;
+static bool g_prof_hold = false;     // prof_hold(true): the next prof_begin / prof_end pairs are ignored
+
+void prof_hold(bool on) { g_prof_hold = on; }
 
 void prof_begin(hipStream_t st) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || g_prof_hold) return;
     if (!g_prof_a) {
         (void)hipEventCreate(&g_prof_a);
         (void)hipEventCreate(&g_prof_b);
@@ -103,7 +106,7 @@ void prof_begin(hipStream_t st) {
 }
 
 void prof_end(hipStream_t st) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || g_prof_hold) return;
     (void)hipEventRecord(g_prof_b, st);
     g_prof_valid = true;
 }

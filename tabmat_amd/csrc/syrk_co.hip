@@ -67,7 +67,11 @@ __device__ __forceinline__ void co_mfma_set(const double (&xa)[8], const double 
 __global__ __launch_bounds__(CO_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_cols,
                     const double *__restrict__ d, int n_items, unsigned *__restrict__ counter,
-                    double *__restrict__ part, double *__restrict__ cpart, WgLogBuf *__restrict__ log) {
+                    double *__restrict__ part, double *__restrict__ cpart, WgLogBuf *__restrict__ log,
+                    const unsigned *__restrict__ only_if) {
+    // (only_if: the int8 syrk's hand-over -- this launch does the work only when the weights were
+    // screened OUT of the int8 kernel's envelope, syrk_i8.hip)
+    if (only_if != nullptr && *only_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);          // [2][CO_RS][CO_LDW]
     double *dl = lds + 2 * CO_CHUNK;                             // [2][CO_RS]
@@ -218,7 +222,9 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
 // block (64 elements), thread (e, s) sums partials s, s + 16, ...
 __global__ __launch_bounds__(1024) void syrk_co_finish_kernel(const double *__restrict__ part,
                                                               int nblk, int n_cols,
-                                                              double *__restrict__ out, int64_t ldo) {
+                                                              double *__restrict__ out, int64_t ldo,
+                                                              const unsigned *__restrict__ only_if) {
+    if (only_if != nullptr && *only_if == 0) return;
     __shared__ double red[16][64];
     const int e = blockIdx.y * 64 + threadIdx.x, s = threadIdx.y, t = blockIdx.x;
     double a = 0.0;
@@ -253,8 +259,14 @@ __global__ __launch_bounds__(CO_W) void syrk_co_colsum_kernel(const double *__re
     if (c < n_cols) colsum[c] = a;
 }
 
-int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out,
-                       double *colsum, hipStream_t st) {
+// bytes of workspace a call needs (grid-dependent upper bound)
+size_t syrk_co_ws_bytes() {
+    const size_t grid = (size_t)std::max<int64_t>(1, tune("co_grid", 3 * NUM_CU));
+    return 256 + sizeof(double) * grid * (CO_T * 256 + CO_W);
+}
+
+static int run_syrk_co_impl(const double *X, int64_t n, int64_t m, const double *d, double *out,
+                            double *colsum, const unsigned *only_if, void *ws_given, hipStream_t st) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m),
                "the co-resident syrk takes a 16-byte aligned C-ordered block of an even number of "
@@ -271,9 +283,11 @@ int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *
     const int grid = (int)std::min<int64_t>(n_items, tune("co_grid", 3 * NUM_CU));
     const size_t part_bytes = sizeof(double) * (size_t)grid * CO_T * 256;
     const size_t cpart_bytes = sizeof(double) * (size_t)grid * CO_W;
-    void *wsv = nullptr;
-    int rc = get_workspace(256 + part_bytes + cpart_bytes, &wsv, st);
-    if (rc) return rc;
+    void *wsv = ws_given;          // (a caller that keeps live data in the stream's workspace passes its own region)
+    if (wsv == nullptr) {
+        int rc = get_workspace(256 + part_bytes + cpart_bytes, &wsv, st);
+        if (rc) return rc;
+    }
     unsigned *counter = reinterpret_cast<unsigned *>(wsv);
     double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(wsv) + 256);
     double *cpart = part + (size_t)grid * CO_T * 256;
@@ -282,11 +296,11 @@ int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS));
     prof_begin(st);
     hipLaunchKernelGGL(syrk_co_kernel, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, m,
-                       (int)m, d, n_items, counter, part, cpart, wg_log_ptr());
+                       (int)m, d, n_items, counter, part, cpart, wg_log_ptr(), only_if);
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_co_finish_kernel, dim3(CO_T, 4), dim3(64, 16), 0, st, part, grid, (int)m,
-                       out, m);
+                       out, m, only_if);
     TM_LAUNCH_CHECK();
     if (colsum) {
         hipLaunchKernelGGL(syrk_co_colsum_kernel, dim3(1), dim3(CO_W), 0, st, cpart, grid, (int)m,
@@ -294,6 +308,17 @@ int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *
         TM_LAUNCH_CHECK();
     }
     return TM_OK;
+}
+
+int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
+                hipStream_t st) {
+    return run_syrk_co_impl(X, n, m, d, out, colsum, nullptr, nullptr, st);
+}
+
+// the same launches, live only when *flag != 0 (device memory): the int8 syrk's fallback
+int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, const unsigned *flag,
+                        void *ws, hipStream_t st) {
+    return run_syrk_co_impl(X, n, m, d, out, nullptr, flag, ws, st);
 }
 
 }  // namespace tmh

@@ -1,0 +1,586 @@
+// K1e  Dense self sandwich  out = X' diag(d) X  for a C-ordered FLOAT64 block of <= 128 columns on the
+// INT8 matrix cores (reference: ext/dense_helpers-tmpl.cpp:266-311; the dense term of BASELINE
+// configs[3], split_matrix.py:337-354).
+//
+// v_mfma_f64_16x16x4_f64 runs at the vector f64 rate on gfx950 and sustains 0.6 of it: the f64 syrk
+// (syrk_co.hip) needs 3.3 ms for 10M x 128 while the block streams in 1.3 ms and the int8 matrix
+// cores (3.9 POPS measured) sit idle.  Ozaki-style slicing moves the product there EXACTLY:
+//   * Y = diag(sqrt d) X is written in 48-bit fixed point per column,
+//         F[r][i] = round(Y[r][i] * 2^k_i),   |F| <= 2^45,   2^k_i = 2^45 / 2^ceil(log2(colmax_i sqrt(dmax)))
+//     by ONE v_fma_f64 with a magic constant (1.5 * 2^52 + 0x808080808080): the low 48 mantissa bits
+//     of the result are F + bias, whose six bytes g_0 .. g_5 are the balanced base-256 digits
+//     b_s = g_s - 128 in [-128, 127] (two's complement byte: g_s ^ 0x80),  F = sum_s b_s 256^s;
+//   * S_ij = 2^-(k_i + k_j) sum_r F_ri F_rj = 2^-(k_i + k_j) sum_{s,t} 256^(s + t) sum_r b_s[r][i] b_t[r][j]:
+//     every digit pair is an int8 GEMM (v_mfma_i32_16x16x64_i8, exact in int32 over <= 2048 rows); the
+//     pairs of one weight class s + t share an accumulator; the classes s + t >= 5 are kept (21 pairs,
+//     6 accumulators per tile) -- the dropped ones weigh <= 2^-46 of the largest product;
+//   * after every work item of 2048 rows the six int32 classes of a tile are folded into the
+//     workgroup's f64 partial (sum_c 256^c C_c, exact in f64 up to the final roundings).
+// Error: |F - Y 2^k| <= 1/2, i.e. 2^-46 of the column's largest scaled entry -- for columns whose
+// largest entry is within 2^10 of their rms (checked once per block on the host) every product is
+// good to ~1e-11 relative and the sums far better; measured against the oracle in
+// tests/test_gpu_syrk_i8.py.  Blocks or weights outside that envelope (non-finite values, negative
+// or non-finite weights, heavy-tailed columns) take the f64 kernel: the weights are screened by a
+// reduction kernel on the device (no host synchronisation) and both kernels are launched -- the one
+// the flag does not select returns at once.
+//
+// Layout (4 waves, ONE per SIMD: 256 VGPRs of digit fragments + 216 AGPRs of int32 accumulators):
+// raw f64 rows come in by LDS-DMA in half chunks of 32 rows into a ring of two buffers; a chunk is 64
+// rows (K of the MFMA); lane (16 columns x 4 row quads per wave instruction) converts 4 rows of a
+// column at a time, transposes the 4 x 6 digit bytes with v_perm_b32 and writes six 4-byte words into
+// the digit planes [digit][column][64 rows]; all 48 fragments (8 column blocks x 6 digits) of a chunk
+// are read into registers between two barriers, then the planes are rewritten for the next chunk
+// while the 189 MFMAs of the wave's 9 tiles run from registers.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace tmh {
+
+constexpr int I8_W = 128;                       // padded columns
+constexpr int I8_T = 36;                        // lower-triangular 16 x 16 tiles
+constexpr int I8_ND = 6;                        // digits
+constexpr int I8_NC = 6;                        // weight classes kept: s + t = 5 .. 10
+constexpr int I8_RS = 64;                       // rows per chunk = K of the MFMA
+constexpr int I8_HS = 32;                       // rows per half chunk (one DMA ring slot)
+constexpr int I8_WAVES = 4;
+constexpr int I8_THREADS = I8_WAVES * 64;
+constexpr int I8_PSTR = 80;                     // bytes per column of a digit plane (64 rows + 16)
+constexpr int I8_PLANE = I8_W * I8_PSTR;
+constexpr int I8_PLANES = I8_ND * I8_PLANE;     // 61 440 B
+constexpr int I8_RAWSTR = 1024 + 32;            // bytes per raw f64 row in LDS
+constexpr int I8_RAWBUF = I8_HS * I8_RAWSTR;    // one half chunk: 33 792 B
+constexpr int I8_CPI = 32;                      // chunks per work item (2048 rows: int32 stays exact)
+constexpr int I8_ITEM_ROWS = I8_CPI * I8_RS;
+constexpr size_t I8_LDS = (size_t)I8_PLANES + 3 * (size_t)I8_RAWBUF + 3 * I8_HS * sizeof(double) + 16;
+static_assert(I8_LDS <= 160 * 1024, "planes + the ring of 3 half chunks fill the CU's LDS");
+
+typedef int i8_v4 __attribute__((ext_vector_type(4)));
+
+struct I8Info {                 // written by the prep kernels, read by the main / finish kernels
+    unsigned dmax_bits_hi;      // max |d| as the high word of its double (monotone for d >= 0)
+    unsigned dmax_bits_lo;
+    unsigned flag;              // != 0: take the f64 kernel (negative / non-finite weight)
+    unsigned pad;
+};
+
+// the 21 digit pairs (s, t) with s + t = 5 .. 10, class by class
+constexpr int i8_pair_s(int idx) {
+    int k = 0;
+    for (int w = 5; w <= 10; ++w)
+        for (int s = 0; s < 6; ++s) {
+            const int t = w - s;
+            if (t < 0 || t >= 6) continue;
+            if (k == idx) return s;
+            ++k;
+        }
+    return 0;
+}
+constexpr int i8_pair_t(int idx) {
+    int k = 0;
+    for (int w = 5; w <= 10; ++w)
+        for (int s = 0; s < 6; ++s) {
+            const int t = w - s;
+            if (t < 0 || t >= 6) continue;
+            if (k == idx) return t;
+            ++k;
+        }
+    return 0;
+}
+
+// The 36 tiles (bi, bj <= bi) of the 8 column blocks, 9 per wave, dealt so that a wave needs the digit
+// fragments of only FIVE blocks (120 registers; all 8 blocks x 6 digits = 192 do not fit next to the
+// 216 accumulators and the conversion -- and a single spill reload inside the chunk loop is a
+// scratch load, whose s_waitcnt vmcnt(0) also waits for every LDS-DMA copy in flight):
+//   wave 0, blocks {0,1,2,3,4}: (1,0) (2,0) (3,0) (4,0) (2,1) (3,1) (4,1) (3,2) (4,2)
+//   wave 1, blocks {0,1,5,6,7}: (5,0) (6,0) (7,0) (5,1) (6,1) (7,1) (6,5) (0,0) (1,1)
+//   wave 2, blocks {2,3,5,6,7}: (5,2) (6,2) (7,2) (5,3) (6,3) (7,3) (7,5) (2,2) (3,3)
+//   wave 3, blocks {3,4,5,6,7}: (5,4) (6,4) (7,4) (4,3) (7,6) (4,4) (5,5) (6,6) (7,7)
+template <int WID>
+struct I8Tiles {
+    static constexpr int NB = 5;
+    static constexpr int block(int l) {
+        constexpr int B[4][5] = {{0, 1, 2, 3, 4}, {0, 1, 5, 6, 7}, {2, 3, 5, 6, 7}, {3, 4, 5, 6, 7}};
+        return B[WID][l];
+    }
+    static constexpr int local(int b) {
+        for (int l = 0; l < NB; ++l)
+            if (block(l) == b) return l;
+        return 0;
+    }
+    static constexpr int bi(int q) {
+        constexpr int T[4][9] = {{1, 2, 3, 4, 2, 3, 4, 3, 4}, {5, 6, 7, 5, 6, 7, 6, 0, 1},
+                                 {5, 6, 7, 5, 6, 7, 7, 2, 3}, {5, 6, 7, 4, 7, 4, 5, 6, 7}};
+        return T[WID][q];
+    }
+    static constexpr int bj(int q) {
+        constexpr int T[4][9] = {{0, 0, 0, 0, 1, 1, 1, 2, 2}, {0, 0, 0, 1, 1, 1, 5, 0, 1},
+                                 {2, 2, 2, 3, 3, 3, 5, 2, 3}, {4, 4, 4, 3, 6, 4, 5, 6, 7}};
+        return T[WID][q];
+    }
+    static constexpr int tile(int q) { return bi(q) * (bi(q) + 1) / 2 + bj(q); }
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t i8_rsrc_t;
+__device__ __forceinline__ i8_rsrc_t i8_rsrc(const void *base, int64_t bytes) {
+    const unsigned nb = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ void i8_dma16(i8_rsrc_t rs, void *lds, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void i8_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned i8_perm(unsigned hi, unsigned lo, unsigned sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+#else
+struct i8_rsrc_t {};
+inline i8_rsrc_t i8_rsrc(const void *, int64_t) { return {}; }
+inline void i8_dma16(i8_rsrc_t, void *, int) {}
+inline void i8_lds_barrier() {}
+inline unsigned i8_perm(unsigned, unsigned, unsigned) { return 0; }
+#endif
+
+// ---- screening of the weights: max |d| and "any weight negative or non-finite"
+__global__ __launch_bounds__(256) void i8_screen_kernel(const double *__restrict__ d, int64_t n, I8Info *info) {
+    double mx = 0.0;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = d[i];
+        bad |= !(v >= 0.0) || !(v <= 1.7e308);          // negative, NaN or inf
+        mx = fmax(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmax(mx, __shfl_down(mx, off, 64));
+        bad |= (bool)__shfl_down((int)bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicOr(&info->flag, 1u);
+        // max of non-negative doubles = max of their bit patterns
+        atomicMax(reinterpret_cast<unsigned long long *>(info), (unsigned long long)__double_as_longlong(mx > 0.0 ? mx : 0.0));
+    }
+}
+
+// sigma[i] = 2^k_i (the fixed-point scale of column i), rscale[i] = 2^-k_i
+__global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, const I8Info *info,
+                                double *__restrict__ sigma, double *__restrict__ rscale) {
+    const int i = threadIdx.x;
+    if (i >= I8_W) return;
+    const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
+    double s = 1.0, r = 1.0;
+    if (i < m) {
+        const double big = colmax[i] * sqrt(dmax);
+        if (big > 0.0 && info->flag == 0) {
+            int e;
+            frexp(big, &e);                      // big = f * 2^e, f in [0.5, 1): big <= 2^e
+            s = ldexp(1.0, 45 - e);
+            r = ldexp(1.0, e - 45);
+        }
+    }
+    sigma[i] = s;
+    rscale[i] = r;
+}
+
+// ---- the main kernel
+__global__ __launch_bounds__(I8_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const double *__restrict__ d,
+                    const double *__restrict__ sigma, const I8Info *__restrict__ info, int n_items,
+                    unsigned *__restrict__ counter, double *__restrict__ part) {
+    if (info->flag != 0) return;                                          // the f64 kernel takes this call
+    // SEPARATE static LDS objects: the compiler tracks LDS-DMA copies per LDS variable (alias scopes of
+    // the module-LDS lowering) and makes every LDS access that may alias a copy in flight wait for it
+    // (s_waitcnt vmcnt(0)) -- carved out of one dynamic buffer, the fragment reads waited for the copies
+    // issued a moment earlier and nothing was asynchronous.  The raw ring is read back with inline-asm
+    // ds_read (invisible to that tracking: the slot being read is never the one being filled; the
+    // hand-over is the explicit vmcnt wait + barrier below).
+    __shared__ __attribute__((aligned(16))) unsigned char planes[I8_PLANES];      // [6][128][I8_PSTR]: ONE chunk
+    __shared__ __attribute__((aligned(16))) unsigned char raw[3 * I8_RAWBUF];     // ring of 3 half chunks: [32 rows][I8_RAWSTR] f64
+    __shared__ double dl[3 * I8_HS];                                              // sqrt(d) of the ring slots
+    __shared__ unsigned slot_mem[4];
+    unsigned *slot = slot_mem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // conversion role: wave w owns columns 32 w .. 32 w + 31; lane = (column in block of 16, row quad)
+    const int cl = lane & 15, rq = lane >> 4;
+
+    // ---- the workgroup's stream of HALF chunks: items of I8_CPI chunks from the atomic counter
+    unsigned idL = blockIdx.x;            // item of the next half to request
+    int hL = 0;                           // its half offset inside the item (0 .. 2 CPI - 1)
+    unsigned idNext;
+    if (tid == 0) *slot = gridDim.x + atomicAdd(counter, 1u);
+    __syncthreads();
+    idNext = __builtin_amdgcn_readfirstlane(*slot);
+    bool pending = false;
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    double dreg = 0.0;
+    const int dma_voff = lane * 2 < m ? lane * 16 : 0x7ffffff0;           // columns >= m read as 0 (m even)
+    // request the next half chunk into ring slot rb: wave w copies rows 8 w .. 8 w + 7
+    auto issue_half = [&](int rb) -> unsigned {
+        const unsigned id = idL;
+        const int64_t tb = (int64_t)id * I8_ITEM_ROWS + (int64_t)hL * I8_HS;
+        const int64_t left = min((n - tb) * m * 8, (int64_t)I8_HS * m * 8);
+        // (the 64-bit products above are computed on the vector unit: without the readfirstlane the
+        // descriptor counts as divergent and every copy sits in a waterfall loop)
+        const uint64_t xb = (uint64_t)(uintptr_t)(X + tb * m);
+        const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xb);
+        const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+        const unsigned nbytes = __builtin_amdgcn_readfirstlane(
+            left <= 0 ? 0u : (left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)left));
+        const i8_rsrc_t rs = i8_rsrc(reinterpret_cast<const void *>((uintptr_t)(((uint64_t)xhi << 32) | xlo)), nbytes);
+        // (d first: the wave that loads it waits for it with the younger copies still in flight)
+        if (wave == 0 && lane < I8_HS) dreg = tb + lane < n ? d[tb + lane] : 0.0;
+#if !defined(I8_ABLATE_NO_DMA)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            i8_dma16(rs, raw + rb * I8_RAWBUF + (8 * wave + j) * I8_RAWSTR, (int)((8 * wave + j) * m * 8) + dma_voff);
+#endif
+        if (++hL == 2 * I8_CPI) {
+            hL = 0;
+            idL = idNext;
+            if (tid == 0) *slot = gridDim.x + atomicAdd(counter, 1u);
+            pending = true;
+        }
+        return id;
+    };
+    auto publish_d = [&](int rb) {          // sqrt(d) of the half just requested (wave 0, after its load landed)
+        if (wave == 0 && lane < I8_HS) dl[rb * I8_HS + lane] = sqrt(dreg);
+    };
+
+    // this lane's two columns and their scales
+    const double sg0 = sigma[32 * wave + cl], sg1 = sigma[32 * wave + 16 + cl];
+    const double MAGIC = 6755399441055744.0 + 141289400074368.0;          // 1.5 * 2^52 + 0x808080808080
+    // one half chunk (ring slot rb) -> rows 32 hh .. 32 hh + 31 of the digit planes.  Per call: the
+    // lane's 4 rows (quad qq of 8) of column block cb (0 / 1) -- 16 calls cover the half.
+    const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)raw;
+    auto convert_quad = [&](int rb, int hh, auto cb_c, auto qq_c) {
+        constexpr int cb = decltype(cb_c)::value, qq = decltype(qq_c)::value;   // qq: 0 / 1 (quads rq and rq + 4)
+#if defined(I8_ABLATE_NO_CONVERT)
+        return;
+#endif
+        const int col = 32 * wave + 16 * cb + cl;
+        const int row0 = 4 * (rq + 4 * qq);                                     // row inside the half
+        const unsigned ra = raw_lds + (unsigned)(rb * I8_RAWBUF + row0 * I8_RAWSTR + col * 8);
+        const double sg = cb ? sg1 : sg0;
+        double xr[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:1056\n\tds_read_b64 %2, %4 offset:2112\n\t"
+                     "ds_read_b64 %3, %4 offset:3168\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(xr[0]), "=&v"(xr[1]), "=&v"(xr[2]), "=&v"(xr[3])
+                     : "v"(ra)
+                     : "memory");
+#else
+        xr[0] = xr[1] = xr[2] = xr[3] = 0.0;
+#endif
+        static_assert(I8_RAWSTR == 1056, "the ds_read offsets above are multiples of the raw row stride");
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double u = xr[j] * dl[rb * I8_HS + row0 + j];
+            const double t = __builtin_fma(u, sg, MAGIC);
+            lo[j] = (unsigned)__double2loint(t) ^ 0x80808080u;
+            hi[j] = (unsigned)__double2hiint(t) ^ 0x00008080u;
+        }
+        // 4 rows x 4 digit bytes -> 4 digits x 4 row bytes
+        const unsigned t0 = i8_perm(lo[1], lo[0], 0x05010400u);     // r0.0 r1.0 r0.1 r1.1
+        const unsigned t1 = i8_perm(lo[1], lo[0], 0x07030602u);     // r0.2 r1.2 r0.3 r1.3
+        const unsigned t2 = i8_perm(lo[3], lo[2], 0x05010400u);
+        const unsigned t3 = i8_perm(lo[3], lo[2], 0x07030602u);
+        const unsigned g0 = i8_perm(t2, t0, 0x05040100u);           // r0.0 r1.0 r2.0 r3.0
+        const unsigned g1 = i8_perm(t2, t0, 0x07060302u);
+        const unsigned g2 = i8_perm(t3, t1, 0x05040100u);
+        const unsigned g3 = i8_perm(t3, t1, 0x07060302u);
+        const unsigned h0 = i8_perm(hi[1], hi[0], 0x05010400u);     // r0.4 r1.4 r0.5 r1.5
+        const unsigned h1 = i8_perm(hi[3], hi[2], 0x05010400u);
+        const unsigned g4 = i8_perm(h1, h0, 0x05040100u);
+        const unsigned g5 = i8_perm(h1, h0, 0x07060302u);
+        unsigned char *pb = planes + col * I8_PSTR + 32 * hh + row0;
+        *reinterpret_cast<unsigned *>(pb) = g0;
+        *reinterpret_cast<unsigned *>(pb + I8_PLANE) = g1;
+        *reinterpret_cast<unsigned *>(pb + 2 * I8_PLANE) = g2;
+        *reinterpret_cast<unsigned *>(pb + 3 * I8_PLANE) = g3;
+        *reinterpret_cast<unsigned *>(pb + 4 * I8_PLANE) = g4;
+        *reinterpret_cast<unsigned *>(pb + 5 * I8_PLANE) = g5;
+    };
+    auto convert_half = [&](int rb, int hh) {
+        convert_quad(rb, hh, C0{}, C0{});
+        convert_quad(rb, hh, C0{}, C1{});
+        convert_quad(rb, hh, C1{}, C0{});
+        convert_quad(rb, hh, C1{}, C1{});
+    };
+
+    // fragment of column block b, digit s: lane (i = lane & 15, kg = lane >> 4) -> rows 16 kg .. 16 kg + 15
+    const int foff = (lane & 15) * I8_PSTR + (lane >> 4) * 16;
+    auto frag = [&](int b, int s) {
+        return *reinterpret_cast<const i8_v4 *>(planes + s * I8_PLANE + b * 16 * I8_PSTR + foff);
+    };
+
+    auto run = [&](auto wid) {
+        constexpr int WID = decltype(wid)::value;
+        i8_v4 acc[9][I8_NC];
+        // the workgroup's f64 partial [tile][16][16]: this wave's 9 tiles, folded after every item
+        double *dst = part + (int64_t)blockIdx.x * (I8_T * 256);
+        auto flush = [&]() {
+            // (the partial's 36 addresses must not be hoisted out of the chunk loop: 72 registers)
+            unsigned lane_off = (unsigned)(((4 * (lane >> 4)) * 16 + (lane & 15)) * 8);
+            asm volatile("" : "+v"(lane_off));
+            char *const fb = reinterpret_cast<char *>(dst) + lane_off;
+            static_for<9>([&](auto sc) {
+                constexpr int s9 = decltype(sc)::value;
+                constexpr int t = I8Tiles<WID>::tile(s9);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // sum_c 256^c C_c, c = 0 .. 5  (Horner from the top class; 256^5 is applied at the end)
+                    double v = (double)acc[s9][5][r];
+                    v = v * 256.0 + (double)acc[s9][4][r];
+                    v = v * 256.0 + (double)acc[s9][3][r];
+                    v = v * 256.0 + (double)acc[s9][2][r];
+                    v = v * 256.0 + (double)acc[s9][1][r];
+                    v = v * 256.0 + (double)acc[s9][0][r];
+                    // (no-return atomic: 36 read-modify-writes in flight instead of 36 round trips; this wave
+                    // is the only writer of the address, so the sum order stays the item order)
+                    atomicAdd(reinterpret_cast<double *>(fb + (t * 256 + r * 16) * 8), v);
+                }
+            });
+        };
+
+        // ---- prologue: halves 0, 1 -> planes (chunk 0); halves 2, 3 requested.  Half k lives in ring slot
+        // k % 3; a half is requested one whole iteration before it is converted.
+        unsigned id_c = issue_half(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // d of half 0 (older than the 8 copies)
+        publish_d(0);
+        (void)issue_half(1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        publish_d(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        i8_lds_barrier();
+        if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
+        convert_half(0, 0);
+        convert_half(1, 1);
+        i8_lds_barrier();                                            // slots 0, 1 free, planes = chunk 0
+        unsigned id_c1 = issue_half(2);                              // half 2 (first half of chunk 1)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        publish_d(2);
+        (void)issue_half(0);                                         // half 3
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        publish_d(0);
+        int sa = 2;                                                  // ring slot of the first half of chunk c + 1
+
+        // Iteration c: planes hold chunk c; the halves of chunk c + 1 sit in slots sa, sa + 1 (landed or
+        // landing); the halves of chunk c + 2 are requested behind barriers B and C into the two slots
+        // that are free by then.
+        // (an item = I8_CPI whole chunks, rows beyond n read as 0: the inner trip count is fixed and the
+        // fold sits at ONE place behind it -- a conditional fold inside the chunk loop made the allocator
+        // keep every accumulator twice across the join)
+        while (id_c < (unsigned)n_items) {
+          // (zeroed HERE, not in the fold: the accumulators are then not live across the item loop)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+              for (int c = 0; c < I8_NC; ++c) {
+                  acc[t][c] = i8_v4{0, 0, 0, 0};
+                  // pinned to the accumulation registers: left to itself the allocator carried part of
+                  // the 216 accumulators through the chunk loop in VGPRs and spilled ~340 registers
+                  asm volatile("" : "+a"(acc[t][c]));
+              }
+          for (int oc = 0; oc < I8_CPI; ++oc) {
+            const int sb = sa == 2 ? 0 : sa + 1;     // slot of the second half of chunk c + 1
+            const int sc = sb == 2 ? 0 : sb + 1;     // the third slot: second half of chunk c, consumed
+            i8_lds_barrier();                        // A: planes complete, slot sc consumed, dl published
+            if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
+            // the digit fragments of the wave's five blocks (30 of the chunk's 48)
+            using TL = I8Tiles<WID>;
+            i8_v4 F[TL::NB][I8_ND];
+#pragma unroll
+            for (int b = 0; b < TL::NB; ++b)
+#pragma unroll
+                for (int s = 0; s < I8_ND; ++s) F[b][s] = frag(TL::block(b), s);
+            // B: every wave holds its fragments (the planes may be rewritten) and its rows of slot sa have
+            // landed (only the 8 copies into slot sb, requested one half iteration later, may be in flight)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            i8_lds_barrier();
+            const unsigned id_a = issue_half(sc);    // first half of chunk c + 2 -> the free slot
+            // digit pairs (s, t), s + t = 5 .. 10, over the wave's 9 tiles; the conversion of the next
+            // chunk's halves is issued in 8 slices behind the pair groups
+            auto pairs = [&](auto lo_c, auto hi_c) {                 // pair indices [lo, hi) of i8_pair_s / _t
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                static_for<HI - LO>([&](auto ic) {
+                    constexpr int idx = LO + decltype(ic)::value;
+                    constexpr int ps = i8_pair_s(idx), pt = i8_pair_t(idx);
+                    static_for<9>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+#if defined(I8_ABLATE_NO_MFMA)
+                        acc[q][ps + pt - 5][0] += F[TL::local(TL::bi(q))][ps][0] ^ F[TL::local(TL::bj(q))][pt][1];
+                        return;
+#endif
+                        acc[q][ps + pt - 5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                            F[TL::local(TL::bi(q))][ps], F[TL::local(TL::bj(q))][pt], acc[q][ps + pt - 5], 0, 0, 0);
+                    });
+                });
+            };
+            pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sa, 0, C0{}, C0{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sa, 0, C0{}, C1{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sa, 0, C1{}, C0{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 8>{}, std::integral_constant<int, 11>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sa, 0, C1{}, C1{});
+            __builtin_amdgcn_sched_barrier(0);
+            // sqrt(d) of the half just requested into slot sc (its old values were last read before barrier A)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            publish_d(sc);
+            // C: slot sa is consumed by everybody; this wave's rows of slot sb have landed (the 8 copies
+            // into slot sc stay in flight)
+            i8_lds_barrier();
+            (void)issue_half(sa);                    // second half of chunk c + 2 -> the slot just consumed
+            pairs(std::integral_constant<int, 11>{}, std::integral_constant<int, 14>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sb, 1, C0{}, C0{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 14>{}, std::integral_constant<int, 16>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sb, 1, C0{}, C1{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 16>{}, std::integral_constant<int, 19>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sb, 1, C1{}, C0{});
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(std::integral_constant<int, 19>{}, std::integral_constant<int, 21>{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert_quad(sb, 1, C1{}, C1{});
+            __builtin_amdgcn_sched_barrier(0);
+            // sqrt(d) of the half just requested into slot sa (its old values were read before barrier C)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            publish_d(sa);
+            sa = sc;                                 // chunk c + 2 starts in the slot requested at B
+            id_c = id_c1;
+            id_c1 = id_a;
+          }
+          flush();                                    // the item is complete: fold the int32 classes
+        }
+    };
+    if (wave == 0) run(std::integral_constant<int, 0>{});
+    else if (wave == 1) run(std::integral_constant<int, 1>{});
+    else if (wave == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (copies of halves beyond the end are still in flight)
+}
+
+// out[i][j] = 2^-(k_i + k_j) * sum over the workgroups' partials, mirrored; a quarter tile per block
+__global__ __launch_bounds__(1024) void syrk_i8_finish_kernel(const double *__restrict__ part, int nblk,
+                                                              int n_cols, const double *__restrict__ rscale,
+                                                              const I8Info *__restrict__ info,
+                                                              double *__restrict__ out, int64_t ldo) {
+    if (info->flag != 0) return;
+    __shared__ double red[16][64];
+    const int e = blockIdx.y * 64 + threadIdx.x, s = threadIdx.y, t = blockIdx.x;
+    double a = 0.0;
+    for (int b = s; b < nblk; b += 16) a += part[((int64_t)b * I8_T + t) * 256 + e];
+    red[s][threadIdx.x] = a;
+    __syncthreads();
+    if (s == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w += 4)
+            v += (red[w][threadIdx.x] + red[w + 1][threadIdx.x]) + (red[w + 2][threadIdx.x] + red[w + 3][threadIdx.x]);
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        const int bj = t - bi * (bi + 1) / 2;
+        const int ci = 16 * bi + (e >> 4), cj = 16 * bj + (e & 15);
+        if (ci < n_cols && cj < n_cols && (bi != bj || (e >> 4) >= (e & 15))) {
+            // 256^5 of the lowest class kept, 2^-k of both columns (all powers of two: exact)
+            v = v * 1099511627776.0 * rscale[ci] * rscale[cj];
+            out[(int64_t)ci * ldo + cj] = v;
+            if (ci != cj) out[(int64_t)cj * ldo + ci] = v;
+        }
+    }
+}
+
+// The a-posteriori envelope check.  Column j is kept to 2^-46 of M_j = max|x_j| sqrt(max d), so an entry
+// out[j][k] carries an error of ~2^-46 M_j / ||sqrt(d) x_j|| of its natural scale ||sqrt(d) x_j|| ||sqrt(d) x_k||
+// -- and ||sqrt(d) x_j||^2 is the diagonal just computed.  Weights that are tiny exactly where a column
+// is large (ratio > 2^10) fall outside: the flag hands the call to the f64 kernel.
+__global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, const double *__restrict__ colmax,
+                                   int m, I8Info *info) {
+    const int j = threadIdx.x;
+    if (j >= m || info->flag != 0) return;
+    const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
+    const double big2 = colmax[j] * colmax[j] * dmax;
+    if (!(big2 <= 1048576.0 * out[(int64_t)j * ldo + j])) atomicOr(&info->flag, 2u);
+}
+
+// the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
+int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, const unsigned *flag,
+                        void *ws, hipStream_t st);
+size_t syrk_co_ws_bytes();
+
+int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
+                hipStream_t st) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    TM_REQUIRE(m == 0 || syrk_co_ok(X, m), "the int8 syrk takes a 16-byte aligned C-ordered f64 block of an "
+                                           "even number of columns <= 128");
+    if (m == 0) return TM_OK;
+    if (n == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(m * m), st));
+        return TM_OK;
+    }
+    const int64_t n_items64 = ceil_div(n, I8_ITEM_ROWS);
+    TM_REQUIRE(n_items64 < (1ll << 31), "too many rows");
+    const int n_items = (int)n_items64;
+    const int grid = (int)std::min<int64_t>(n_items, tune("i8_grid", NUM_CU));
+    const size_t part_bytes = sizeof(double) * (size_t)grid * I8_T * 256;
+    // one workspace for both kernels: [this kernel's region | the f64 kernel's region]
+    const size_t own_bytes = (4096 + part_bytes + 255) / 256 * 256;
+    void *wsv = nullptr;
+    int rc = get_workspace(own_bytes + syrk_co_ws_bytes(), &wsv, st);
+    if (rc) return rc;
+    char *wb = reinterpret_cast<char *>(wsv);
+    I8Info *info = reinterpret_cast<I8Info *>(wb);                      // 16 B
+    unsigned *counter = reinterpret_cast<unsigned *>(wb + 256);
+    double *sigma = reinterpret_cast<double *>(wb + 512);               // 128 doubles
+    double *rscale = reinterpret_cast<double *>(wb + 512 + 1024);       // 128 doubles
+    double *part = reinterpret_cast<double *>(wb + 4096);
+    TM_HIP(hipMemsetAsync(wb, 0, 4096 + part_bytes, st));
+    const int sgrid = (int)std::min<int64_t>(2 * NUM_CU, ceil_div(n, 1024));
+    hipLaunchKernelGGL(i8_screen_kernel, dim3((unsigned)sgrid), dim3(256), 0, st, d, n, info);
+    hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, info, sigma, rscale);
+    TM_LAUNCH_CHECK();
+    prof_begin(st);
+    hipLaunchKernelGGL(syrk_i8_kernel, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma, info,
+                       n_items, counter, part);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
+                       out, m);
+    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, info);
+    TM_LAUNCH_CHECK();
+    // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
+    prof_hold(true);               // (the event pair stays on the int8 kernel)
+    rc = run_syrk_co_flagged(X, n, m, d, out, &info->flag, wb + own_bytes, st);
+    prof_hold(false);
+    return rc;
+}
+
+}  // namespace tmh
+
+extern "C" {
+
+int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                             double *out, void *stream) {
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, tmh::as_stream(stream));
+}
+
+}  // extern "C"

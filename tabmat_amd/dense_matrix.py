@@ -29,6 +29,9 @@ from .util import (
 # F-ordered blocks get a row-major twin in HBM for the sandwich kernels (DenseMatrix._dev_c);
 # TABMAT_AMD_ROW_MAJOR_TWIN=0 keeps the caller's layout only (column-major kernel variants).
 ROW_MAJOR_TWIN = os.environ.get("TABMAT_AMD_ROW_MAJOR_TWIN", "1") != "0"
+# the float64 syrk on the int8 matrix cores (Ozaki-style slicing, csrc/syrk_i8.hip) for blocks it suits
+SYRK_I8 = os.environ.get("TABMAT_AMD_SYRK_I8", "1") != "0"
+I8_MIN_ROWS = 4096
 
 
 class DenseMatrix(MatrixBase):
@@ -166,7 +169,29 @@ class DenseMatrix(MatrixBase):
         return type(self)(arr, column_names=self._colnames, term_names=self._terms)
 
     # ---- hot path -----------------------------------------------------------------------
+    def _i8_colmax(self):
+        """max |x| per column (float64 device tensor) when the block qualifies for the int8-sliced
+        syrk (csrc/syrk_i8.hip), else None: finite float64 blocks of 66 .. 128 (even) columns.  One
+        pass over the block at first use.  The part of the envelope that depends on the weights
+        (negative / non-finite d, weights tiny exactly where a column is large) is checked on the
+        device inside every call, which then runs the f64 kernel instead."""
+        hit = getattr(self, "_i8_ok", None)
+        if hit is None:
+            hit = False
+            blk = self._dev_c()
+            if (SYRK_I8 and not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= 128
+                    and blk.m % 2 == 0 and blk.n >= I8_MIN_ROWS and blk.buf.data_ptr() % 16 == 0):
+                cmax = blk.as_2d().abs().amax(dim=0)
+                if bool(torch.isfinite(cmax).all().item()):
+                    hit = cmax.contiguous()
+            self._i8_ok = hit
+        return None if hit is False else hit
+
     def _sandwich_dev(self, d, rows, cols):
+        if rows is None and cols is None and d.dtype == torch.float64:
+            cmax = self._i8_colmax()
+            if cmax is not None:
+                return xd.dense_sandwich_i8(self._dev_c(), d, cmax)
         return xd.dense_sandwich(self._dev_c(), d, rows, cols)
 
     def sandwich(self, d, rows=None, cols=None):

@@ -1,0 +1,95 @@
+"""-m gpu parity of K1e, the float64 dense syrk on the int8 matrix cores (csrc/syrk_i8.hip; reference:
+ext/dense_helpers-tmpl.cpp:266-311): against the oracle at 1e-10 of max|out| AND entry by entry
+relative to each entry's natural scale, the device-side hand-over to the f64 kernel for weights
+outside the envelope, chunk (64 rows) / item (2048 rows) edges, columns of mixed magnitude."""
+import numpy as np
+import pytest
+import torch
+
+from _gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _orc():
+    from oracle import oracle as orc
+
+    return orc
+
+
+def _run(X, d):
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext._types import DenseDev
+
+    Xd = DenseDev.from_host(X)
+    cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
+    return xd.dense_sandwich_i8(Xd, torch.from_numpy(d).cuda(), cmax).cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2047, 2048, 2049, 10_000, 131_075])
+@pytest.mark.parametrize("m", [2, 66, 100, 128])
+def test_i8_vs_oracle(n, m):
+    rng = np.random.default_rng(n * 3 + m)
+    X = rng.standard_normal((n, m)) * rng.lognormal(0, 3, m)          # column scales over ~5 decades
+    d = rng.random(n)
+    d[::7] = 0.0
+    out = _run(X, d)
+    ref = _orc().dense_sandwich(X, d, None, None)
+    assert rel_err(out, ref) < 1e-10
+    assert np.array_equal(out, out.T)
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300     # entry-wise natural scale
+    assert float((np.abs(out - ref) / scale).max()) < 1e-10
+
+
+def test_i8_hand_over_for_negative_or_nonfinite_weights():
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((20_000, 128))
+    d = rng.random(20_000) - 0.3                    # negative weights: the f64 kernel must take over
+    ref = _orc().dense_sandwich(X, d, None, None)
+    assert rel_err(_run(X, d), ref) < 1e-10
+    d2 = rng.random(20_000)
+    d2[17] = np.inf
+    out = _run(X, d2)
+    assert not np.isfinite(out).all()               # inf propagates as in the reference
+
+
+def test_dense_matrix_takes_the_i8_path_only_inside_the_envelope(monkeypatch):
+    import tabmat_amd as tm
+    from tabmat_amd.ext import dense as xd
+
+    calls = []
+    real = xd.dense_sandwich_i8
+    monkeypatch.setattr(xd, "dense_sandwich_i8", lambda *a: (calls.append(1), real(*a))[1])
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((30_000, 128))
+    d = rng.random(30_000)
+    ref = _orc().dense_sandwich(X, d, None, None)
+    assert rel_err(tm.DenseMatrix(X).sandwich(d), ref) < 1e-10 and calls
+    calls.clear()
+    Xn = X.copy()
+    Xn[7, 3] = np.nan
+    tm.DenseMatrix(Xn).sandwich(d)
+    assert not calls
+    assert rel_err(tm.DenseMatrix(X[:, :64].copy()).sandwich(d), ref[:64, :64]) < 1e-10 and not calls
+
+
+def test_i8_hand_over_when_the_weights_hide_a_columns_large_entries():
+    """Fixed point keeps 2^-46 of max|x_j| sqrt(max d): with the weight ~0 exactly on a column's huge
+    entries the rest of the column would lose its digits -- the call must come back at f64 accuracy
+    (entry by entry relative to the natural scale), i.e. from the f64 kernel."""
+    rng = np.random.default_rng(9)
+    n, m = 40_000, 128
+    X = rng.standard_normal((n, m))
+    X[::1000, 5] = 1e12
+    d = rng.random(n)
+    d[::1000] = 1e-300
+    out = _run(X, d)
+    ref = _orc().dense_sandwich(X, d, None, None)
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert float((np.abs(out - ref) / scale).max()) < 1e-12
+    # ... while a heavy-tailed column under ordinary weights stays inside the envelope
+    d2 = rng.random(n)
+    out2 = _run(X, d2)
+    ref2 = _orc().dense_sandwich(X, d2, None, None)
+    scale2 = np.sqrt(np.outer(np.diag(ref2), np.diag(ref2)))
+    assert float((np.abs(out2 - ref2) / scale2).max()) < 1e-10
