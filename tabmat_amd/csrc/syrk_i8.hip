@@ -4,51 +4,77 @@
 //
 // v_mfma_f64_16x16x4_f64 runs at the vector f64 rate on gfx950 and sustains 0.6 of it: the f64 syrk
 // (syrk_co.hip) needs 3.3 ms for 10M x 128 while the block streams in 1.3 ms and the int8 matrix
-// cores (3.9 POPS measured) sit idle.  Ozaki-style slicing moves the product there EXACTLY:
-//   * Y = diag(sqrt d) X is written in 48-bit fixed point per column,
-//         F[r][i] = round(Y[r][i] * 2^k_i),   |F| <= 2^45,   2^k_i = 2^45 / 2^ceil(log2(colmax_i sqrt(dmax)))
-//     by ONE v_fma_f64 with a magic constant (1.5 * 2^52 + 0x808080808080): the low 48 mantissa bits
-//     of the result are F + bias, whose six bytes g_0 .. g_5 are the balanced base-256 digits
+// cores (3.9 POPS measured) sit idle.  Ozaki-style slicing moves the product there:
+//   * Y = diag(sqrt d) X is written in 40-bit fixed point per column,
+//         F[r][i] = round(Y[r][i] * 2^k_i),   |F| <= 2^38,   2^k_i = 2^38 / 2^ceil(log2(colmax_i sqrt(dmax)))
+//     by ONE v_fma_f64 with a magic constant (1.5 * 2^52 + 0x8080808080): the low 40 mantissa bits
+//     of the result are F + bias, whose five bytes g_0 .. g_4 are the balanced base-256 digits
 //     b_s = g_s - 128 in [-128, 127] (two's complement byte: g_s ^ 0x80),  F = sum_s b_s 256^s;
 //   * S_ij = 2^-(k_i + k_j) sum_r F_ri F_rj = 2^-(k_i + k_j) sum_{s,t} 256^(s + t) sum_r b_s[r][i] b_t[r][j]:
 //     every digit pair is an int8 GEMM (v_mfma_i32_16x16x64_i8, exact in int32 over <= 2048 rows); the
-//     pairs of one weight class s + t share an accumulator; the classes s + t >= 5 are kept (21 pairs,
-//     6 accumulators per tile) -- the dropped ones weigh <= 2^-46 of the largest product;
-//   * after every work item of 2048 rows the six int32 classes of a tile are folded into the
+//     pairs of one weight class s + t share an accumulator; the classes s + t >= 2 are kept (22 of the
+//     25 pairs, 7 accumulators per tile);
+//   * after every work item of 2048 rows the seven int32 classes of a tile are folded into the
 //     workgroup's f64 partial (sum_c 256^c C_c, exact in f64 up to the final roundings).
-// Error: |F - Y 2^k| <= 1/2, i.e. 2^-46 of the column's largest scaled entry -- for columns whose
-// largest entry is within 2^10 of their rms (checked once per block on the host) every product is
-// good to ~1e-11 relative and the sums far better; measured against the oracle in
-// tests/test_gpu_syrk_i8.py.  Blocks or weights outside that envelope (non-finite values, negative
-// or non-finite weights, heavy-tailed columns) take the f64 kernel: the weights are screened by a
-// reduction kernel on the device (no host synchronisation) and both kernels are launched -- the one
-// the flag does not select returns at once.
+// Error, relative to an entry's natural scale ||y_i|| ||y_j|| (y = sqrt(d) x; M_i = colmax_i sqrt(dmax)
+// is what the fixed point is scaled to, R_i = M_i / ||y_i||):
+//   * rounding to fixed point: |F - Y 2^k| <= 1/2 = 2^-39 M  ->  2^-39 R_i / sqrt 3; R <= 1 unless the
+//     weights are tiny exactly where the column is large, typically 1e-2 .. 1e-3: ~1e-14;
+//   * the three dropped pairs (0,0) (0,1) (1,0): on the diagonal b_0^2 does not average out -- a bias
+//     of 2^12.4 per row against (2^38 / (M / rms))^2: 2^-63.6 (M_i / rms y_i)^2 = 2^-63.6 n R_i^2.
+//     (The first cut of this kernel kept six digits and the classes s + t >= 5: 21 pairs, and a
+//     diagonal bias of 2^-45.6 (M / rms)^2 -- 2.4e-12 measured on standard normal columns, and an
+//     envelope of M / rms < ~30.  One digit less and the lowest classes kept costs one MFMA more per
+//     tile and chunk and is 2^18 times better where it matters.)
+// The envelope R_i^2 <= min(64, 2^27 / n) (both terms < 1e-11) is checked on the DEVICE after the
+// product -- ||y_i||^2 is the diagonal just computed -- together with the screening of d (negative
+// or non-finite weights): a call outside it is handed to the f64 kernel without a host
+// synchronisation; both kernels are launched and the one the flag does not select returns at once.
+// Non-finite X is excluded once per block on the host (dense_matrix.py).  Measured against the oracle
+// in tests/test_gpu_syrk_i8.py.
 //
-// Layout (4 waves, ONE per SIMD: 256 VGPRs of digit fragments + 216 AGPRs of int32 accumulators):
-// raw f64 rows come in by LDS-DMA in half chunks of 32 rows into a ring of two buffers; a chunk is 64
-// rows (K of the MFMA); lane (16 columns x 4 row quads per wave instruction) converts 4 rows of a
-// column at a time, transposes the 4 x 6 digit bytes with v_perm_b32 and writes six 4-byte words into
-// the digit planes [digit][column][64 rows]; all 48 fragments (8 column blocks x 6 digits) of a chunk
-// are read into registers between two barriers, then the planes are rewritten for the next chunk
-// while the 189 MFMAs of the wave's 9 tiles run from registers.
+// Layout (4 waves, ONE per SIMD: 256 VGPRs of digit fragments + 252 AGPRs of int32 accumulators):
+// raw f64 rows come in by LDS-DMA in half chunks of 32 rows into a ring of THREE buffers (every half is
+// requested one whole chunk iteration before it is converted); a chunk is 64 rows (K of the MFMA);
+// lane (16 columns x 4 row quads per wave instruction) converts 4 rows of a column at a time,
+// transposes the 4 x 5 digit bytes with v_perm_b32 and writes five 4-byte words into the digit planes
+// [digit][column][64 rows]; the 25 fragments a wave needs (5 column blocks x 5 digits) are read into
+// registers between two barriers, then the planes are rewritten for the next chunk while the 198
+// MFMAs of the wave's 9 tiles run from registers.
 #include <algorithm>
 #include <cmath>
 
 #include "common.hpp"
 
+#if defined(I8_NO_SB)
+#define I8_SB
+#else
+#define I8_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+#if defined(I8_TRACE)   // ablation build: workgroup 0 stamps the phases of chunk iterations 8 .. 11 (scripts/dev/trace_i8.py)
+#define I8_STAMP(k)                                                                                     \
+    do {                                                                                                \
+        if (blockIdx.x == 0 && lane == 0 && trace_it >= 8 && trace_it < 12)                             \
+            trace_buf[((trace_it - 8) * 4 + wave) * 8 + (k)] = __builtin_readcyclecounter();            \
+    } while (0)
+#else
+#define I8_STAMP(k)
+#endif
 namespace tmh {
 
 constexpr int I8_W = 128;                       // padded columns
 constexpr int I8_T = 36;                        // lower-triangular 16 x 16 tiles
-constexpr int I8_ND = 6;                        // digits
-constexpr int I8_NC = 6;                        // weight classes kept: s + t = 5 .. 10
+constexpr int I8_ND = 5;                        // digits (40-bit fixed point)
+constexpr int I8_WLO = 2;                       // lowest weight class s + t kept
+constexpr int I8_NC = 2 * (I8_ND - 1) - I8_WLO + 1;   // classes kept: s + t = 2 .. 8 (7)
+constexpr int I8_FBITS = 38;                    // |F| <= 2^38 < 0.498 * 2^40
 constexpr int I8_RS = 64;                       // rows per chunk = K of the MFMA
 constexpr int I8_HS = 32;                       // rows per half chunk (one DMA ring slot)
 constexpr int I8_WAVES = 4;
 constexpr int I8_THREADS = I8_WAVES * 64;
-constexpr int I8_PSTR = 80;                     // bytes per column of a digit plane (64 rows + 16)
+constexpr int I8_PSTR = 64;                     // bytes per column of a digit plane (64 rows, 16-byte groups swizzled)
 constexpr int I8_PLANE = I8_W * I8_PSTR;
-constexpr int I8_PLANES = I8_ND * I8_PLANE;     // 61 440 B
+constexpr int I8_PLANES = I8_ND * I8_PLANE;     // 40 960 B
 constexpr int I8_RAWSTR = 1024 + 32;            // bytes per raw f64 row in LDS
 constexpr int I8_RAWBUF = I8_HS * I8_RAWSTR;    // one half chunk: 33 792 B
 constexpr int I8_CPI = 32;                      // chunks per work item (2048 rows: int32 stays exact)
@@ -65,33 +91,32 @@ struct I8Info {                 // written by the prep kernels, read by the main
     unsigned pad;
 };
 
-// the 21 digit pairs (s, t) with s + t = 5 .. 10, class by class
-constexpr int i8_pair_s(int idx) {
+// the digit pairs (s, t) with s + t >= I8_WLO, class by class (22 of the 25)
+constexpr int i8_pair_find(int idx, bool want_s) {
     int k = 0;
-    for (int w = 5; w <= 10; ++w)
-        for (int s = 0; s < 6; ++s) {
+    for (int w = I8_WLO; w <= 2 * (I8_ND - 1); ++w)
+        for (int s = 0; s < I8_ND; ++s) {
             const int t = w - s;
-            if (t < 0 || t >= 6) continue;
-            if (k == idx) return s;
+            if (t < 0 || t >= I8_ND) continue;
+            if (k == idx) return want_s ? s : t;
             ++k;
         }
-    return 0;
+    return -1;
 }
-constexpr int i8_pair_t(int idx) {
+constexpr int i8_pair_s(int idx) { return i8_pair_find(idx, true); }
+constexpr int i8_pair_t(int idx) { return i8_pair_find(idx, false); }
+constexpr int i8_count_pairs() {
     int k = 0;
-    for (int w = 5; w <= 10; ++w)
-        for (int s = 0; s < 6; ++s) {
-            const int t = w - s;
-            if (t < 0 || t >= 6) continue;
-            if (k == idx) return t;
-            ++k;
-        }
-    return 0;
+    while (i8_pair_find(k, true) >= 0) ++k;
+    return k;
 }
+constexpr int I8_NP = i8_count_pairs();
+static_assert(I8_NP == 22, "the pair groups of the chunk loop are laid out for 22 pairs");
+// (a class holds <= 5 pairs: 5 * 128 * 128 * 2048 rows < 2^31 -- the int32 sums are exact)
 
 // The 36 tiles (bi, bj <= bi) of the 8 column blocks, 9 per wave, dealt so that a wave needs the digit
-// fragments of only FIVE blocks (120 registers; all 8 blocks x 6 digits = 192 do not fit next to the
-// 216 accumulators and the conversion -- and a single spill reload inside the chunk loop is a
+// fragments of only FIVE blocks (100 registers; all 8 blocks x 5 digits = 160 do not fit next to the
+// 252 accumulators and the conversion -- and a single spill reload inside the chunk loop is a
 // scratch load, whose s_waitcnt vmcnt(0) also waits for every LDS-DMA copy in flight):
 //   wave 0, blocks {0,1,2,3,4}: (1,0) (2,0) (3,0) (4,0) (2,1) (3,1) (4,1) (3,2) (4,2)
 //   wave 1, blocks {0,1,5,6,7}: (5,0) (6,0) (7,0) (5,1) (6,1) (7,1) (6,5) (0,0) (1,1)
@@ -175,8 +200,8 @@ __global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, const 
         if (big > 0.0 && info->flag == 0) {
             int e;
             frexp(big, &e);                      // big = f * 2^e, f in [0.5, 1): big <= 2^e
-            s = ldexp(1.0, 45 - e);
-            r = ldexp(1.0, e - 45);
+            s = ldexp(1.0, I8_FBITS - e);
+            r = ldexp(1.0, e - I8_FBITS);
         }
     }
     sigma[i] = s;
@@ -200,6 +225,10 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
     __shared__ double dl[3 * I8_HS];                                              // sqrt(d) of the ring slots
     __shared__ unsigned slot_mem[4];
     unsigned *slot = slot_mem;
+#if defined(I8_TRACE)
+    unsigned long long *trace_buf = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(counter) - 256 + 2560);
+    int trace_it = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -254,58 +283,115 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
 
     // this lane's two columns and their scales
     const double sg0 = sigma[32 * wave + cl], sg1 = sigma[32 * wave + 16 + cl];
-    const double MAGIC = 6755399441055744.0 + 141289400074368.0;          // 1.5 * 2^52 + 0x808080808080
+    const double MAGIC = 6755399441055744.0 + 551911719040.0;             // 1.5 * 2^52 + 0x8080808080
     // one half chunk (ring slot rb) -> rows 32 hh .. 32 hh + 31 of the digit planes.  Per call: the
     // lane's 4 rows (quad qq of 8) of column block cb (0 / 1) -- 16 calls cover the half.
     const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)raw;
-    auto convert_quad = [&](int rb, int hh, auto cb_c, auto qq_c) {
+    const unsigned planes_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)planes;
+    struct Quad { double x[4]; };
+    // the lane's 4 raw rows (quad qq of 8) of column block cb from ring slot rb: issued here, complete
+    // after quad_wait (inline asm: see the note on the LDS objects above)
+    auto quad_issue = [&](int rb, auto cb_c, auto qq_c) -> Quad {
         constexpr int cb = decltype(cb_c)::value, qq = decltype(qq_c)::value;   // qq: 0 / 1 (quads rq and rq + 4)
-#if defined(I8_ABLATE_NO_CONVERT)
-        return;
+        Quad q;
+#if defined(I8_ABLATE_NO_CONVERT) || defined(I8_ABLATE_DMA_ONLY)
+        q.x[0] = q.x[1] = q.x[2] = q.x[3] = 0.0;
+        return q;
 #endif
         const int col = 32 * wave + 16 * cb + cl;
         const int row0 = 4 * (rq + 4 * qq);                                     // row inside the half
         const unsigned ra = raw_lds + (unsigned)(rb * I8_RAWBUF + row0 * I8_RAWSTR + col * 8);
-        const double sg = cb ? sg1 : sg0;
-        double xr[4];
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:1056\n\tds_read_b64 %2, %4 offset:2112\n\t"
-                     "ds_read_b64 %3, %4 offset:3168\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(xr[0]), "=&v"(xr[1]), "=&v"(xr[2]), "=&v"(xr[3])
+                     "ds_read_b64 %3, %4 offset:3168"
+                     : "=&v"(q.x[0]), "=&v"(q.x[1]), "=&v"(q.x[2]), "=&v"(q.x[3])
                      : "v"(ra)
                      : "memory");
 #else
-        xr[0] = xr[1] = xr[2] = xr[3] = 0.0;
+        (void)ra;
+        q.x[0] = q.x[1] = q.x[2] = q.x[3] = 0.0;
 #endif
         static_assert(I8_RAWSTR == 1056, "the ds_read offsets above are multiples of the raw row stride");
+        return q;
+    };
+    auto quad_wait = [&](Quad &q) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(I8_ABLATE_NO_CONVERT) && !defined(I8_ABLATE_DMA_ONLY)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q.x[0]), "+v"(q.x[1]), "+v"(q.x[2]), "+v"(q.x[3])::"memory");
+#endif
+    };
+    // 4 rows of one column -> fixed point -> 5 digit words of the planes (rows 32 hh + row0 ..), cut into
+    // I8_CSTEPS steps of two or three instructions: the chunk loop issues one step behind each MFMA
+    // (fenced with sched_barrier -- left to the scheduler, the conversion ended up in one lump behind
+    // the MFMAs, or the MFMAs of one accumulator back to back).
+    struct Conv {
+        double dv[4];
         unsigned lo[4], hi[4];
+        unsigned t[4], h[2], g[5];
+    };
+    auto conv_step = [&](auto k_c, const Quad &q, Conv &c, int rb, int hh, auto cb_c, auto qq_c) {
+        constexpr int k = decltype(k_c)::value;
+        constexpr int cb = decltype(cb_c)::value, qq = decltype(qq_c)::value;
+#if defined(I8_ABLATE_NO_CONVERT) || defined(I8_ABLATE_DMA_ONLY)
+        return;
+#endif
+        const int row0 = 4 * (rq + 4 * qq);
+        if constexpr (k == 0) {                     // sqrt(d) of the 4 rows (LDS; used from step 1 + I8_CLAT on)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double u = xr[j] * dl[rb * I8_HS + row0 + j];
-            const double t = __builtin_fma(u, sg, MAGIC);
-            lo[j] = (unsigned)__double2loint(t) ^ 0x80808080u;
-            hi[j] = (unsigned)__double2hiint(t) ^ 0x00008080u;
+            for (int j = 0; j < 4; ++j) c.dv[j] = dl[rb * I8_HS + row0 + j];
+        } else if constexpr (k >= 1 && k <= 4) {
+            const double sg = cb ? sg1 : sg0;
+            const double t = __builtin_fma(q.x[k - 1] * c.dv[k - 1], sg, MAGIC);
+            c.lo[k - 1] = (unsigned)__double2loint(t);
+            c.hi[k - 1] = (unsigned)__double2hiint(t);
+        } else if constexpr (k == 5) {              // 4 rows x 4 digit bytes -> 4 digits x 4 row bytes
+            c.t[0] = i8_perm(c.lo[1], c.lo[0], 0x05010400u);     // r0.0 r1.0 r0.1 r1.1
+            c.t[1] = i8_perm(c.lo[1], c.lo[0], 0x07030602u);     // r0.2 r1.2 r0.3 r1.3
+        } else if constexpr (k == 6) {
+            c.t[2] = i8_perm(c.lo[3], c.lo[2], 0x05010400u);
+            c.t[3] = i8_perm(c.lo[3], c.lo[2], 0x07030602u);
+        } else if constexpr (k == 7) {              // g ^ 0x80: biased byte -> two's complement digit
+            c.g[0] = i8_perm(c.t[2], c.t[0], 0x05040100u) ^ 0x80808080u;   // r0.0 r1.0 r2.0 r3.0
+        } else if constexpr (k == 8) {
+            c.g[1] = i8_perm(c.t[2], c.t[0], 0x07060302u) ^ 0x80808080u;
+        } else if constexpr (k == 9) {
+            c.g[2] = i8_perm(c.t[3], c.t[1], 0x05040100u) ^ 0x80808080u;
+        } else if constexpr (k == 10) {
+            c.g[3] = i8_perm(c.t[3], c.t[1], 0x07060302u) ^ 0x80808080u;
+        } else if constexpr (k == 11) {
+            c.h[0] = i8_perm(c.hi[1], c.hi[0], 0x05010400u);               // r0.4 r1.4 . .
+            c.h[1] = i8_perm(c.hi[3], c.hi[2], 0x05010400u);
+        } else if constexpr (k == 12) {
+            c.g[4] = i8_perm(c.h[1], c.h[0], 0x05040100u) ^ 0x80808080u;
+        } else if constexpr (k == 13) {
+            // rows 32 hh + row0 ..: 16-byte group 2 hh + qq, swizzled by the column (see frag below).
+            // Written with inline asm: the compiler pairs these stores into ds_write2st64_b32, whose merged
+            // memory operand loses the LDS variable -- and an LDS access the wait-count pass cannot
+            // attribute waits for EVERY LDS-DMA copy in flight (vmcnt(0) right behind the request of a half).
+            const int col = 32 * wave + 16 * cb + cl;
+            const unsigned pa =
+                planes_lds + (unsigned)(col * I8_PSTR + (((2 * hh + qq) ^ ((cl >> 1) & 3)) << 4) + 4 * rq);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:8192\n\tds_write_b32 %0, %3 offset:16384\n\t"
+                         "ds_write_b32 %0, %4 offset:24576\n\tds_write_b32 %0, %5 offset:32768"
+                         :
+                         : "v"(pa), "v"(c.g[0]), "v"(c.g[1]), "v"(c.g[2]), "v"(c.g[3]), "v"(c.g[4])
+                         : "memory");
+#else
+            (void)pa;
+#endif
+            static_assert(I8_PLANE == 8192 && I8_ND == 5, "the ds_write offsets above are the plane strides");
         }
-        // 4 rows x 4 digit bytes -> 4 digits x 4 row bytes
-        const unsigned t0 = i8_perm(lo[1], lo[0], 0x05010400u);     // r0.0 r1.0 r0.1 r1.1
-        const unsigned t1 = i8_perm(lo[1], lo[0], 0x07030602u);     // r0.2 r1.2 r0.3 r1.3
-        const unsigned t2 = i8_perm(lo[3], lo[2], 0x05010400u);
-        const unsigned t3 = i8_perm(lo[3], lo[2], 0x07030602u);
-        const unsigned g0 = i8_perm(t2, t0, 0x05040100u);           // r0.0 r1.0 r2.0 r3.0
-        const unsigned g1 = i8_perm(t2, t0, 0x07060302u);
-        const unsigned g2 = i8_perm(t3, t1, 0x05040100u);
-        const unsigned g3 = i8_perm(t3, t1, 0x07060302u);
-        const unsigned h0 = i8_perm(hi[1], hi[0], 0x05010400u);     // r0.4 r1.4 r0.5 r1.5
-        const unsigned h1 = i8_perm(hi[3], hi[2], 0x05010400u);
-        const unsigned g4 = i8_perm(h1, h0, 0x05040100u);
-        const unsigned g5 = i8_perm(h1, h0, 0x07060302u);
-        unsigned char *pb = planes + col * I8_PSTR + 32 * hh + row0;
-        *reinterpret_cast<unsigned *>(pb) = g0;
-        *reinterpret_cast<unsigned *>(pb + I8_PLANE) = g1;
-        *reinterpret_cast<unsigned *>(pb + 2 * I8_PLANE) = g2;
-        *reinterpret_cast<unsigned *>(pb + 3 * I8_PLANE) = g3;
-        *reinterpret_cast<unsigned *>(pb + 4 * I8_PLANE) = g4;
-        *reinterpret_cast<unsigned *>(pb + 5 * I8_PLANE) = g5;
+    };
+    constexpr int I8_CSTEPS = 14;
+    constexpr int I8_CLAT = 3;                      // MFMAs between the sqrt(d) read and its first use
+    auto quad_convert = [&](const Quad &q, int rb, int hh, auto cb_c, auto qq_c) {
+        Conv c;
+        static_for<I8_CSTEPS>([&](auto kc) { conv_step(kc, q, c, rb, hh, cb_c, qq_c); });
+    };
+    auto convert_quad = [&](int rb, int hh, auto cb_c, auto qq_c) {
+        Quad q = quad_issue(rb, cb_c, qq_c);
+        quad_wait(q);
+        quad_convert(q, rb, hh, cb_c, qq_c);
     };
     auto convert_half = [&](int rb, int hh) {
         convert_quad(rb, hh, C0{}, C0{});
@@ -314,8 +400,11 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
         convert_quad(rb, hh, C1{}, C1{});
     };
 
-    // fragment of column block b, digit s: lane (i = lane & 15, kg = lane >> 4) -> rows 16 kg .. 16 kg + 15
-    const int foff = (lane & 15) * I8_PSTR + (lane >> 4) * 16;
+    // fragment of column block b, digit s: lane (i = lane & 15, kg = lane >> 4) -> rows 16 kg .. 16 kg + 15.
+    // A column is 64 bytes, its four 16-byte row groups stored at (kg ^ (column >> 1)) & 3: both the
+    // ds_read_b128 of the fragments and the ds_write_b32 of the conversion are then free of bank conflicts
+    // (with a padded stride of 80 bytes every fragment read took 8 LDS cycles instead of 4).
+    const int foff = (lane & 15) * I8_PSTR + (((lane >> 4) ^ ((lane >> 1) & 3)) << 4);
     auto frag = [&](int b, int s) {
         return *reinterpret_cast<const i8_v4 *>(planes + s * I8_PLANE + b * 16 * I8_PSTR + foff);
     };
@@ -326,6 +415,9 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
         // the workgroup's f64 partial [tile][16][16]: this wave's 9 tiles, folded after every item
         double *dst = part + (int64_t)blockIdx.x * (I8_T * 256);
         auto flush = [&]() {
+            // (the MFMAs are inline asm: the hazard recognizer does not see them -- their results are read
+            // below with v_accvgpr_read, 18 wait states behind the last one at the most)
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             // (the partial's 36 addresses must not be hoisted out of the chunk loop: 72 registers)
             unsigned lane_off = (unsigned)(((4 * (lane >> 4)) * 16 + (lane & 15)) * 8);
             asm volatile("" : "+v"(lane_off));
@@ -335,13 +427,10 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
                 constexpr int t = I8Tiles<WID>::tile(s9);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // sum_c 256^c C_c, c = 0 .. 5  (Horner from the top class; 256^5 is applied at the end)
-                    double v = (double)acc[s9][5][r];
-                    v = v * 256.0 + (double)acc[s9][4][r];
-                    v = v * 256.0 + (double)acc[s9][3][r];
-                    v = v * 256.0 + (double)acc[s9][2][r];
-                    v = v * 256.0 + (double)acc[s9][1][r];
-                    v = v * 256.0 + (double)acc[s9][0][r];
+                    // sum_c 256^c C_c over the kept classes (Horner from the top; 256^I8_WLO is applied at the end)
+                    double v = (double)acc[s9][I8_NC - 1][r];
+#pragma unroll
+                    for (int c = I8_NC - 2; c >= 0; --c) v = v * 256.0 + (double)acc[s9][c][r];
                     // (no-return atomic: 36 read-modify-writes in flight instead of 36 round trips; this wave
                     // is the only writer of the address, so the sum order stays the item order)
                     atomicAdd(reinterpret_cast<double *>(fb + (t * 256 + r * 16) * 8), v);
@@ -385,86 +474,144 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
               for (int c = 0; c < I8_NC; ++c) {
                   acc[t][c] = i8_v4{0, 0, 0, 0};
                   // pinned to the accumulation registers: left to itself the allocator carried part of
-                  // the 216 accumulators through the chunk loop in VGPRs and spilled ~340 registers
+                  // the accumulators through the chunk loop in VGPRs and spilled ~340 registers
                   asm volatile("" : "+a"(acc[t][c]));
               }
           for (int oc = 0; oc < I8_CPI; ++oc) {
+            I8_STAMP(0);
             const int sb = sa == 2 ? 0 : sa + 1;     // slot of the second half of chunk c + 1
             const int sc = sb == 2 ? 0 : sb + 1;     // the third slot: second half of chunk c, consumed
-            i8_lds_barrier();                        // A: planes complete, slot sc consumed, dl published
+            i8_lds_barrier();                        // A: planes complete, slot sc consumed, dl published; this
+                                                     // wave waited for its rows of slot sa before it
+            I8_STAMP(1);
             if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
-            // the digit fragments of the wave's five blocks (30 of the chunk's 48)
+            Quad qa = quad_issue(sa, C0{}, C0{});    // (slot sa: every wave's rows landed before A)
+            // The 198 MFMAs (22 digit pairs x the wave's 9 tiles, pair-major).  The first 27 (class 2: the
+            // digits 0, 2, then 1) start while the fragments of the digits 3 and 4 are still being read;
+            // behind barrier B every group runs interleaved with the conversion of one quad of the NEXT chunk
+            // (its raw rows were read into registers during the group before): one MFMA keeps the matrix
+            // pipe for 16 cycles, two conversion instructions issue in its shadow.
             using TL = I8Tiles<WID>;
             i8_v4 F[TL::NB][I8_ND];
-#pragma unroll
-            for (int b = 0; b < TL::NB; ++b)
-#pragma unroll
-                for (int s = 0; s < I8_ND; ++s) F[b][s] = frag(TL::block(b), s);
-            // B: every wave holds its fragments (the planes may be rewritten) and its rows of slot sa have
-            // landed (only the 8 copies into slot sb, requested one half iteration later, may be in flight)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            i8_lds_barrier();
-            const unsigned id_a = issue_half(sc);    // first half of chunk c + 2 -> the free slot
-            // digit pairs (s, t), s + t = 5 .. 10, over the wave's 9 tiles; the conversion of the next
-            // chunk's halves is issued in 8 slices behind the pair groups
-            auto pairs = [&](auto lo_c, auto hi_c) {                 // pair indices [lo, hi) of i8_pair_s / _t
+            auto mf = [&](auto lo_c, auto hi_c) {
                 constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
                 static_for<HI - LO>([&](auto ic) {
-                    constexpr int idx = LO + decltype(ic)::value;
+                    constexpr int k = LO + decltype(ic)::value;
+                    constexpr int idx = k / 9, q = k % 9;
                     constexpr int ps = i8_pair_s(idx), pt = i8_pair_t(idx);
-                    static_for<9>([&](auto qc) {
-                        constexpr int q = decltype(qc)::value;
-#if defined(I8_ABLATE_NO_MFMA)
-                        acc[q][ps + pt - 5][0] += F[TL::local(TL::bi(q))][ps][0] ^ F[TL::local(TL::bj(q))][pt][1];
-                        return;
+#if defined(I8_ABLATE_DMA_ONLY)
+                    return;
 #endif
-                        acc[q][ps + pt - 5] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                            F[TL::local(TL::bi(q))][ps], F[TL::local(TL::bj(q))][pt], acc[q][ps + pt - 5], 0, 0, 0);
-                    });
+                    // (inline asm with the accumulator tied in place: through the builtin the allocator gave
+                    // many MFMAs a destination other than their accumulator and, with 252 of the 256
+                    // accumulation registers taken, parked accumulators in VGPRs around them -- ~1000
+                    // v_accvgpr_read / _write and the stalls for the MFMA results they copy)
+                    i8_v4 &cacc = acc[q][ps + pt - I8_WLO];
+                    const i8_v4 fa = F[TL::local(TL::bi(q))][ps], fb = F[TL::local(TL::bj(q))][pt];
+                    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(cacc) : "v"(fa), "v"(fb));
                 });
             };
-            pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sa, 0, C0{}, C0{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sa, 0, C0{}, C1{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sa, 0, C1{}, C0{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 8>{}, std::integral_constant<int, 11>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sa, 0, C1{}, C1{});
-            __builtin_amdgcn_sched_barrier(0);
+#define I8_MF(lo, hi) mf(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{})
+            // the digit fragments of the wave's five blocks (25 of the chunk's 40), in the order of first use
+            static_for<I8_ND>([&](auto oc_) {
+                constexpr int order[I8_ND] = {0, 2, 1, 3, 4};
+                constexpr int sd = order[decltype(oc_)::value];
+#pragma unroll
+                for (int b = 0; b < TL::NB; ++b) {
+#if defined(I8_ABLATE_DMA_ONLY)
+                    F[b][sd] = i8_v4{0, 0, 0, 0};
+#else
+                    F[b][sd] = frag(TL::block(b), sd);
+#endif
+                }
+            });
+            static_assert(i8_pair_s(0) == 0 && i8_pair_t(0) == 2 && i8_pair_s(2) == 2 && i8_pair_s(3) + i8_pair_t(3) == 3,
+                          "the first three pairs are class 2");
+            I8_MF(0, 27);
+#if !defined(I8_NO_WEAVE)
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);          // digits 0, 2
+            static_for<15>([&](auto) {                                   // digits 1, 3, 4 behind the first MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            });
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#endif
+            I8_SB;
+            I8_STAMP(2);
+            // B: every wave holds its fragments: the planes may be rewritten
+            i8_lds_barrier();
+            I8_STAMP(3);
+            quad_wait(qa);
+            const unsigned id_a = issue_half(sc);    // first half of chunk c + 2 -> the free slot
+            // one group: MFMAs [lo, hi) of the list, the conversion steps of quad q behind them one by one
+            auto group = [&](auto lo_c, auto hi_c, const Quad &q, int rb, int hh, auto cb_c, auto qq_c) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                static_assert(HI - LO >= I8_CSTEPS + I8_CLAT, "a group holds all steps of one quad");
+                Conv c;
+                static_for<HI - LO>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    mf(std::integral_constant<int, LO + i>{}, std::integral_constant<int, LO + i + 1>{});
+                    if constexpr (i == 0) conv_step(std::integral_constant<int, 0>{}, q, c, rb, hh, cb_c, qq_c);
+                    if constexpr (i > I8_CLAT && i - I8_CLAT < I8_CSTEPS)
+                        conv_step(std::integral_constant<int, i - I8_CLAT>{}, q, c, rb, hh, cb_c, qq_c);
+                    I8_SB;
+                });
+            };
+#define I8_GROUP(lo, hi, q, rb, hh, cb, qq) \
+    group(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}, q, rb, hh, cb, qq)
+            Quad qb = quad_issue(sa, C0{}, C1{});
+            I8_GROUP(27, 49, qa, sa, 0, C0{}, C0{});
+            quad_wait(qb);
+            I8_SB;
+            qa = quad_issue(sa, C1{}, C0{});
+            I8_GROUP(49, 71, qb, sa, 0, C0{}, C1{});
+            quad_wait(qa);
+            I8_SB;
+            qb = quad_issue(sa, C1{}, C1{});
+            I8_GROUP(71, 93, qa, sa, 0, C1{}, C0{});
+            quad_wait(qb);
+            I8_SB;
+            I8_GROUP(93, 114, qb, sa, 0, C1{}, C1{});
+            I8_SB;
             // sqrt(d) of the half just requested into slot sc (its old values were last read before barrier A)
+            I8_STAMP(4);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             publish_d(sc);
+            I8_STAMP(5);
             // C: slot sa is consumed by everybody; this wave's rows of slot sb have landed (the 8 copies
             // into slot sc stay in flight)
             i8_lds_barrier();
+            I8_STAMP(6);
             (void)issue_half(sa);                    // second half of chunk c + 2 -> the slot just consumed
-            pairs(std::integral_constant<int, 11>{}, std::integral_constant<int, 14>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sb, 1, C0{}, C0{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 14>{}, std::integral_constant<int, 16>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sb, 1, C0{}, C1{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 16>{}, std::integral_constant<int, 19>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sb, 1, C1{}, C0{});
-            __builtin_amdgcn_sched_barrier(0);
-            pairs(std::integral_constant<int, 19>{}, std::integral_constant<int, 21>{});
-            __builtin_amdgcn_sched_barrier(0);
-            convert_quad(sb, 1, C1{}, C1{});
-            __builtin_amdgcn_sched_barrier(0);
-            // sqrt(d) of the half just requested into slot sa (its old values were read before barrier C)
+            qa = quad_issue(sb, C0{}, C0{});
+            I8_MF(114, 120);                         // (covers the latency of the first raw read behind C)
+            quad_wait(qa);
+            I8_SB;
+            qb = quad_issue(sb, C0{}, C1{});
+            I8_GROUP(120, 140, qa, sb, 1, C0{}, C0{});
+            quad_wait(qb);
+            I8_SB;
+            qa = quad_issue(sb, C1{}, C0{});
+            I8_GROUP(140, 160, qb, sb, 1, C0{}, C1{});
+            quad_wait(qa);
+            I8_SB;
+            qb = quad_issue(sb, C1{}, C1{});
+            I8_GROUP(160, 180, qa, sb, 1, C1{}, C0{});
+            quad_wait(qb);
+            I8_SB;
+            I8_GROUP(180, 198, qb, sb, 1, C1{}, C1{});
+            I8_SB;
+#undef I8_MF
+#undef I8_GROUP
+            static_assert(I8_NP * 9 == 198, "the group bounds above");
+            // sqrt(d) of the half just requested into slot sa (its old values were read before barrier C);
+            // the wait also covers this wave's rows of the next chunk's first half (slot sc)
+            I8_STAMP(7);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             publish_d(sa);
+#if defined(I8_TRACE)
+            ++trace_it;
+#endif
             sa = sc;                                 // chunk c + 2 starts in the slot requested at B
             id_c = id_c1;
             id_c1 = id_a;
@@ -485,6 +632,13 @@ __global__ __launch_bounds__(1024) void syrk_i8_finish_kernel(const double *__re
                                                               const I8Info *__restrict__ info,
                                                               double *__restrict__ out, int64_t ldo) {
     if (info->flag != 0) return;
+#if defined(I8_TRACE)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.y == 0) {
+        const unsigned long long *tb = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(info) + 2560);
+        for (int k = threadIdx.x; k < 128; k += 64) out[k] = (double)(tb[k] - tb[0]);
+    }
+    return;
+#endif
     __shared__ double red[16][64];
     const int e = blockIdx.y * 64 + threadIdx.x, s = threadIdx.y, t = blockIdx.x;
     double a = 0.0;
@@ -501,25 +655,29 @@ __global__ __launch_bounds__(1024) void syrk_i8_finish_kernel(const double *__re
         const int bj = t - bi * (bi + 1) / 2;
         const int ci = 16 * bi + (e >> 4), cj = 16 * bj + (e & 15);
         if (ci < n_cols && cj < n_cols && (bi != bj || (e >> 4) >= (e & 15))) {
-            // 256^5 of the lowest class kept, 2^-k of both columns (all powers of two: exact)
-            v = v * 1099511627776.0 * rscale[ci] * rscale[cj];
+            // 256^I8_WLO of the lowest class kept, 2^-k of both columns (all powers of two: exact)
+            v = v * 65536.0 * rscale[ci] * rscale[cj];
+            static_assert(I8_WLO == 2, "65536 = 256^I8_WLO");
             out[(int64_t)ci * ldo + cj] = v;
             if (ci != cj) out[(int64_t)cj * ldo + ci] = v;
         }
     }
 }
 
-// The a-posteriori envelope check.  Column j is kept to 2^-46 of M_j = max|x_j| sqrt(max d), so an entry
-// out[j][k] carries an error of ~2^-46 M_j / ||sqrt(d) x_j|| of its natural scale ||sqrt(d) x_j|| ||sqrt(d) x_k||
-// -- and ||sqrt(d) x_j||^2 is the diagonal just computed.  Weights that are tiny exactly where a column
-// is large (ratio > 2^10) fall outside: the flag hands the call to the f64 kernel.
+// The a-posteriori envelope check (header: R_j^2 = colmax_j^2 dmax / out[j][j] <= min(64, 2^27 / n)); a
+// column that fails it hands the call to the f64 kernel.  (A column whose weighted norm is 0 has only
+// zero digits: exact, passes as 0 <= 0.)
 __global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, const double *__restrict__ colmax,
-                                   int m, I8Info *info) {
+                                   int m, int64_t n, I8Info *info) {
     const int j = threadIdx.x;
+#if defined(I8_TRACE)
+    return;
+#endif
     if (j >= m || info->flag != 0) return;
     const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
     const double big2 = colmax[j] * colmax[j] * dmax;
-    if (!(big2 <= 1048576.0 * out[(int64_t)j * ldo + j])) atomicOr(&info->flag, 2u);
+    const double bound = fmin(64.0, 134217728.0 / (double)n);
+    if (!(big2 <= bound * out[(int64_t)j * ldo + j])) atomicOr(&info->flag, 2u);
 }
 
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
@@ -565,7 +723,7 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
                        out, m);
-    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, info);
+    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, n, info);
     TM_LAUNCH_CHECK();
     // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
     prof_hold(true);               // (the event pair stays on the int8 kernel)
