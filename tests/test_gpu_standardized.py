@@ -220,7 +220,8 @@ def test_xtd_in_one_pass_without_a_complete_categorical(design):
     want = mat.transpose_matvec(d)
     assert float((xtd - want).abs().max() / want.abs().max()) < 1e-12
     full = mat.sandwich(d)
-    assert float((inner - full).abs().max() / full.abs().max()) < 1e-13
+    # (mat.sandwich takes the int8-sliced syrk for the dense block, the X'd form the f64 syrk)
+    assert float((inner - full).abs().max() / full.abs().max()) < 1e-12
     # and the standardized product built on it matches dense algebra
     Xh = np.empty(mat.shape)
     for m, ix in zip(mat.matrices, mat.indices):
