@@ -257,6 +257,15 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     advance();
     finish_slab(0);
     __syncthreads();
+#if defined(LG_ABLATE_NO_STREAM)      // (the re-used slots must not announce overflow entries)
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+        for (int c = 0; c < LG_CHUNKS; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pk[q][c] &= LG_KMASK;
+        }
+#endif
 
     unsigned slab_base = lds_base;                // LDS address of the current buffer
     unsigned next_base = lds_base + (unsigned)L::BUFB;
@@ -370,11 +379,19 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                 if (more) {
 #pragma unroll
                     for (int i = lg_piece_lo(cq, NV, NCQ); i < lg_piece_lo(cq + 1, NV, NCQ); ++i)
+#if !defined(LG_ABLATE_NO_COPY)       // timing only: the slab of B is not refreshed
                         issue_piece(buf ^ 1, i);
+#else
+                        (void)i;
+#endif
                 }
                 v = pv[q][c];
                 k = pk[q][c];
+#if defined(LG_ABLATE_NO_STREAM)      // timing only: every slab re-uses the first slab's slots (no stream traffic)
+                (void)0;
+#else
                 if (more) load_chunk(q, c);
+#endif
             };
             auto entry_of = [&](int pass, int &ec, int &eslot, F &eval) {
                 if (pass > 1) e = xent[rec0 + pass - 1];     // a second entry in a block is rare
