@@ -111,7 +111,7 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
     unsigned idNext;
     if (tid == 0) *slot = gridDim.x + atomicAdd(counter, 1u);
     __syncthreads();
-    idNext = *slot;
+    idNext = __builtin_amdgcn_readfirstlane(*slot);
     bool pending = false;
 
     // The raw f32 rows of a chunk come in by LDS-DMA (buffer_load ... lds: no registers, nobody waits for
@@ -126,7 +126,14 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
         const int64_t tb = (int64_t)id * BX_ITEM_ROWS + (int64_t)oL * BX_RS;
         // the chunk's rows that exist: everything beyond reads as 0 (rows >= n, columns >= m)
         const int64_t left = min((n - tb) * m * 4, (int64_t)BX_RS * m * 4);
-        const bx_rsrc_t rs = bx_rsrc(X + tb * m, left);
+        // (uniform by construction, but the 64-bit products are VALU work: without the readfirstlane the
+        // descriptor counts as divergent and every copy sits in a waterfall loop)
+        const uint64_t xb = (uint64_t)(uintptr_t)(X + tb * m);
+        const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xb);
+        const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+        const unsigned nbytes = __builtin_amdgcn_readfirstlane(
+            left <= 0 ? 0u : (left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)left));
+        const bx_rsrc_t rs = bx_rsrc(reinterpret_cast<const void *>((uintptr_t)(((uint64_t)xhi << 32) | xlo)), nbytes);
         // (d first: the wave that loads it then waits for it with the 4 younger copies still in flight)
         if (wave == 0 && lane < BX_RS) dreg = tb + lane < n ? d[tb + lane] : 0.0f;
 #pragma unroll
@@ -202,7 +209,7 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
         unsigned id_c1 = issue_chunk(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bx_lds_barrier();
-        if (pending) { idNext = *slot; pending = false; }
+        if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
         convert_begin(0);
         static_for<4>([&](auto kc) { convert_col(0, kc); });
         if (wave == 0 && lane < BX_RS) dl[BX_RS + lane] = dreg;           // d of chunk 1
@@ -210,7 +217,7 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
         while (id_c < (unsigned)n_items) {
             // ---- top: chunk c + 2 -> raw[par] (its rows were converted one iteration ago)
             bx_lds_barrier();                       // A: planes hold chunk c, raw[par] and dl are settled
-            if (pending) { idNext = *slot; pending = false; }
+            if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
             const unsigned id_c2 = issue_chunk(par);
             // sign masks of this lane's 8 rows (pairs of rows per register, as the bf16 are packed)
             const bx_f4 da = *reinterpret_cast<const bx_f4 *>(dl + par * BX_RS + 8 * (lane >> 4));
