@@ -118,16 +118,22 @@ int tm_dense_sandwich_co_f64(const double *X, int64_t n, int64_t m, const double
                              double *colsum, void *stream);
 
 /* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered f64 block of an even number m <= 128 of
- * columns on the INT8 matrix cores (Ozaki-style slicing): diag(sqrt d) X in 48-bit fixed point per
+ * columns on the INT8 matrix cores (Ozaki-style slicing): diag(sqrt d) X in 40-bit fixed point per
  * column (scale from colmax[i] = max_r |X[r][i]|, length m, computed once per block by the caller,
- * and from max d), six balanced base-256 digits per entry, the 21 leading digit-pair products
- * accumulated exactly in int32 with v_mfma_i32_16x16x64_i8 and folded into f64 every 2048 rows.
- * The weights are screened on the device: when one is negative or non-finite the same call runs the
- * f64 kernel of tm_dense_sandwich_co_f64 instead (no host synchronisation).  The caller vouches for the
- * block: finite values, max |x| of every column within 2^10 of its rms.  Replaces
- * _denseC_sandwich<int, double> (ext/dense_helpers-tmpl.cpp:266-311).  out (m, m) is overwritten. */
+ * and from max d), five balanced base-256 digits per entry, the 22 digit-pair products of weight
+ * >= 2^16 accumulated exactly in int32 with v_mfma_i32_16x16x64_i8 and folded into f64 every 2048
+ * rows (error ~2e-14 of max |out| on well-scaled data; model in csrc/syrk_i8.hip).  The part of
+ * the envelope that depends on d is checked on the device -- a negative or non-finite weight before
+ * the product, colmax_i^2 max(d) <= min(64, 2^27 / n) out[i][i] after it -- and a call outside it runs
+ * the f64 kernel of tm_dense_sandwich_co_f64 instead (no host synchronisation).  The caller vouches
+ * for finite X.  Replaces _denseC_sandwich<int, double> (ext/dense_helpers-tmpl.cpp:266-311).
+ * out (m, m) is overwritten.
+ * _xtd_: colsum (length m) = X' d from the same pass (replaces the transpose_matvec call of
+ * standardized_mat.py:149-150). */
 int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                              double *out, void *stream);
+int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                 double *out, double *colsum, void *stream);
 
 /* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered FLOAT32 block of m = 4 k <= 256 columns
  * on the bf16 matrix cores: every element of diag(sqrt|d|) X is split into three bf16 pieces (24

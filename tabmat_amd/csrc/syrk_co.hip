@@ -252,7 +252,9 @@ __global__ __launch_bounds__(1024) void syrk_co_finish_kernel(const double *__re
 
 __global__ __launch_bounds__(CO_W) void syrk_co_colsum_kernel(const double *__restrict__ cpart,
                                                               int nblk, int n_cols,
-                                                              double *__restrict__ colsum) {
+                                                              double *__restrict__ colsum,
+                                                              const unsigned *__restrict__ only_if) {
+    if (only_if != nullptr && *only_if == 0u) return;
     const int c = threadIdx.x;
     double a = 0.0;
     for (int b = 0; b < nblk; ++b) a += cpart[(int64_t)b * CO_W + c];
@@ -304,7 +306,7 @@ static int run_syrk_co_impl(const double *X, int64_t n, int64_t m, const double 
     TM_LAUNCH_CHECK();
     if (colsum) {
         hipLaunchKernelGGL(syrk_co_colsum_kernel, dim3(1), dim3(CO_W), 0, st, cpart, grid, (int)m,
-                           colsum);
+                           colsum, only_if);
         TM_LAUNCH_CHECK();
     }
     return TM_OK;
@@ -316,9 +318,9 @@ int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *
 }
 
 // the same launches, live only when *flag != 0 (device memory): the int8 syrk's fallback
-int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, const unsigned *flag,
-                        void *ws, hipStream_t st) {
-    return run_syrk_co_impl(X, n, m, d, out, nullptr, flag, ws, st);
+int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
+                        const unsigned *flag, void *ws, hipStream_t st) {
+    return run_syrk_co_impl(X, n, m, d, out, colsum, flag, ws, st);
 }
 
 }  // namespace tmh

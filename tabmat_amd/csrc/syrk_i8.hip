@@ -209,10 +209,15 @@ __global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, const 
 }
 
 // ---- the main kernel
+// CSUM: X' d (length m) comes out of the same pass -- the conversion forms x sqrt(d) for every entry anyway,
+// one more v_fma_f64 per entry accumulates (x sqrt d) sqrt d per lane in f64 (exact arithmetic on the raw
+// values, independent of the fixed-point envelope); StandardizedMatrix.sandwich then needs no second pass
+// (reference: standardized_mat.py:149-150 calls transpose_matvec).
+template <bool CSUM>
 __global__ __launch_bounds__(I8_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const double *__restrict__ d,
                     const double *__restrict__ sigma, const I8Info *__restrict__ info, int n_items,
-                    unsigned *__restrict__ counter, double *__restrict__ part) {
+                    unsigned *__restrict__ counter, double *__restrict__ part, double *__restrict__ colsum) {
     if (info->flag != 0) return;                                          // the f64 kernel takes this call
     // SEPARATE static LDS objects: the compiler tracks LDS-DMA copies per LDS variable (alias scopes of
     // the module-LDS lowering) and makes every LDS access that may alias a copy in flight wait for it
@@ -283,6 +288,7 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
 
     // this lane's two columns and their scales
     const double sg0 = sigma[32 * wave + cl], sg1 = sigma[32 * wave + 16 + cl];
+    double cs0 = 0.0, cs1 = 0.0;                                           // CSUM: this lane's share of X' d, columns cb = 0 / 1
     const double MAGIC = 6755399441055744.0 + 551911719040.0;             // 1.5 * 2^52 + 0x8080808080
     // one half chunk (ring slot rb) -> rows 32 hh .. 32 hh + 31 of the digit planes.  Per call: the
     // lane's 4 rows (quad qq of 8) of column block cb (0 / 1) -- 16 calls cover the half.
@@ -340,7 +346,12 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
             for (int j = 0; j < 4; ++j) c.dv[j] = dl[rb * I8_HS + row0 + j];
         } else if constexpr (k >= 1 && k <= 4) {
             const double sg = cb ? sg1 : sg0;
-            const double t = __builtin_fma(q.x[k - 1] * c.dv[k - 1], sg, MAGIC);
+            const double u = q.x[k - 1] * c.dv[k - 1];
+            const double t = __builtin_fma(u, sg, MAGIC);
+            if constexpr (CSUM) {
+                if constexpr (cb) cs1 = __builtin_fma(u, c.dv[k - 1], cs1);
+                else cs0 = __builtin_fma(u, c.dv[k - 1], cs0);
+            }
             c.lo[k - 1] = (unsigned)__double2loint(t);
             c.hi[k - 1] = (unsigned)__double2hiint(t);
         } else if constexpr (k == 5) {              // 4 rows x 4 digit bytes -> 4 digits x 4 row bytes
@@ -624,6 +635,17 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
     else if (wave == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 3>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (copies of halves beyond the end are still in flight)
+    if constexpr (CSUM) {
+        // lane (cl, rq) holds the rows 4 (rq + 4 qq) .. of its two columns: sum over the 4 row quads
+        cs0 += __shfl_xor(cs0, 16, 64);
+        cs0 += __shfl_xor(cs0, 32, 64);
+        cs1 += __shfl_xor(cs1, 16, 64);
+        cs1 += __shfl_xor(cs1, 32, 64);
+        if (lane < 16) {
+            if (32 * wave + cl < m) atomicAdd(colsum + 32 * wave + cl, cs0);
+            if (32 * wave + 16 + cl < m) atomicAdd(colsum + 32 * wave + 16 + cl, cs1);
+        }
+    }
 }
 
 // out[i][j] = 2^-(k_i + k_j) * sum over the workgroups' partials, mirrored; a quarter tile per block
@@ -681,20 +703,22 @@ __global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, 
 }
 
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
-int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, const unsigned *flag,
-                        void *ws, hipStream_t st);
+int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
+                        const unsigned *flag, void *ws, hipStream_t st);
 size_t syrk_co_ws_bytes();
 
 int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
-                hipStream_t st) {
+                double *colsum, hipStream_t st) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m), "the int8 syrk takes a 16-byte aligned C-ordered f64 block of an "
                                            "even number of columns <= 128");
     if (m == 0) return TM_OK;
     if (n == 0) {
         TM_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(m * m), st));
+        if (colsum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(double) * (size_t)m, st));
         return TM_OK;
     }
+    if (colsum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(double) * (size_t)m, st));
     const int64_t n_items64 = ceil_div(n, I8_ITEM_ROWS);
     TM_REQUIRE(n_items64 < (1ll << 31), "too many rows");
     const int n_items = (int)n_items64;
@@ -717,8 +741,12 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, info, sigma, rscale);
     TM_LAUNCH_CHECK();
     prof_begin(st);
-    hipLaunchKernelGGL(syrk_i8_kernel, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma, info,
-                       n_items, counter, part);
+    if (colsum)
+        hipLaunchKernelGGL(syrk_i8_kernel<true>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma,
+                           info, n_items, counter, part, colsum);
+    else
+        hipLaunchKernelGGL(syrk_i8_kernel<false>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma,
+                           info, n_items, counter, part, colsum);
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
@@ -727,7 +755,7 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     TM_LAUNCH_CHECK();
     // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
     prof_hold(true);               // (the event pair stays on the int8 kernel)
-    rc = run_syrk_co_flagged(X, n, m, d, out, &info->flag, wb + own_bytes, st);
+    rc = run_syrk_co_flagged(X, n, m, d, out, colsum, &info->flag, wb + own_bytes, st);
     prof_hold(false);
     return rc;
 }
@@ -738,7 +766,12 @@ extern "C" {
 
 int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                              double *out, void *stream) {
-    return tmh::run_syrk_i8(X, n, m, d, colmax, out, tmh::as_stream(stream));
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, nullptr, tmh::as_stream(stream));
+}
+
+int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                 double *out, double *colsum, void *stream) {
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, tmh::as_stream(stream));
 }
 
 }  // extern "C"

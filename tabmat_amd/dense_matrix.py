@@ -194,6 +194,20 @@ class DenseMatrix(MatrixBase):
                 return xd.dense_sandwich_i8(self._dev_c(), d, cmax)
         return xd.dense_sandwich(self._dev_c(), d, rows, cols)
 
+    def _sandwich_xtd_dev(self, d):
+        """(X' diag(d) X, X' d) of the unrestricted block in ONE pass over it, or None when no
+        one-pass kernel takes the block (then the caller makes the reference's second pass,
+        standardized_mat.py:149-150): the int8-sliced syrk (K1e) inside its envelope, else the f64
+        syrk with the column sums of its A-side fragments (K1c)."""
+        blk = self._dev_c()
+        if d.dtype == torch.float64:
+            cmax = self._i8_colmax()
+            if cmax is not None:
+                return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True)
+        if xd.co_supported(blk, d):
+            return xd.dense_sandwich_co(blk, d, want_colsum=True)
+        return None
+
     def sandwich(self, d, rows=None, cols=None):
         """X[rows, cols].T @ diag(d[rows]) @ X[rows, cols] (dense_matrix.py:153-163)."""
         on_dev = D.is_dev(d)

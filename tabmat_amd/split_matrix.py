@@ -856,9 +856,10 @@ class SplitMatrix(MatrixBase):
                     if i not in diag_scattered:
                         xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
                 elif (colsum is not None and colsum[i] is None and isinstance(mi, DenseMatrix)
-                      and rows is None and sub_d[i] is None and xd.co_supported(mi._dev_c(), d)):
-                    # X_dense' d comes out of the syrk's A-side fragments (csrc/syrk_co.hip)
-                    res, colsum[i] = xd.dense_sandwich_co(mi._dev_c(), d, want_colsum=True)
+                      and rows is None and sub_d[i] is None
+                      and (both := mi._sandwich_xtd_dev(d)) is not None):
+                    # X_dense' d comes out of the syrk's own pass (csrc/syrk_i8.hip, csrc/syrk_co.hip)
+                    res, colsum[i] = both
                     xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
                 else:
                     res = mi._sandwich_dev(d, rows, sub_d[i])

@@ -123,10 +123,10 @@ class StandardizedMatrix:
         from .dense_matrix import DenseMatrix
         from .ext import dense as xd
 
-        if (isinstance(mat, DenseMatrix) and rows_d is None and cols_d is None
-                and xd.co_supported(mat._dev_c(), d)):
-            inner, xtd = xd.dense_sandwich_co(mat._dev_c(), d, want_colsum=True)   # one pass
-            return inner, None, xtd
+        if isinstance(mat, DenseMatrix) and rows_d is None and cols_d is None:
+            both = mat._sandwich_xtd_dev(d)                                       # one pass
+            if both is not None:
+                return both[0], None, both[1]
         inner = mat._sandwich_dev(d, rows_d, cols_d).to(torch.float64)
         xtd = mat._matvec_dev(d, rows_d, cols_d, None, True).to(torch.float64)
         return inner, None, xtd

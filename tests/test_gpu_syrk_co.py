@@ -26,7 +26,11 @@ def _tune(key, value):
 
 
 @pytest.fixture
-def knobs():
+def knobs(monkeypatch):
+    # (the int8-sliced syrk would take these blocks first: K1c is its fallback and the X'd form)
+    import tabmat_amd.dense_matrix as dmod
+
+    monkeypatch.setattr(dmod, "SYRK_I8", False)
     yield _tune
     for k, v in (("co_grid", 768), ("syrk_co", 1), ("wg_log", 0)):
         _tune(k, v)
@@ -86,7 +90,7 @@ def test_syrk_co_is_the_default_f64_path_and_matches_plain(knobs):
     assert rel_err(a, b) < 1e-13
 
 
-def test_zero_weight_rows_and_empty():
+def test_zero_weight_rows_and_empty(knobs):
     import tabmat_amd as tm
 
     rng = np.random.default_rng(4)

@@ -17,13 +17,16 @@ def _orc():
     return orc
 
 
-def _run(X, d):
+def _run(X, d, want_colsum=False):
     from tabmat_amd.ext import dense as xd
     from tabmat_amd.ext._types import DenseDev
 
     Xd = DenseDev.from_host(X)
     cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
-    return xd.dense_sandwich_i8(Xd, torch.from_numpy(d).cuda(), cmax).cpu().numpy()
+    res = xd.dense_sandwich_i8(Xd, torch.from_numpy(d).cuda(), cmax, want_colsum)
+    if want_colsum:
+        return res[0].cpu().numpy(), res[1].cpu().numpy()
+    return res.cpu().numpy()
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 2047, 2048, 2049, 10_000, 131_075])
@@ -93,3 +96,16 @@ def test_i8_hand_over_when_the_weights_hide_a_columns_large_entries():
     ref2 = _orc().dense_sandwich(X, d2, None, None)
     scale2 = np.sqrt(np.outer(np.diag(ref2), np.diag(ref2)))
     assert float((np.abs(out2 - ref2) / scale2).max()) < 1e-10
+
+
+@pytest.mark.parametrize("n,m", [(1, 66), (4097, 128), (20_000, 100), (131_075, 128)])
+def test_i8_column_sums_from_the_same_pass(n, m):
+    """tm_dense_sandwich_i8_xtd_f64: X' d next to the product (f64 arithmetic on the raw values), also
+    when the call is handed over to the f64 kernel."""
+    rng = np.random.default_rng(n + m)
+    X = rng.standard_normal((n, m)) * rng.lognormal(0, 2, m)
+    for d in (rng.random(n), rng.random(n) - 0.3):            # inside the envelope / negative weights
+        out, cs = _run(X, d, want_colsum=True)
+        assert rel_err(out, _orc().dense_sandwich(X, d, None, None)) < 1e-10
+        want = X.T @ d
+        assert np.abs(cs - want).max() <= 1e-12 * (np.abs(X).T @ np.abs(d)).max()
