@@ -327,6 +327,23 @@ int tm_csr_dense_sandwich_lg_xtd_f64(const double *vals, const uint32_t *koff, c
                                      const double *B, int64_t r, const double *d, int unconditional,
                                      double *out, double *colsum, void *stream);
 
+/* The same product on the COMPACT lane-group stream (round 3: 2.7 instead of 7.7 GB at BASELINE configs[3]):
+ * cvals F[real slots + 1]: the values of the real (non-padding) slots of round 0 only, block after block,
+ *   inside a block chunk after chunk in slot order;
+ * cmap uint8 [S * G][32 slots][4 chunks]: 1 + row in slab of the slot's nonzero, 0 = padding (the kernel
+ *   reads one dword per lane: the four chunks of its slot);
+ * crec int64 [S * G][2]: {index of the block's first value in cvals, number of overflow entries of the
+ *   block | index of its first overflow entry << 32};
+ * xkoff: the overflow entries of tm_csr_dense_sandwich_lg_* (unchanged).  colsum (length m, kernel column
+ * order, A' d from the same pass) may be NULL. */
+int tm_csr_dense_sandwich_lgc_f32(const float *cvals, const uint32_t *cmap, const int64_t *crec,
+                                  const uint32_t *xkoff, int64_t n, int64_t m, const float *B, int64_t r,
+                                  const float *d, int unconditional, float *out, float *colsum, void *stream);
+int tm_csr_dense_sandwich_lgc_f64(const double *cvals, const uint32_t *cmap, const int64_t *crec,
+                                  const uint32_t *xkoff, int64_t n, int64_t m, const double *B, int64_t r,
+                                  const double *d, int unconditional, double *out, double *colsum,
+                                  void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

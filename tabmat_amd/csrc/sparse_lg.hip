@@ -126,7 +126,17 @@ __device__ __forceinline__ void lg_fmac(float &acc, float a, float x) {
 // `value * d` is formed for every slot anyway, one v_add per chunk accumulates it per lane, the 8
 // positions of a column are summed at the end.  StandardizedMatrix.sandwich then needs no second
 // pass over the sparse block (reference: standardized_mat.py:149-150 calls transpose_matvec).
-template <typename F, int UNC, int NG, bool CSUM>
+//
+// CP = true: the COMPACT stream (round 3).  The padded stream spends 12 bytes on every slot, 60 % of them
+// padding at 5 % density (7.7 GB at cfg4 for 3.1 GB of nonzeros).  Compact form of a (slab, group) block:
+//   cmap  uint8 [32 slots][4 chunks]   1 + row in slab of the slot's nonzero, 0 = padding (one dword per lane)
+//   cvals F[...]                        the values of the block's real slots only, chunk after chunk in slot order
+//   crec  {int64 first value, uint32 overflow entries, uint32 first entry}   one 16-byte record per block
+// (passed through the vals / koff / xptr arguments).  A lane finds its value at first + (real slots of the
+// earlier chunks) + (real slots below its own in the chunk): one ballot + two popcounts per chunk.  The
+// map of slab w + 2 and the record of slab w + 2 (a SCALAR load) are requested at the top of slab w, the
+// values of slab w + 1 between the chunks of slab w as before: 2.7 GB instead of 7.7.
+template <typename F, int UNC, int NG, bool CSUM, bool CP = false>
 __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     const F *__restrict__ vals, const unsigned *__restrict__ koff, const int64_t *__restrict__ xptr,
     const F *__restrict__ xvals, const unsigned *__restrict__ xkoff, int n_groups, int64_t n_slabs,
@@ -202,6 +212,11 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     const int64_t sstride = (int64_t)n_groups * (LG_CHUNKS * LG_SLOTS);
     const F *vnext = vals + (s0 * n_groups + group) * (int64_t)(LG_CHUNKS * LG_SLOTS);
     const unsigned *knext = koff + (s0 * n_groups + group) * (int64_t)(LG_CHUNKS * LG_SLOTS);
+    // compact stream: map dwords and block records of the slab whose map is requested next
+    static_assert(!CP || NG == 1, "compact stream: one group per wave");
+    const unsigned *mnext = koff + (s0 * n_groups + group) * (int64_t)LG_SLOTS;
+    const int64_t *rnext = xptr + (s0 * n_groups + group) * (int64_t)2;
+    constexpr int KSH = RSB == 1024 ? 10 : 9;     // koff = (1 + row) << KSH
 
     F dsc = F(0);
     // `which` = index of the slab inside the workgroup's range (0 .. ns - 1)
@@ -226,6 +241,26 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         vnext += sstride;
         knext += sstride;
     };
+    // ---- compact stream state: maps of the current / next / next-but-one slab, records likewise
+    // (the record travels as one dword per lane -- lane & 3 -- and is taken apart with v_readlane when its
+    // slab comes up: decoded where it is loaded, the compiler waits for the load at once)
+    unsigned mcur = 0u, mnxt = 0u, mnx2 = 0u, rv_nxt = 0u, rv_nx2 = 0u;
+    int64_t vb_nxt = 0;                          // first value of the next slab's block (uniform)
+    unsigned nrec_cur = 0u, rec0_cur = 0u, nrec_nxt = 0u, rec0_nxt = 0u;
+    int cpre = 0;                                // real slots of the chunks already requested (uniform)
+    auto load_map = [&](unsigned &mm, unsigned &rv) {
+        mm = mnext[lane32];
+        rv = reinterpret_cast<const unsigned *>(rnext)[lane & 3];
+        mnext += (int64_t)n_groups * LG_SLOTS;
+        rnext += (int64_t)n_groups * 2;
+    };
+    auto decode_nxt = [&]() {                    // the record of the slab whose values are requested next
+        vb_nxt = (int64_t)(((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)rv_nxt, 1) << 32) |
+                           (unsigned)__builtin_amdgcn_readlane((int)rv_nxt, 0));
+        nrec_nxt = (unsigned)__builtin_amdgcn_readlane((int)rv_nxt, 2);
+        rec0_nxt = (unsigned)__builtin_amdgcn_readlane((int)rv_nxt, 3);
+        cpre = 0;
+    };
 
     // the four chunks of round 0 of the NEXT slab, requested while the current one is worked on
     F pv[NG][LG_CHUNKS];
@@ -239,8 +274,19 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     for (int q = 0; q < NG; ++q) act[q] = group + q * NWV < n_groups;
     auto load_chunk = [&](int q, int c) {
         if (act[q]) {
-            pv[q][c] = vnext[(q * NWV * LG_CHUNKS + c) * LG_SLOTS + lane32];
-            pk[q][c] = knext[(q * NWV * LG_CHUNKS + c) * LG_SLOTS + lane32];
+            if constexpr (CP) {
+                // value of this lane's slot in chunk c of the NEXT slab (map mnxt, first value vb_nxt)
+                const bool real = ((mnxt >> (8 * c)) & 0xffu) != 0u;
+                const unsigned long long b = __builtin_amdgcn_ballot_w64(real);
+                const unsigned m32 = ((unsigned)b & 0xFFFFu) | (((unsigned)(b >> 32) & 0xFFFFu) << 16);
+                const int rank = __builtin_popcount(m32 & ((1u << lane32) - 1u));
+                const int idx = real ? cpre + rank : 0;          // (padding: any valid address; masked on use)
+                pv[q][c] = vals[vb_nxt + idx];
+                cpre += __builtin_popcount(m32);
+            } else {
+                pv[q][c] = vnext[(q * NWV * LG_CHUNKS + c) * LG_SLOTS + lane32];
+                pk[q][c] = knext[(q * NWV * LG_CHUNKS + c) * LG_SLOTS + lane32];
+            }
         }
     };
 
@@ -249,10 +295,20 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     for (int i = 0; i < NV; ++i) issue_piece(0, i);
     load_d();
     if (active) {
+        if constexpr (CP) {
+            // maps / records of slabs 0 and 1; the values of slab 0 (addressed through its map)
+            load_map(mnxt, rv_nxt);
+            if (ns > 1) load_map(mnx2, rv_nx2);
+            decode_nxt();
+        }
 #pragma unroll
         for (int q = 0; q < NG; ++q)
 #pragma unroll
             for (int c = 0; c < LG_CHUNKS; ++c) load_chunk(q, c);
+        if constexpr (CP) {
+            mcur = mnxt; nrec_cur = nrec_nxt; rec0_cur = rec0_nxt;
+            mnxt = mnx2; rv_nxt = rv_nx2;
+        }
     }
     advance();
     finish_slab(0);
@@ -280,6 +336,10 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         const int buf = w & 1;
         const bool more = w + 1 < ns;
         if (more) load_d();
+        if constexpr (CP) {
+            if (active && more) decode_nxt();    // (its map and record were requested a slab ago)
+            if (active && w + 2 < ns) load_map(mnx2, rv_nx2);
+        }
         int pseen = 0x7fffffff;
         if (my_prog != nullptr && tid == 0 && gridDim.z > 1)
             pseen = __hip_atomic_load(my_prog + zn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -300,6 +360,7 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                 if (comb == 0u) return;
                 const F dk = dl[kk >> (RSB == 1024 ? 10 : 9)];          // row = kk / RSB
                 F a = v * dk;
+                if constexpr (CP) a = kk != 0u ? a : F(0);               // (compact stream: no zero stored for padding)
                 if constexpr (CSUM) csum[q][c] += a;                     // (padding: v = 0, dk = d[-1] = 0)
                 unsigned kq = slab_base + (dk != F(0) ? kk : 0u);      // absolute LDS address
                 // DPP reads of a VGPR need two wait states after the VALU write
@@ -362,14 +423,21 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
             static_for<NG>([&](auto qc_) {
             constexpr int q = decltype(qc_)::value;
             if (!act[q]) return;
-            const int nrec = __builtin_amdgcn_readlane((int)pk[q][0], 0) >> 20 & 0xFFF;
+            int nrec;
             int64_t rec0 = 0;
             uint4 e = uint4{0u, 0u, 0u, 0u};
-            if (nrec > 0) {
-                rec0 = (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 1) >> 20) |
-                       (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 2) >> 20) << 12 |
-                       (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 3) >> 20) << 24;
-                e = xent[rec0];
+            if constexpr (CP) {
+                nrec = (int)nrec_cur;
+                rec0 = (int64_t)rec0_cur;
+                if (nrec > 0) e = xent[rec0];
+            } else {
+                nrec = __builtin_amdgcn_readlane((int)pk[q][0], 0) >> 20 & 0xFFF;
+                if (nrec > 0) {
+                    rec0 = (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 1) >> 20) |
+                           (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 2) >> 20) << 12 |
+                           (int64_t)((unsigned)__builtin_amdgcn_readlane((int)pk[q][0], 3) >> 20) << 24;
+                    e = xent[rec0];
+                }
             }
             // pass 0 of chunk c (shared by both forms)
             auto round0 = [&](auto cc_, F &v, unsigned &k) {
@@ -385,8 +453,13 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
                         (void)i;
 #endif
                 }
-                v = pv[q][c];
-                k = pk[q][c];
+                if constexpr (CP) {
+                    k = ((mcur >> (8 * c)) & 0xffu) << KSH;
+                    v = pv[q][c];                 // (a padding slot holds SOME value of the block: masked in do_chunk)
+                } else {
+                    v = pv[q][c];
+                    k = pk[q][c];
+                }
 #if defined(LG_ABLATE_NO_STREAM)      // timing only: every slab re-uses the first slab's slots (no stream traffic)
                 (void)0;
 #else
@@ -428,6 +501,10 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
         if (more) {
             advance();
             finish_slab(buf ^ 1);
+        }
+        if constexpr (CP) {
+            mcur = mnxt; nrec_cur = nrec_nxt; rec0_cur = rec0_nxt;
+            mnxt = mnx2; rv_nxt = rv_nx2;
         }
         if (my_prog != nullptr && tid == 0 && gridDim.z > 1) {
             __hip_atomic_store(my_prog + blockIdx.z, w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -515,7 +592,7 @@ __global__ void lg_csum_kernel(const F *__restrict__ part, int nblk, int64_t m, 
 template <typename F>
 static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *xptr, const F *xvals,
                             const unsigned *xkoff, int64_t n, int64_t m, const F *B, int64_t r,
-                            const F *d, int unc, F *out, F *colsum, hipStream_t st) {
+                            const F *d, int unc, F *out, F *colsum, bool compact, hipStream_t st) {
     const int64_t nB = r;
     const int64_t total = m * nB;
     if (total == 0) return TM_OK;
@@ -568,6 +645,11 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     auto kern = want_csum ? (unc >= 4 && sizeof(F) == 4 ? &csr_dense_lg_kernel<F, 4, 1, true>
                                                         : &csr_dense_lg_kernel<F, 2, 1, true>)
                           : (unc >= 4 ? &csr_dense_lg_kernel<F, 4, 1, false> : &csr_dense_lg_kernel<F, 2, 1, false>);
+    if (compact)       // (vals / koff / xptr carry cvals / cmap / crec)
+        kern = want_csum ? (unc >= 4 && sizeof(F) == 4 ? &csr_dense_lg_kernel<F, 4, 1, true, true>
+                                                       : &csr_dense_lg_kernel<F, 2, 1, true, true>)
+                         : (unc >= 4 ? &csr_dense_lg_kernel<F, 4, 1, false, true>
+                                     : &csr_dense_lg_kernel<F, 2, 1, false, true>);
     const int threads = LG_THREADS;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -604,14 +686,14 @@ int tm_csr_dense_sandwich_lg_f32(const float *vals, const uint32_t *koff, const 
                                  const float *B, int64_t r, const float *d, int unconditional,
                                  float *out, void *stream) {
     return tmh::run_csr_dense_lg<float>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d, unconditional,
-                                        out, nullptr, tmh::as_stream(stream));
+                                        out, nullptr, false, tmh::as_stream(stream));
 }
 int tm_csr_dense_sandwich_lg_f64(const double *vals, const uint32_t *koff, const int64_t *xptr,
                                  const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
                                  const double *B, int64_t r, const double *d, int unconditional,
                                  double *out, void *stream) {
     return tmh::run_csr_dense_lg<double>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d,
-                                         unconditional, out, nullptr, tmh::as_stream(stream));
+                                         unconditional, out, nullptr, false, tmh::as_stream(stream));
 }
 /* the same pass, additionally colsum (length m, kernel column order) = A' d */
 int tm_csr_dense_sandwich_lg_xtd_f32(const float *vals, const uint32_t *koff, const int64_t *xptr,
@@ -623,7 +705,7 @@ int tm_csr_dense_sandwich_lg_xtd_f32(const float *vals, const uint32_t *koff, co
         return TM_EINVAL;
     }
     return tmh::run_csr_dense_lg<float>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d, unconditional,
-                                        out, colsum, tmh::as_stream(stream));
+                                        out, colsum, false, tmh::as_stream(stream));
 }
 int tm_csr_dense_sandwich_lg_xtd_f64(const double *vals, const uint32_t *koff, const int64_t *xptr,
                                      const double *xvals, const uint32_t *xkoff, int64_t n, int64_t m,
@@ -634,7 +716,26 @@ int tm_csr_dense_sandwich_lg_xtd_f64(const double *vals, const uint32_t *koff, c
         return TM_EINVAL;
     }
     return tmh::run_csr_dense_lg<double>(vals, koff, xptr, xvals, xkoff, n, m, B, r, d,
-                                         unconditional, out, colsum, tmh::as_stream(stream));
+                                         unconditional, out, colsum, false, tmh::as_stream(stream));
+}
+
+
+/* the compact stream (round 3): cvals = the values of the real slots only, cmap = uint8 [block][32 slots][4
+ * chunks] (1 + row in slab, 0 = padding) read as one dword per lane, crec = int64 [block][2] {index of the
+ * block's first value in cvals, overflow entries | first overflow entry << 32}; xkoff as above.
+ * colsum may be NULL. */
+int tm_csr_dense_sandwich_lgc_f32(const float *cvals, const uint32_t *cmap, const int64_t *crec,
+                                  const uint32_t *xkoff, int64_t n, int64_t m, const float *B, int64_t r,
+                                  const float *d, int unconditional, float *out, float *colsum, void *stream) {
+    return tmh::run_csr_dense_lg<float>(cvals, cmap, crec, nullptr, xkoff, n, m, B, r, d, unconditional, out,
+                                        colsum, true, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_lgc_f64(const double *cvals, const uint32_t *cmap, const int64_t *crec,
+                                  const uint32_t *xkoff, int64_t n, int64_t m, const double *B, int64_t r,
+                                  const double *d, int unconditional, double *out, double *colsum,
+                                  void *stream) {
+    return tmh::run_csr_dense_lg<double>(cvals, cmap, crec, nullptr, xkoff, n, m, B, r, d, unconditional, out,
+                                         colsum, true, tmh::as_stream(stream));
 }
 
 }  // extern "C"

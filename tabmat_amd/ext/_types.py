@@ -408,6 +408,40 @@ class SlabLg:
     m: int
     mk: int                # kernel rows = G * C
     unc: int               # positions per column run without a test (2 or 4)
+    # compact form (tm_csr_dense_sandwich_lgc_*), set by compact_(): vals / koff / xptr are dropped
+    cvals: torch.Tensor = None   # F[real slots + 1]
+    cmap: torch.Tensor = None    # uint8[S * G, 32, 4]   1 + row in slab, 0 = padding
+    crec: torch.Tensor = None    # int64[S * G, 2]       {first value, entries | first entry << 32}
+
+    @property
+    def dtype(self):
+        return (self.cvals if self.vals is None else self.vals).dtype
+
+    def compact_(self) -> "SlabLg":
+        """Rewrites round 0 in place as the compact stream of tm_csr_dense_sandwich_lgc_*: the
+        values of the real slots only (block after block, chunk after chunk, slot order), one
+        byte per slot (1 + row in slab, 0 = padding) laid out [slot][chunk] so that a lane reads
+        the four chunks of its slot as one dword, and a 16-byte record per block.  At 5 % density
+        40 % of the slots are real: 12 bytes per slot become 8 x 0.4 + 1 + 16 / 128."""
+        from .._lib import lib
+
+        if self.cvals is not None:
+            return self
+        CH, SL = 4, 32
+        nblk = int(self.koff.numel()) // (CH * SL)
+        rowb = int(lib().tm_lg_row_bytes(self.vals.element_size()))
+        k = torch.bitwise_and(self.koff, 0xFFFFF)
+        real = k != 0
+        cvals = torch.cat([self.vals[real], torch.zeros(1, dtype=self.vals.dtype, device=self.vals.device)])
+        cnt = real.view(nblk, CH * SL).sum(dim=1, dtype=torch.int64)
+        first = torch.cumsum(cnt, dim=0) - cnt
+        cmap = torch.div(k, rowb, rounding_mode="floor").to(torch.uint8).view(nblk, CH, SL) \
+            .permute(0, 2, 1).contiguous()
+        nrec = self.xptr[1:] - self.xptr[:-1]
+        crec = torch.stack([first, nrec | (self.xptr[:-1] << 32)], dim=1).contiguous()
+        self.cvals, self.cmap, self.crec = cvals.contiguous(), cmap, crec
+        self.vals = self.koff = None
+        return self
 
     @staticmethod
     def from_csr(csr: CsrDev, max_pad: float = None, max_extra: float = 0.25) -> "SlabLg":

@@ -119,24 +119,32 @@ def csr_dense_sandwich_ell(A: SlabEll, B: DenseDev, d):
 
 def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None, want_colsum=False):
     """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B of
-    more than 64 columns: lane-group twin, DPP-broadcast gather (csrc/sparse_lg.hip).
+    more than 64 columns: lane-group twin, DPP-broadcast gather (csrc/sparse_lg.hip), on the
+    compact stream (tm_csr_dense_sandwich_lgc_*) when the twin has been compacted.
     want_colsum: returns (out, A' d) -- the column sums ride along in the same pass."""
     assert B.n == A.n and ell_supported(B)
+    dt = A.dtype
     if A.m == 0 or B.m == 0 or A.n == 0:
-        z = D.zeros((A.m, B.m), A.vals.dtype)
-        return (z, D.zeros((A.m,), A.vals.dtype)) if want_colsum else z
-    out = D.out_buf((A.mk, B.m), A.vals.dtype)
-    D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
+        z = D.zeros((A.m, B.m), dt)
+        return (z, D.zeros((A.m,), dt)) if want_colsum else z
+    out = D.out_buf((A.mk, B.m), dt)
     u = int(A.unc if unc is None else unc)
-    if want_colsum:
-        cs = D.out_buf((A.mk,), A.vals.dtype)
+    cs = D.out_buf((A.mk,), dt) if want_colsum else None
+    if A.cvals is not None:
+        D.same_float("csr_dense_sandwich_lg", A.cvals, B.buf, d)
+        call("tm_csr_dense_sandwich_lgc_" + D.fsuf(A.cvals), D.p(A.cvals), D.p(A.cmap), D.p(A.crec),
+             D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.p(cs), D.stream_ptr())
+    elif want_colsum:
+        D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
         call("tm_csr_dense_sandwich_lg_xtd_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
              D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.p(cs),
              D.stream_ptr())
-        return out[A.inv], cs[A.inv]
-    call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
-         D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.stream_ptr())
-    return out[A.inv]      # kernel rows are the density-sorted columns
+    else:
+        D.same_float("csr_dense_sandwich_lg", A.vals, B.buf, d)
+        call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
+             D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.stream_ptr())
+    # kernel rows are the density-sorted columns
+    return (out[A.inv], cs[A.inv]) if want_colsum else out[A.inv]
 
 
 def _row_table(A: CsrDev, rows, d, as_set: bool):

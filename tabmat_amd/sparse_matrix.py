@@ -27,6 +27,9 @@ from .util import (
 # The interleaved-ELL twin pads every non-empty (slab, column group) to whole 64-slot iterations
 # (x1.9 .. x2.5 at 5 % density); beyond this factor the compact slab stream is used instead.
 ELL_MAX_PAD = 8.0
+# K3's lane-group stream in its compact form (values of the real slots + a byte map: 2.7 instead of 7.7 GB at
+# BASELINE configs[3]); TABMAT_AMD_LG_COMPACT=0 keeps the padded stream of round 2
+LG_COMPACT = os.environ.get("TABMAT_AMD_LG_COMPACT", "1") != "0"
 # A row restriction with at most this fraction of the rows runs the row-list kernels (cost
 # proportional to len(rows)); above it the full-pass kernels with a masked d are cheaper
 # (scripts/dev/time_rows.py: break-even near one half for the self sandwich, one quarter for the
@@ -150,6 +153,8 @@ class SparseMatrix(MatrixBase):
         64 columns); None when the block is too sparse or too dense for it."""
         if getattr(self, "_lgblk", None) is None:
             twin = SlabLg.from_csr(self._dev(), max_pad=ELL_MAX_PAD)
+            if twin is not None and LG_COMPACT:
+                twin.compact_()
             self._lgblk = twin if twin is not None else False
         return self._lgblk if self._lgblk is not False else None
 

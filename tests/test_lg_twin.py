@@ -83,6 +83,48 @@ def test_twin_decodes_to_the_matrix(n, m, density, dtype):
     assert tw.unc in (2, 4)
 
 
+def _decode_compact(tw: SlabLg):
+    """(kernel column, row, value, position) of round 0 as the kernel reads the COMPACT stream."""
+    R, C, CH, SL = 64, 16, 4, 32
+    G = tw.mk // C
+    S = (tw.n + R - 1) // R
+    cvals, cmap, crec = tw.cvals.numpy(), tw.cmap.numpy(), tw.crec.numpy()
+    assert cmap.shape == (S * G, SL, CH) and crec.shape == (S * G, 2)
+    out = []
+    for blk in range(S * G):
+        s, g = divmod(blk, G)
+        nxt = int(crec[blk, 0])
+        for c in range(CH):
+            for slot in range(SL):
+                b = int(cmap[blk, slot, c])
+                if b == 0:
+                    continue
+                h, jl, it = slot // 16, (slot % 16) // 8, slot % 8
+                out.append((g * C + 8 * h + 2 * c + jl, s * R + b - 1, float(cvals[nxt]), it))
+                nxt += 1
+        assert nxt == (int(crec[blk + 1, 0]) if blk + 1 < S * G else len(cvals) - 1)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,density", [(300, 40, 0.05), (64, 16, 0.5), (129, 33, 0.2), (1000, 512, 0.02)])
+def test_compact_twin_holds_the_same_round_0(n, m, density, dtype):
+    """compact_(): values of the real slots only + a byte per slot + a record per block -- the same
+    (column, row, value, position) set as the padded stream, the overflow entries untouched."""
+    rng = np.random.default_rng(n + 3 * m)
+    S = sps.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
+    S.data += 0.5
+    tw = SlabLg.from_csr(_csr_cpu(S, dtype), max_pad=None, max_extra=None)
+    padded = [t for t in _decode(tw, np.dtype(dtype).itemsize) if t[3] < 8]
+    xptr = tw.xptr.numpy().copy()
+    tw.compact_()
+    assert tw.vals is None and tw.koff is None and tw.dtype == torch.from_numpy(np.zeros(1, dtype)).dtype
+    assert sorted(_decode_compact(tw)) == sorted(padded)
+    rec = tw.crec.numpy()[:, 1]
+    np.testing.assert_array_equal(rec & 0xFFFFFFFF, xptr[1:] - xptr[:-1])
+    np.testing.assert_array_equal((rec >> 32)[(rec & 0xFFFFFFFF) > 0], xptr[:-1][(rec & 0xFFFFFFFF) > 0])
+
+
 def test_twin_gives_up_outside_its_regime():
     rng = np.random.default_rng(0)
     S = sps.random(64 * 1200, 512, density=0.0005, format="csr", random_state=rng)
@@ -95,10 +137,11 @@ def test_twin_gives_up_outside_its_regime():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("unc", [2, 4])
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("n,m,k,density", [(20_000, 512, 128, 0.05), (777, 40, 72, 0.1),
                                            (64, 16, 128, 0.5), (4099, 100, 200, 0.3),
                                            (30_000, 300, 256, 0.01), (129, 7, 68, 1.0)])
-def test_lg_kernel_matches_oracle(n, m, k, density, unc, dtype):
+def test_lg_kernel_matches_oracle(n, m, k, density, unc, compact, dtype):
     import tabmat_amd as tm
     from oracle import oracle as orc
     from tabmat_amd import _device as D
@@ -114,6 +157,8 @@ def test_lg_kernel_matches_oracle(n, m, k, density, unc, dtype):
     B[d == 0] = np.inf                           # ... and must not leak inf * 0
     sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
     tw = SlabLg.from_csr(sm._dev(), max_pad=None, max_extra=None)
+    if compact:
+        tw.compact_()
     got = D.to_host(xs.csr_dense_sandwich_lg(tw, dm._dev_c(), D.to_dev(d), unc=unc))
     Bz = B.copy()
     Bz[d == 0] = 0
