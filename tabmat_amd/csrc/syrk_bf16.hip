@@ -138,7 +138,13 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
     // Wave w copies rows 4 w .. 4 w + 3 of a chunk: one instruction = one row = 64 lanes x 16 bytes.
     float dreg = 0.0f;
     const int dma_voff = lane * 4 < m ? lane * 16 : 0x7ffffff0;           // columns >= m read as 0
-    auto issue_chunk = [&](int rb) -> unsigned {                          // rb: ring slot
+    bx_rsrc_t cur_rs;                                                     // descriptor of the chunk being requested
+    auto issue_piece = [&](int rb, int j) {
+#if !defined(BX_ABLATE_NO_DMA)         // (timing only)
+        bx_dma16(cur_rs, raw + rb * BX_RAWBUF + (4 * wave + j) * BX_RAWSTR, (int)((4 * wave + j) * m * 4) + dma_voff);
+#endif
+    };
+    auto issue_begin = [&](int rb) -> unsigned {                          // rb: ring slot
         const unsigned id = idL;
         const int64_t tb = (int64_t)id * BX_ITEM_ROWS + (int64_t)oL * BX_RS;
         // the chunk's rows that exist: everything beyond reads as 0 (rows >= n, columns >= m)
@@ -150,21 +156,21 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
         const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
         const unsigned nbytes = __builtin_amdgcn_readfirstlane(
             left <= 0 ? 0u : (left > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)left));
-        const bx_rsrc_t rs = bx_rsrc(reinterpret_cast<const void *>((uintptr_t)(((uint64_t)xhi << 32) | xlo)), nbytes);
+        cur_rs = bx_rsrc(reinterpret_cast<const void *>((uintptr_t)(((uint64_t)xhi << 32) | xlo)), nbytes);
         // (d first: the wave that loads it then waits for it with the 4 younger copies still in flight)
         if (wave == 0 && lane < BX_RS) dreg = tb + lane < n ? d[tb + lane] : 0.0f;
-#if !defined(BX_ABLATE_NO_DMA)         // (timing only)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            bx_dma16(rs, raw + rb * BX_RAWBUF + (4 * wave + j) * BX_RAWSTR,
-                     (int)((4 * wave + j) * m * 4) + dma_voff);
-#endif
         if (++oL == BX_CPI) {
             oL = 0;
             idL = idNext;
             if (tid == 0) *slot = gridDim.x + atomicAdd(counter, 1u);
             pending = true;
         }
+        return id;
+    };
+    auto issue_chunk = [&](int rb) -> unsigned {                          // the whole chunk at once (prologue)
+        const unsigned id = issue_begin(rb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_piece(rb, j);
         return id;
     };
     auto publish_d = [&](int rb) {          // d of the chunk just requested (wave 0, once its load has landed)
@@ -298,7 +304,14 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
             // ---- A: planes hold chunk c, slot s0 is converted by everybody, dl is settled
             bx_lds_barrier();
             if (pending) { idNext = __builtin_amdgcn_readfirstlane(*slot); pending = false; }
-            const unsigned id_c3 = issue_chunk(s0);  // chunk c + 3 -> the slot of chunk c
+            // chunk c + 3 -> the slot of chunk c: its four copies are issued one behind each product group
+            // after barrier B (an LDS-DMA piece costs ~60 cycles of issue among bare MFMAs and 100-185 inside
+            // a phase full of ds_read_b128 -- MI355X_MICROARCH.md -- all four in the fragment phase right
+            // behind barrier A made the copies cost more than the conversion)
+            const unsigned id_c3 = issue_begin(s0);
+#if defined(BX_DMA_BURST)              // (timing only: the first form, all four copies behind barrier A)
+            for (int j = 0; j < 4; ++j) issue_piece(s0, j);
+#endif
             // sign masks of this lane's 8 rows (pairs of rows per register, as the bf16 are packed)
             bx_u4 sm = bx_u4{0u, 0u, 0u, 0u};
             if constexpr (NEG) {
@@ -354,8 +367,14 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
             group(I0{}, I2{});
             bx_sched_fence();
             // ---- B: every wave holds its fragments (the planes may be rewritten) and its rows of chunk
-            // c + 1 have landed (the copies of chunks c + 2 and c + 3 stay in flight)
+            // c + 1 have landed (the 4 copies of chunk c + 2 -- and wave 0's load of d for chunk c + 3 -- stay
+            // in flight; the copies of chunk c + 3 follow behind this barrier)
+#if defined(BX_DMA_BURST)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
             bx_lds_barrier();
             convert_begin(s1);
             Unit q0 = unit_read(s1, 0);
@@ -365,15 +384,27 @@ void syrk_bf16x3_kernel(const float *__restrict__ X, int64_t n, int64_t m, const
             unit_wait(q0);
             unit_wait(q1);
             unit_col(q0, 0, I0{});
+#if !defined(BX_DMA_BURST)
+            issue_piece(s0, 0);
+#endif
             bx_sched_fence();
             group(I1{}, I0{});
             unit_col(q0, 0, I1{});
+#if !defined(BX_DMA_BURST)
+            issue_piece(s0, 1);
+#endif
             bx_sched_fence();
             group(I0{}, I1{});
             unit_col(q1, 1, I0{});
+#if !defined(BX_DMA_BURST)
+            issue_piece(s0, 2);
+#endif
             bx_sched_fence();
             group(I0{}, I0{});
             unit_col(q1, 1, I1{});
+#if !defined(BX_DMA_BURST)
+            issue_piece(s0, 3);
+#endif
             bx_sched_fence();
             // d of chunk c + 3 replaces d of chunk c (its sign masks are in registers, its rows converted)
             publish_d(s0);
