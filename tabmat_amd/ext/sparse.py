@@ -285,9 +285,14 @@ def direct_sandwich_pays(A: CsrDev) -> bool:
         return False
     nch = (m + 127) // 128
     per_row = nnz / n
+    pairs = n * per_row * (per_row + 1.0) / 2.0 * 1.3          # (+ spread of the row lengths)
+    if nch > 32:
+        # beyond 32 column chunks only the generic tiled kernel is left, at ~0.3 ns per row and tile
+        # (reference benchmark design 'sparse_wide', 40k x 10k at 1 %: 38 ms against 9.7 ms direct,
+        # profiles/r3_bench_sparse_wide.json)
+        return pairs / 15e9 < n * (nch * (nch + 1) / 2) * 0.3e-9
     if per_row / nch > 0.6:
         return False
-    pairs = n * per_row * (per_row + 1.0) / 2.0 * 1.3          # (+ spread of the row lengths)
     return pairs / 15e9 < n * (nch * (nch + 1) / 2) * 15e-12
 
 
