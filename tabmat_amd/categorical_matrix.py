@@ -423,6 +423,9 @@ class CategoricalMatrix(MatrixBase):
                 if (other.dtype == self.dtype and d.dtype == other._dev_c().buf.dtype
                         and xsplit.multi_cat_dense_wide_ok(cats, other._dev_c())):
                     res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev_c())
+                elif (other.dtype == self.dtype and d.dtype == other._dev_c().buf.dtype
+                      and xsplit.multi_cat_dense_tile_ok(cats, other._dev_c())):
+                    res = xsplit.multi_cat_dense_sandwich(cats, d, other._dev_c())    # narrow operand
                 elif (d.dtype == other._dev_c().buf.dtype
                       and xsplit.cat_dense_sorted_ok(other._dev_c())):
                     # more levels than one LDS tile holds: rows grouped by level, one pass over

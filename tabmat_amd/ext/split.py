@@ -365,6 +365,23 @@ def multi_cat_dense_wide_ok(cats, mat_j: DenseDev) -> bool:
             and mat_j.buf.data_ptr() % 16 == 0 and lds <= 150 * 1024)
 
 
+def multi_cat_dense_tile_ok(cats, mat_j: DenseDev) -> bool:
+    """True when the generic LDS-tile kernel of tm_multi_cat_dense_sandwich_* (any width, order and
+    alignment; tile [sum(n_cols)][TJ] doubles, TJ a power of two) covers a NARROW operand in at most two
+    column parts -- e.g. the reference's benchmark design dense_cat (2 x 1000 levels, 5 dense columns:
+    0.11 ms against 1.96 ms for the one-hot gather that F-ordered / unaligned operands took before)."""
+    total = sum(int(c[1]) for c in cats)
+    m = mat_j.m
+    if total == 0 or m == 0 or not 1 <= len(cats) <= 16:
+        return False
+    tj = 64
+    while tj > 1 and 8 * total * tj > 128 * 1024:        # HIST_LDS_MAX of csrc/cat.hip
+        tj >>= 1
+    while tj > 1 and tj // 2 >= m:
+        tj >>= 1
+    return 8 * total * tj <= 128 * 1024 and (m + tj - 1) // tj <= 2
+
+
 def multi_cat_dense_sandwich(cats, d, mat_j: DenseDev, rows=None):
     """All categorical x dense cross blocks in one pass over the dense block:
     returns the stacked [sum(n_cols) x mat_j.m] result (ext/split.pyx:32-80, fused over cats).

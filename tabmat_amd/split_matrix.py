@@ -293,6 +293,7 @@ class SplitMatrix(MatrixBase):
             cats = [(self.matrices[i]._dev(), self.matrices[i].shape[1], self.matrices[i].drop_first)
                     for i in grp]
             if any(isinstance(m, DenseMatrix) and not xsplit.multi_cat_dense_wide_ok(cats, m._dev_c())
+                   and not xsplit.multi_cat_dense_tile_ok(cats, m._dev_c())
                    and not xsplit.cat_dense_sorted_ok(m._dev_c()) for m in self.matrices):
                 self._onehot_slab(grp)
         others = any(not isinstance(m, CategoricalMatrix) for m in self.matrices)
@@ -501,6 +502,9 @@ class SplitMatrix(MatrixBase):
             if rows is not None and D.nlen(rows) <= 0.5 * self.shape[0]:
                 # short row list: only those rows of the dense block are read
                 return xsplit.multi_cat_dense_sandwich(cats, d_rows, mw._dev_c(), rows)
+            return xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
+        if isinstance(mw, DenseMatrix) and xsplit.multi_cat_dense_tile_ok(cats, mw._dev_c()):
+            # a narrow dense block (any order / alignment): the generic LDS-tile kernel
             return xsplit.multi_cat_dense_sandwich(cats, d_eff, mw._dev_c())
         if isinstance(mw, DenseMatrix):
             if xsplit.cat_dense_sorted_ok(mw._dev_c()):
