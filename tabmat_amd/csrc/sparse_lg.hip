@@ -214,8 +214,13 @@ __global__ __launch_bounds__(LG_THREADS / NG) void csr_dense_lg_kernel(
     const unsigned *knext = koff + (s0 * n_groups + group) * (int64_t)(LG_CHUNKS * LG_SLOTS);
     // compact stream: map dwords and block records of the slab whose map is requested next
     static_assert(!CP || NG == 1, "compact stream: one group per wave");
-    const unsigned *mnext = koff + (s0 * n_groups + group) * (int64_t)LG_SLOTS;
-    const int64_t *rnext = xptr + (s0 * n_groups + group) * (int64_t)2;
+#if defined(LG_ABLATE_SAME_GROUP)     // timing only: every wave walks the stream of the workgroup's FIRST group
+    const int sgroup = blockIdx.z * LG_NW;   // (identical work per slab in all 16 waves: no barrier skew)
+#else
+    const int sgroup = group;
+#endif
+    const unsigned *mnext = koff + (s0 * n_groups + sgroup) * (int64_t)LG_SLOTS;
+    const int64_t *rnext = xptr + (s0 * n_groups + sgroup) * (int64_t)2;
     constexpr int KSH = RSB == 1024 ? 10 : 9;     // koff = (1 + row) << KSH
 
     F dsc = F(0);
