@@ -418,6 +418,20 @@ int tm_cat_cat_sandwich_f64(const int32_t *i_codes, const int32_t *j_codes, int6
                             int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
                             void *stream);
 
+/* The same table with GLOBAL atomics as soon as the LDS-tiled form would need more than 12 passes over
+ * the codes (a table of more than ~12 x 128 KB: 1000 x 1000 levels in f64 takes 63 passes, 0.16 ms for
+ * 1M rows against 0.05 ms here).  The caller vouches that no cell collects more than a few thousand
+ * rows (atomics on one address serialise); the host layer checks the level counts
+ * (CategoricalMatrix._hot_count). */
+int tm_cat_cat_sandwich_atomic_f32(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                                   const float *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                                   int64_t j_ncol, int i_drop_first, int j_drop_first, float *out,
+                                   void *stream);
+int tm_cat_cat_sandwich_atomic_f64(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                                   const double *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                                   int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
+                                   void *stream);
+
 /* out[i_ncol x n_j] (row-major): out[col(k), jc] = sum_{k in rows} d[k] * M[k, j_cols[jc]].
  * Replaces _sandwich_cat_dense{C,F}_{fast,complex} (cat_split_helpers-tmpl.cpp:97-151) as bound
  * by sandwich_cat_dense (ext/split.pyx:32-80). */

@@ -459,9 +459,18 @@ class CategoricalMatrix(MatrixBase):
         if isinstance(other, CategoricalMatrix):
             res = xsplit.sandwich_cat_cat(self._dev(), other._dev(), self.shape[1],
                                           other.shape[1], d, rows, self.drop_first,
-                                          other.drop_first)
+                                          other.drop_first, hot=min(self._hot_count(), other._hot_count()))
             return self._restrict(res, L_cols, R_cols)
         raise TypeError
+
+    def _hot_count(self) -> int:
+        """Rows of the most frequent level (cached): an upper bound of what one cell of a
+        categorical x categorical table collects."""
+        h = getattr(self, "_hot", None)
+        if h is None:
+            c = self._dev()
+            h = self._hot = int(torch.bincount(c.to(torch.int64).clamp_(min=0)).max().item()) if c.numel() else 0
+        return h
 
     @staticmethod
     def _restrict(res, L_cols, R_cols):

@@ -137,7 +137,7 @@ constexpr size_t HIST_LDS_MAX = 128 * 1024;
 template <typename F, bool TWO>
 static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int32_t *rows,
                     int64_t n_iter, int drop_i, int drop_j, int64_t i_ncol, int64_t j_ncol,
-                    const int32_t *col_map, F *out, bool accumulate, hipStream_t st) {
+                    const int32_t *col_map, F *out, bool accumulate, hipStream_t st, int parts_max = 64) {
     const int64_t total = TWO ? i_ncol * j_ncol : i_ncol;
     if (total == 0) return TM_OK;
     if (!accumulate) TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
@@ -152,7 +152,7 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     }
     int64_t ti = std::min<int64_t>(i_ncol, (int64_t)(HIST_LDS_MAX / row_bytes));
     const int64_t n_parts = ceil_div(i_ncol, ti);
-    if (n_parts > 64) {  // too many passes over the codes: global atomics instead
+    if (n_parts > parts_max) {  // too many passes over the codes: global atomics instead
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 256 * 4), 2048);
         hipLaunchKernelGGL((hist_global_kernel<F, TWO>), dim3((unsigned)nblk), dim3(256), 0, st, ci,
                            cj, w, rows, n_iter, drop_i, drop_j, (int)j_ncol, col_map, out);
@@ -1286,6 +1286,27 @@ int tm_cat_cat_sandwich_f64(const int32_t *i_codes, const int32_t *j_codes, int6
     return run_hist<double, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
                                   j_drop_first, i_ncol, j_ncol, nullptr, out, false,
                                   as_stream(stream));
+}
+
+// (the caller vouches that no cell of the table collects more than a few thousand rows: global atomics
+// on one address serialise)
+int tm_cat_cat_sandwich_atomic_f32(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                                   const float *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                                   int64_t j_ncol, int i_drop_first, int j_drop_first, float *out,
+                                   void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_hist<float, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
+                                 j_drop_first, i_ncol, j_ncol, nullptr, out, false,
+                                 as_stream(stream), 12);
+}
+int tm_cat_cat_sandwich_atomic_f64(const int32_t *i_codes, const int32_t *j_codes, int64_t n,
+                                   const double *d, const int32_t *rows, int64_t n_rows, int64_t i_ncol,
+                                   int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
+                                   void *stream) {
+    TM_CHECK_COMMON(n);
+    return run_hist<double, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
+                                  j_drop_first, i_ncol, j_ncol, nullptr, out, false,
+                                  as_stream(stream), 12);
 }
 
 int tm_cat_dense_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,

@@ -25,12 +25,15 @@ def sandwich_cat_dense(i_indices, i_ncol, d, mat_j: DenseDev, rows, j_cols, drop
 
 
 def sandwich_cat_cat(i_indices, j_indices, i_ncol, j_ncol, d, rows, i_drop_first=False,
-                     j_drop_first=False):
-    """ext/split.pyx:83-111."""
+                     j_drop_first=False, hot=None):
+    """ext/split.pyx:83-111.  hot: an upper bound of the rows any one cell of the table collects
+    (None = unknown); a large, evenly filled table then takes global atomics instead of dozens of
+    LDS-tiled passes over the codes (tm_cat_cat_sandwich_atomic_*)."""
     if i_ncol == 0 or j_ncol == 0 or (rows is not None and D.nlen(rows) == 0):
         return D.zeros((i_ncol, j_ncol), d.dtype)
     res = D.out_buf((i_ncol, j_ncol), d.dtype)
-    call(f"tm_cat_cat_sandwich_{D.fsuf(d)}", D.p(i_indices), D.p(j_indices), i_indices.numel(),
+    fn = "tm_cat_cat_sandwich_atomic_" if (hot is not None and hot <= 4096) else "tm_cat_cat_sandwich_"
+    call(fn + D.fsuf(d), D.p(i_indices), D.p(j_indices), i_indices.numel(),
          D.p(d), D.p(rows), D.nlen(rows), i_ncol, j_ncol, int(i_drop_first), int(j_drop_first),
          D.p(res), D.stream_ptr())
     return res
