@@ -71,6 +71,11 @@ inline bool syrk_bf16x3_ok(const void *X, int64_t m) {
     return m > 0 && m <= 256 && m % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
 
+// K1n (syrk_narrow.hip): unrestricted blocks of at most 11 columns, any order / alignment
+bool syrk_narrow_ok(int64_t m);
+template <typename F>
+int run_syrk_narrow(const F *X, int64_t n, int64_t m, int order_f, const F *d, F *out, hipStream_t st);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -503,6 +503,9 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
         return TM_OK;
     }
     TM_REQUIRE(n_cols < (1 << 20), "too many columns");
+    // a handful of columns: one lane per pair of columns, no tiles (syrk_narrow.hip)
+    if (rows == nullptr && cols == nullptr && syrk_narrow_ok(m) && tune("syrk_narrow", 1))
+        return run_syrk_narrow<F>(X, n, m, order_f, d, out, st);
     if constexpr (sizeof(F) == 8) {
         // unrestricted C-ordered f64 block of <= 128 columns: the LDS-light kernel with fragment
         // prefetch and dynamic work items (syrk_co.hip; 3.2-3.4 ms against 3.6-3.7 ms at cfg4)
