@@ -673,6 +673,24 @@ def test_sandwich_graph_replay_matches_eager():
     assert rel_err(f(d).cpu().numpy(), X.sandwich(d).cpu().numpy()) < F64_TOL
 
 
+def test_sandwich_graph_replay_of_the_round_3_kernels():
+    """The cfg4 geometry (dense 128 -> int8-sliced syrk with its device-side hand-over, sparse 512 -> pair-block
+    K2 and the compact K3 stream) captured into a HIP graph: replays match the eager call, also for weights
+    that leave the int8 envelope (the flag is evaluated on the device at replay time)."""
+    import torch
+
+    specs, idx = cs.mixed_specs(20_000, 128, 512, (32, 16, 8), seed=11)
+    X = to_tm_split(specs, idx)
+    rng = np.random.default_rng(12)
+    d0 = torch.from_numpy(rng.random(20_000)).cuda()
+    f = X.sandwich_graph(d0)
+    blocks = [cs.to_oracle_block(s_) for s_ in specs]
+    for seed, shift in ((1, 0.0), (2, 0.3), (3, 0.0)):          # 0.3: negative weights -> f64 kernel at replay
+        dh = np.random.default_rng(seed).random(20_000) - shift
+        got = f(torch.from_numpy(dh).cuda()).cpu().numpy()
+        assert rel_err(got, _orc().split_sandwich(blocks, idx, dh)) < F64_TOL
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,dens", [(30_011, 2048, 0.0125), (20_000, 1024, 0.003), (9000, 700, 0.01),
