@@ -11,6 +11,6 @@ lg = sm._lg()
 _lib.call("tm_profile_enable", 1)
 ts = []
 for _ in range(6):
-    xs.csr_dense_sandwich_lg(lg, dm._dev_c(), d, unc=2)
+    xs.csr_dense_sandwich_lg(lg, dm._dev_c(), d, unc=int(os.environ.get("UNC", 2)))
     ms = C.c_float(0); _lib.call("tm_profile_last_ms", C.byref(ms)); ts.append(ms.value)
 print(f"K3 lg f64: min {min(ts):.3f} ms  (all: {' '.join(f'{t:.2f}' for t in ts)})")
