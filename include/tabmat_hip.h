@@ -134,6 +134,13 @@ int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double
                              double *out, void *stream);
 int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                  double *out, double *colsum, void *stream);
+/* The same with a per-matrix HISTORY (int32[2] in device memory, zeroed by the caller once; colsum may be
+ * NULL): [0] counts consecutive calls whose weights left the envelope after the product, [1] the calls.
+ * After three misses in a row the int8 kernel is skipped on the device (the f64 kernel alone runs
+ * instead of both) and tried again every 32nd call -- a solver whose weights stay outside the envelope
+ * pays for the int8 attempt three times, not in every iteration. */
+int tm_dense_sandwich_i8_hist_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                  double *out, double *colsum, int32_t *history, void *stream);
 
 /* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered FLOAT32 block of m = 4 k <= 256 columns
  * on the bf16 matrix cores: every element of diag(sqrt|d|) X is split into three bf16 pieces (24

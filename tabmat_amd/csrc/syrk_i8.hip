@@ -207,9 +207,16 @@ __global__ __launch_bounds__(256) void i8_screen_kernel(const double *__restrict
 }
 
 // sigma[i] = 2^k_i (the fixed-point scale of column i), rscale[i] = 2^-k_i
-__global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, const I8Info *info,
-                                double *__restrict__ sigma, double *__restrict__ rscale) {
+// history (may be NULL; per matrix, device memory): [0] = consecutive calls that left the envelope after the
+// product, [1] = calls.  After three misses in a row the int8 kernel is skipped (flag bit 2: the f64
+// kernel alone runs, instead of both) and tried again every 32nd call.
+__global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, I8Info *info,
+                                double *__restrict__ sigma, double *__restrict__ rscale, int *history) {
     const int i = threadIdx.x;
+    if (history != nullptr && i == 0) {
+        const int calls = history[1]++;
+        if (history[0] >= 3 && (calls & 31) != 0) atomicOr(&info->flag, 4u);
+    }
     if (i >= I8_W) return;
     const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
     double s = 1.0, r = 1.0;
@@ -708,16 +715,27 @@ __global__ __launch_bounds__(1024) void syrk_i8_finish_kernel(const double *__re
 // column that fails it hands the call to the f64 kernel.  (A column whose weighted norm is 0 has only
 // zero digits: exact, passes as 0 <= 0.)
 __global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, const double *__restrict__ colmax,
-                                   int m, int64_t n, I8Info *info) {
+                                   int m, int64_t n, I8Info *info, int *history) {
     const int j = threadIdx.x;
+    __shared__ int miss;
+    if (j == 0) miss = 0;
+    __syncthreads();
+    const bool live = info->flag == 0;
 #if defined(I8_TRACE)
     return;
 #endif
-    if (j >= m || info->flag != 0) return;
-    const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
-    const double big2 = colmax[j] * colmax[j] * dmax;
-    const double bound = fmin(64.0, 134217728.0 / (double)n);
-    if (!(big2 <= bound * out[(int64_t)j * ldo + j])) atomicOr(&info->flag, 2u);
+    if (j < m && live) {
+        const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
+        const double big2 = colmax[j] * colmax[j] * dmax;
+        const double bound = fmin(64.0, 134217728.0 / (double)n);
+        if (!(big2 <= bound * out[(int64_t)j * ldo + j])) {
+            atomicOr(&info->flag, 2u);
+            miss = 1;
+        }
+    }
+    __syncthreads();
+    // (only calls in which the int8 kernel ran count: a negative weight or a skipped call leaves the history)
+    if (history != nullptr && j == 0 && live) history[0] = miss ? history[0] + 1 : 0;
 }
 
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
@@ -726,7 +744,7 @@ int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, 
 size_t syrk_co_ws_bytes();
 
 int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
-                double *colsum, hipStream_t st) {
+                double *colsum, int *history, hipStream_t st) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m), "the int8 syrk takes a 16-byte aligned C-ordered f64 block of an "
                                            "even number of columns <= 128");
@@ -756,7 +774,7 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     TM_HIP(hipMemsetAsync(wb, 0, 4096 + part_bytes, st));
     const int sgrid = (int)std::min<int64_t>(4 * NUM_CU, ceil_div(n, 1024));
     hipLaunchKernelGGL(i8_screen_kernel, dim3((unsigned)sgrid), dim3(256), 0, st, d, n, info);
-    hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, info, sigma, rscale);
+    hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, info, sigma, rscale, history);
     TM_LAUNCH_CHECK();
     prof_begin(st);
     if (colsum)
@@ -769,7 +787,7 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
                        out, m);
-    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, n, info);
+    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, n, info, history);
     TM_LAUNCH_CHECK();
     // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
     prof_hold(true);               // (the event pair stays on the int8 kernel)
@@ -784,12 +802,17 @@ extern "C" {
 
 int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                              double *out, void *stream) {
-    return tmh::run_syrk_i8(X, n, m, d, colmax, out, nullptr, tmh::as_stream(stream));
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, nullptr, nullptr, tmh::as_stream(stream));
 }
 
 int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                  double *out, double *colsum, void *stream) {
-    return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, tmh::as_stream(stream));
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, nullptr, tmh::as_stream(stream));
+}
+
+int tm_dense_sandwich_i8_hist_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                  double *out, double *colsum, int32_t *history, void *stream) {
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, history, tmh::as_stream(stream));
 }
 
 }  // extern "C"

@@ -187,11 +187,18 @@ class DenseMatrix(MatrixBase):
             self._i8_ok = hit
         return None if hit is False else hit
 
+    def _i8_history(self):
+        """int32 [2] on the device: {consecutive envelope misses, calls} of this block's int8 syrk."""
+        h = getattr(self, "_i8_hist", None)
+        if h is None:
+            h = self._i8_hist = torch.zeros(2, dtype=torch.int32, device=self._dev_c().buf.device)
+        return h
+
     def _sandwich_dev(self, d, rows, cols):
         if rows is None and cols is None and d.dtype == torch.float64:
             cmax = self._i8_colmax()
             if cmax is not None:
-                return xd.dense_sandwich_i8(self._dev_c(), d, cmax)
+                return xd.dense_sandwich_i8(self._dev_c(), d, cmax, history=self._i8_history())
         return xd.dense_sandwich(self._dev_c(), d, rows, cols)
 
     def _sandwich_xtd_dev(self, d):
@@ -203,7 +210,7 @@ class DenseMatrix(MatrixBase):
         if d.dtype == torch.float64:
             cmax = self._i8_colmax()
             if cmax is not None:
-                return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True)
+                return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True, history=self._i8_history())
         if xd.co_supported(blk, d):
             return xd.dense_sandwich_co(blk, d, want_colsum=True)
         return None

@@ -119,19 +119,24 @@ def dense_sandwich_bf16x3(X: DenseDev, d):
     return out
 
 
-def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False):
+def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False, history=None):
     """X' diag(d) X of an unrestricted C-ordered float64 block of an even number of columns <= 128 on
     the int8 matrix cores (tm_dense_sandwich_i8_f64: 40-bit fixed point per column, five base-256
     digits, 22 exact int8 digit-pair products).  colmax: float64 device tensor of max |x| per column.
     Weights outside the envelope (negative, non-finite, tiny exactly where a column is large) make
     the call run the f64 kernel instead (checked on the device).  want_colsum: also X' d from the
-    same pass -> (out, colsum)."""
+    same pass -> (out, colsum).  history: int32 device tensor [2] kept per matrix
+    (tm_dense_sandwich_i8_hist_f64: after three misses in a row the int8 attempt is skipped)."""
     import torch
 
     out = D.out_buf((X.m, X.m), torch.float64)
     D.same_float("dense_sandwich_i8", X.buf, d, colmax)
+    cs = D.out_buf((X.m,), torch.float64) if want_colsum else None
+    if history is not None:
+        call("tm_dense_sandwich_i8_hist_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.p(cs),
+             D.p(history), D.stream_ptr())
+        return (out, cs) if want_colsum else out
     if want_colsum:
-        cs = D.out_buf((X.m,), torch.float64)
         call("tm_dense_sandwich_i8_xtd_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.p(cs),
              D.stream_ptr())
         return out, cs

@@ -215,7 +215,7 @@ def test_xtd_in_one_pass_without_a_complete_categorical(design):
     inner, xtd, seen = _spy_xtd(mat, d)
     assert not any(s.startswith(("tm_dense_rmatvec", "tm_csr_rmatvec", "tm_dense_matvec",
                                  "tm_csr_matvec")) for s in seen), seen
-    assert any(s in ("tm_dense_sandwich_i8_xtd_f64", "tm_dense_sandwich_co_f64") for s in seen)
+    assert any(s.startswith("tm_dense_sandwich_i8_") or s == "tm_dense_sandwich_co_f64" for s in seen)
     assert any(s.startswith(("tm_csr_dense_sandwich_lgc_", "tm_csr_dense_sandwich_lg_xtd")) for s in seen)
     want = mat.transpose_matvec(d)
     assert float((xtd - want).abs().max() / want.abs().max()) < 1e-12

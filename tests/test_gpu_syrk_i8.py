@@ -62,7 +62,7 @@ def test_dense_matrix_takes_the_i8_path_only_inside_the_envelope(monkeypatch):
 
     calls = []
     real = xd.dense_sandwich_i8
-    monkeypatch.setattr(xd, "dense_sandwich_i8", lambda *a: (calls.append(1), real(*a))[1])
+    monkeypatch.setattr(xd, "dense_sandwich_i8", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     rng = np.random.default_rng(6)
     X = rng.standard_normal((30_000, 128))
     d = rng.random(30_000)
@@ -109,3 +109,37 @@ def test_i8_column_sums_from_the_same_pass(n, m):
         assert rel_err(out, _orc().dense_sandwich(X, d, None, None)) < 1e-10
         want = X.T @ d
         assert np.abs(cs - want).max() <= 1e-12 * (np.abs(X).T @ np.abs(d)).max()
+
+
+def test_i8_history_skips_the_attempt_after_three_misses():
+    """tm_dense_sandwich_i8_hist_f64: weights that keep leaving the envelope pay for the int8 attempt three
+    times; from then on the device skips it (history[0] stays, the f64 kernel alone produces the result)
+    until the 32nd call tries again."""
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext._types import DenseDev
+
+    rng = np.random.default_rng(21)
+    n, m = 20_000, 128
+    X = rng.standard_normal((n, m))
+    X[::1000, 5] = 1e12
+    bad = rng.random(n)
+    bad[::1000] = 1e-300                                  # hides the column's large entries
+    good = rng.random(n)
+    Xd = DenseDev.from_host(X)
+    cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
+    hist = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ref_bad = _orc().dense_sandwich(X, bad, None, None)
+    scale = np.sqrt(np.outer(np.diag(ref_bad), np.diag(ref_bad)))
+    for call in range(1, 7):
+        out = xd.dense_sandwich_i8(Xd, torch.from_numpy(bad).cuda(), cmax, history=hist).cpu().numpy()
+        assert float((np.abs(out - ref_bad) / scale).max()) < 1e-12
+        h = hist.cpu().numpy()
+        assert h[1] == call and h[0] == min(call, 3)      # misses counted while the int8 kernel still runs
+    # good weights while the attempt is skipped: still the f64 kernel, the history stays
+    out = xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist).cpu().numpy()
+    assert rel_err(out, _orc().dense_sandwich(X, good, None, None)) < 1e-10
+    assert hist.cpu().numpy()[0] == 3
+    # the 32nd call tries again and clears it
+    hist[1] = 32
+    xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist)
+    assert hist.cpu().numpy()[0] == 0
