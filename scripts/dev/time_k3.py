@@ -9,6 +9,7 @@ sm = synth.sparse_block(n, 512, 0.05, torch.float64, 1003)
 d = torch.rand(n, dtype=torch.float64, device="cuda")
 lg = sm._lg()
 _lib.call("tm_profile_enable", 1)
+_lib.call("tm_tune_set", b"lg_rounds", int(os.environ.get("ROUNDS", 1)))
 ts = []
 for _ in range(6):
     xs.csr_dense_sandwich_lg(lg, dm._dev_c(), d, unc=int(os.environ.get("UNC", 2)))

@@ -620,7 +620,7 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
         if (want_csum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(F) * (size_t)m, st));
         return TM_OK;
     }
-    int64_t nblk = std::max<int64_t>(1, NUM_CU / ((int64_t)n_parts * nz));
+    int64_t nblk = std::max<int64_t>(1, tune("lg_rounds", 1) * NUM_CU / ((int64_t)n_parts * nz));
     nblk = std::min<int64_t>(nblk, n_slabs);
     const int64_t spb = ceil_div(n_slabs, nblk);
     nblk = ceil_div(n_slabs, spb);

@@ -99,7 +99,7 @@ class CsrDev:
             self._cm = cm
         return cm
 
-    def pair_blocks(self, n_wg: int = 256):
+    def pair_blocks(self, n_wg: int = 512):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
         at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
@@ -134,6 +134,19 @@ class CsrDev:
             # than a FULL one (55 vs 88) but takes as long -- the kernel waits for its loads -- measured
             # at 4M rows: 1.64 ms with equal weights, 1.89 ms with 49 : 88 (profiles/r3_k2_blocks.txt)
             COST_FULL, COST_HALF, NW = 1.0, 1.0, 16
+            # workgroups per tile in proportion to its blocks, EXACTLY n_wg in all (largest remainders): the
+            # grid then runs in whole rounds of 256 -- 386 workgroups (one and a half rounds) took 5.0 ms
+            # where 256 take 4.25 and 512 take 4.04 (two rounds of half-sized workgroups balance the tail)
+            share = [n_wg * c / max(total_blocks, 1) for c in counts]
+            cap = [max(1, -(-c // 256)) if c else 0 for c in counts]         # at least 256 blocks per workgroup
+            nbp = [0 if c == 0 else max(min_nb, min(int(sh), cp)) for c, sh, cp in zip(counts, share, cap)]
+            rest = n_wg - sum(nbp)
+            for k in sorted(range(len(counts)), key=lambda k: share[k] - int(share[k]), reverse=True):
+                if rest <= 0:
+                    break
+                if counts[k] and nbp[k] < cap[k]:
+                    nbp[k] += 1
+                    rest -= 1
             descs, tab, off, max_nb, part = [], [], 0, 1, -1
             for I in range(nch):
                 for J in range(I + 1):
@@ -160,8 +173,7 @@ class CsrDev:
                     flags = torch.where((na <= 4) & (nb > 4), 1 << 16, 0) | torch.where((na > 4) & (nb <= 4), 1 << 17, 0)
                     desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
                                         row, na | (nb << 8) | flags], dim=1).to(torch.int32)
-                    nb_p = max(min_nb, int(round(n_wg * c / max(total_blocks, 1))))
-                    nb_p = max(1, min(nb_p, -(-c // 256)))
+                    nb_p = max(1, nbp[part])
                     per = -(-c // nb_p)
                     wg = torch.div(torch.arange(c, device=dev, dtype=torch.int64), per, rounding_mode="floor")
                     key = wg * 2 + (~full).to(torch.int64)
