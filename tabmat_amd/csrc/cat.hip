@@ -1037,7 +1037,7 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
             (int64_t)cs.total * TJW * (int64_t)sizeof(lds_acc_t) < (1ll << 30)) {
             const int64_t n_parts = ceil_div(m, TJW);
             const int64_t stride = (int64_t)cs.total * TJW;
-            int64_t nblk = std::max<int64_t>(1, NUM_CU / n_parts);
+            int64_t nblk = std::max<int64_t>(1, tune("catdense_rounds", 1) * NUM_CU / n_parts);
             nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n, 4096)));
             const int64_t rpb = ceil_div(ceil_div(n, nblk), MCW_RS) * MCW_RS;
             nblk = ceil_div(n, rpb);
@@ -1178,7 +1178,7 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     const size_t lds = tile_bytes + (stage ? stage_bytes : 0);
     const int n_groups = (int)ceil_div(m, group_cols);
     const int64_t n_slabs = ceil_div(n, slab_rows);
-    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_groups);
+    int64_t nblk = std::max<int64_t>(1, tune("catsparse_rounds", 1) * NUM_CU / n_groups);
     nblk = std::min<int64_t>(nblk, n_slabs);
     const int64_t spb = ceil_div(n_slabs, nblk);
     nblk = ceil_div(n_slabs, spb);
@@ -1419,7 +1419,7 @@ static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *
     }
     const int n_groups = (int)ceil_div(m, GC);
     const int64_t stride = (int64_t)cs.total * GC;
-    int64_t nblk = std::max<int64_t>(1, NUM_CU / n_groups);
+    int64_t nblk = std::max<int64_t>(1, tune("catsparse_rounds", 1) * NUM_CU / n_groups);
     nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, ceil_div(n_sel, 2048)));
     const int64_t rpb = ceil_div(n_sel, nblk);
     nblk = ceil_div(n_sel, rpb);
