@@ -77,7 +77,10 @@ constexpr int I8_PLANE = I8_W * I8_PSTR;
 constexpr int I8_PLANES = I8_ND * I8_PLANE;     // 40 960 B
 constexpr int I8_RAWSTR = 1024 + 32;            // bytes per raw f64 row in LDS
 constexpr int I8_RAWBUF = I8_HS * I8_RAWSTR;    // one half chunk: 33 792 B
-constexpr int I8_CPI = 32;                      // chunks per work item (2048 rows: int32 stays exact)
+#ifndef I8_CPI_N
+#define I8_CPI_N 32
+#endif
+constexpr int I8_CPI = I8_CPI_N;                // chunks per work item (2048 rows: int32 stays exact)
 constexpr int I8_ITEM_ROWS = I8_CPI * I8_RS;
 constexpr size_t I8_LDS = (size_t)I8_PLANES + 3 * (size_t)I8_RAWBUF + 3 * I8_HS * sizeof(double) + 16;
 static_assert(I8_LDS <= 160 * 1024, "planes + the ring of 3 half chunks fill the CU's LDS");
