@@ -86,6 +86,7 @@ int tm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on 
  * (workgroups of the co-resident syrk), "wg_log" (device pointer to a placement log: uint64
  * {count, capacity, 0, 0} followed by records {XCC_ID << 32 | HW_ID, start, end, kernel tag} that
  * the instrumented kernels append per workgroup, s_memrealtime ticks; 0 = off). ---- */
+/* (value INT64_MIN removes the setting: the built-in default applies again) */
 int tm_tune_set(const char *h_key, int64_t value);
 int tm_tune_get(const char *h_key, int64_t dflt, int64_t *value);
 

@@ -5,6 +5,10 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tabmat_amd import synth
 N = 2_000_000
+for kv in os.environ.get("TUNE", "").split(","):          # e.g. TUNE=catdense_waves=8
+    if "=" in kv:
+        from tabmat_amd import _lib
+        _lib.call("tm_tune_set", kv.split("=")[0].encode(), int(kv.split("=")[1]))
 CASES = [
     ("cfg4 shape (dense128 + sp512@5% + cats 256/96/32)", dict()),
     ("float32", dict(dtype=torch.float32)),

@@ -1051,8 +1051,12 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
                 TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
                 prof_begin(st);
-                // 16 waves own a CU; 12 leave registers for the co-resident syrk (syrk_co.hip)
-                const int nw = (int)std::min<int64_t>(16, std::max<int64_t>(4, tune("catdense_waves", 16)));
+                // 16 waves own a CU; 12 leave registers for the co-resident syrk (syrk_co.hip).  With a large
+                // f64 tile (cfg4: 384 levels x 32 columns = 96 KB) EIGHT waves are faster -- 1.63 against
+                // 1.82 ms alone, 14.6 against 15.0 ms for the whole cfg4 step (fewer waves queue on the LDS
+                // atomic pipe; 6, 10 and 12 waves gain nothing); small tiles and f32 stay at 16
+                const int nw_dflt = (sizeof(F) == 8 && tile_b > 64 * 1024) ? 8 : 16;
+                const int nw = (int)std::min<int64_t>(16, std::max<int64_t>(4, tune("catdense_waves", nw_dflt)));
                 hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts), dim3(nw * 64), lds_w, st,
                                    cs, d, M, n, m, rpb, ws, stride, rows, wg_log_ptr());
                 prof_end(st);

@@ -212,7 +212,8 @@ int tm_workspace_generation(int64_t *generation) {
 int tm_tune_set(const char *h_key, int64_t value) {
     TM_REQUIRE(h_key != nullptr, "key is NULL");
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    g_tune[h_key] = value;
+    if (value == INT64_MIN) g_tune.erase(h_key);     // back to the built-in default
+    else g_tune[h_key] = value;
     return TM_OK;
 }
 

@@ -746,7 +746,7 @@ class SplitMatrix(MatrixBase):
                                         fan, self_done)
         finally:
             if guest is not None:
-                _set_knobs({k: 16 for k in OVERLAP_KNOBS})
+                _set_knobs({k: -2**63 for k in OVERLAP_KNOBS})      # (INT64_MIN: back to the defaults)
                 guest.join()
 
     def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done, fan,
