@@ -9,7 +9,9 @@ d = torch.rand(n, dtype=torch.float64, device="cuda")
 A = sm._dev()
 A.chunk_major()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-blocks, wg_tab, max_nb = A.pair_blocks(int(os.environ.get("NWG", 512)))
+NW = int(os.environ.get("K2B_WAVES", 16))
+_lib.call("tm_tune_set", b"k2b_waves", NW)
+blocks, wg_tab, max_nb = A.pair_blocks(int(os.environ.get("NWG", 512)), NW)
 torch.cuda.synchronize()
 print(f"block list: {blocks.shape[0]} blocks ({blocks.shape[0] / n / 10:.3f} per row and tile), "
       f"{wg_tab.shape[0]} workgroups, max {max_nb} per tile, built in {time.perf_counter() - t0:.2f} s, "

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
         };
         auto run_tile = [&](auto diag_c) {
             if (wave < wfull) run_list(diag_c, std::true_type{}, b0, bfull, 0, wfull);
-            else run_list(diag_c, std::false_type{}, bfull, b1, wfull, KB_WAVES - wfull);
+            else run_list(diag_c, std::false_type{}, bfull, b1, wfull, (int)(blockDim.x >> 6) - wfull);
         };
         if (I == J) run_tile(std::true_type{});
         else run_tile(std::false_type{});
@@ -232,7 +232,9 @@ static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const i
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(KB_WAVES * 64), lds, st, data, ind, cptr, n, nnz - 1,
+    // (the wave split of the table -- wg_tab[5] = waves on the FULL list -- is built for this many waves)
+    const int kb_waves = (int)std::min<int64_t>(KB_WAVES, std::max<int64_t>(2, tune("k2b_waves", KB_WAVES)));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(kb_waves * 64), lds, st, data, ind, cptr, n, nnz - 1,
                        reinterpret_cast<const int4 *>(blocks), reinterpret_cast<const int4 *>(wg_tab), d,
                        max_nb, ws, wg_log_ptr());
     prof_end(st);

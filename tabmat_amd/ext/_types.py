@@ -99,7 +99,7 @@ class CsrDev:
             self._cm = cm
         return cm
 
-    def pair_blocks(self, n_wg: int = 512):
+    def pair_blocks(self, n_wg: int = 512, nw: int = 16):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
         at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
@@ -133,7 +133,7 @@ class CsrDev:
             # waves per list in proportion to the block counts: a HALF step issues fewer instructions
             # than a FULL one (55 vs 88) but takes as long -- the kernel waits for its loads -- measured
             # at 4M rows: 1.64 ms with equal weights, 1.89 ms with 49 : 88 (profiles/r3_k2_blocks.txt)
-            COST_FULL, COST_HALF, NW = 1.0, 1.0, 16
+            COST_FULL, COST_HALF, NW = 1.0, 1.0, int(nw)
             # workgroups per tile in proportion to its blocks, EXACTLY n_wg in all (largest remainders): the
             # grid then runs in whole rounds of 256 -- 386 workgroups (one and a half rounds) took 5.0 ms
             # where 256 take 4.25 and 512 take 4.04 (two rounds of half-sized workgroups balance the tail)
