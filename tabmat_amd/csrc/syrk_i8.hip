@@ -77,6 +77,9 @@ constexpr int I8_PLANE = I8_W * I8_PSTR;
 constexpr int I8_PLANES = I8_ND * I8_PLANE;     // 40 960 B
 constexpr int I8_RAWSTR = 1024 + 32;            // bytes per raw f64 row in LDS
 constexpr int I8_RAWBUF = I8_HS * I8_RAWSTR;    // one half chunk: 33 792 B
+#ifndef I8_DMA_AUX
+#define I8_DMA_AUX 0                 // cache policy bits of the LDS-DMA copies (1 / 2 / 3 = sc0 / nt / both: within the noise, -1 %)
+#endif
 #ifndef I8_CPI_N
 #define I8_CPI_N 32
 #endif
@@ -157,7 +160,7 @@ __device__ __forceinline__ i8_rsrc_t i8_rsrc(const void *base, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)nb, 0x00020000);
 }
 __device__ __forceinline__ void i8_dma16(i8_rsrc_t rs, void *lds, int voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff, 0, 0, I8_DMA_AUX);
 }
 __device__ __forceinline__ void i8_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ unsigned i8_perm(unsigned hi, unsigned lo, unsigned sel) {
