@@ -352,6 +352,29 @@ int tm_csr_dense_sandwich_lgc_f64(const double *cvals, const uint32_t *cmap, con
                                   const double *d, int unconditional, double *out, double *colsum,
                                   void *stream);
 
+/* Entry-list form of the same unrestricted product (round 4; ext/sparse.pyx:211-260 csr_dense_sandwich ->
+ * ext/sparse_helpers-tmpl.cpp:23-146) for a C-ordered B with 16-byte aligned rows: the accumulator of a
+ * nonzero is picked at run time (VGPR index mode), so the stream is a plain list of entries -- one LDS read
+ * and two FMAs per nonzero, no padding to a partner column (csrc/sparse_ent.hip).  Rows in slabs of
+ * R = tm_ent_rows() = 64, columns in groups of C = tm_ent_group_cols() = 16 (m a multiple of C; kernel
+ * column = group * C + column in group), G = m / C groups, S = ceil(n / R) slabs.  The entries of block
+ * (group, slab) are padded to a whole number of units of U = tm_ent_unit_slots() = 8 slots; the blocks of a
+ * group follow one another slab after slab, group after group:
+ *   vals F[8 * units + 16]         value (padding: 0; 16 slots of slack at the end are read, not used)
+ *   meta uint16[8 * units + 16]    (1 + row in slab) << 4 | column in group; 0 = padding
+ *   uptr uint32[G][S + 1]          first unit of block (group, slab); entry S = the end of the group's stream
+ * colsum (length m, kernel column order, = A' d from the same pass; reference standardized_mat.py:149-150)
+ * may be NULL.  out: (m, r), kernel column order, overwritten. */
+int tm_ent_rows(void);
+int tm_ent_group_cols(void);
+int tm_ent_unit_slots(void);
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+                                  int64_t m, const float *B, int64_t r, const float *d, float *out,
+                                  float *colsum, void *stream);
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+                                  int64_t m, const double *B, int64_t r, const double *d, double *out,
+                                  double *colsum, void *stream);
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,

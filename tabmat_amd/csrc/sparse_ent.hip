@@ -1,0 +1,537 @@
+// K3 (entry-list form, round 4): sparse x dense sandwich  out = A^T diag(d) B  for a C-ordered dense
+// operand with more than 64 columns (reference: ext/sparse.pyx:211-260 csr_dense_sandwich ->
+// ext/sparse_helpers-tmpl.cpp:23-146 _csr_denseC_sandwich).
+//
+// Why another form.  The lane-group kernel (sparse_lg.hip) keeps the accumulators of a sparse column in
+// STATIC registers, so it has to walk its stream column by column: two columns side by side in the two
+// halves of the wave, padded to the longer one (1.5 LDS reads per nonzero), two positions per scalar bit
+// test -- 19 short dependent LDS round trips per wave and slab, LDS pipe 53 % busy, 56 % of the wave
+// cycles parked (profiles/r3_sq_counters.txt); removing its HBM waste (compact stream, round 3) did not
+// move its time.  Here the accumulator of a nonzero is picked AT RUN TIME with the VGPR index mode of
+// gfx9 (s_set_gpr_idx_on: M0[7:0] is added to the register number of the enabled operands of the
+// following VALU instructions), so the stream is a plain list of ENTRIES {value, row in slab, column in
+// group} in batches of 16 -- no padding inside a batch, no branch, one LDS read per nonzero, EN_NSLOT
+// reads in flight per wave:
+//     v_add_u32_dpp   row offset of entry i (row_newbcast inside every row of 16 lanes) + lane offset
+//     ds_read_b128    the whole wave reads the 1 KiB row of B: lane <-> 2 of the 128 dense columns
+//     v_readlane_b32  4 * column  ->  SGPR
+//     s_set_gpr_idx_on / 2 x v_fmac_f64_dpp (value by row_newbcast) / s_set_gpr_idx_off
+// scripts/ubench/gather_idx.hip: 6.8 cycles per entry and CU with 16 waves (the lane-group kernel runs at
+// 13.2 at BASELINE configs[3]; the LDS floor of one ds_read_b128 per nonzero is 4.4).
+//
+// Stream ("entry twin", built once per block by SlabEnt.from_csr): rows in slabs of EN_R = 64, columns
+// dealt to groups of EN_C = 16 = one wave.  The entries of a (group, slab) block are padded to a whole
+// number of UNITS of 8 slots (padding: value 0, meta 0); the blocks of a group follow one another, slab
+// after slab, so a wave walks ONE contiguous stream:
+//     vals F[T]            value
+//     meta uint16[T]       (1 + row in slab) << 4 | column in group;  0 = padding
+//     uptr uint32[G][S+1]  first unit of block (group, slab); the last one of a row = the group's end
+// 10 bytes per nonzero (+ 7 % padding at 5 % density) against 12 for CSR.  d is NOT staged in LDS: the
+// d of an entry's row is gathered from global memory (an L2-resident 512-byte line per slab) one batch
+// ahead, and v * d is folded before the batch is worked on; a row with d == 0 (or padding) reads the
+// all-zero LDS row, so inf * 0 of an excluded row cannot leak.
+//
+// The accumulators (v[64:127]) and the landing registers of the LDS reads (below v64) are pinned with
+// physical-register constraints: the index mode needs a base register known when the code is written.
+#include "common.hpp"
+#include "reduce.hpp"
+
+namespace tmh {
+
+constexpr int EN_R = 64;            // rows per slab
+constexpr int EN_C = 16;            // sparse columns per wave
+constexpr int EN_NW = 16;           // waves per workgroup (256 sparse columns)
+constexpr int EN_THREADS = EN_NW * 64;
+constexpr int EN_W = 128;           // dense columns per part
+constexpr int EN_U = 8;             // slots per unit
+#ifndef EN_NSLOT
+#define EN_NSLOT 4                  // LDS reads in flight per wave (landing slots): 4 or 8
+#endif
+static_assert(EN_NSLOT == 4 || EN_NSLOT == 8, "landing slots");
+
+template <typename F>
+struct EnLds {
+    static constexpr int ROWB = EN_W * (int)sizeof(F);      // bytes of a slab row (1024 / 512)
+    static constexpr int SLABB = EN_R * ROWB;
+    // [zero row][buffer 0: EN_R rows][buffer 1: EN_R rows]; row r (0-based) of buffer b at
+    // b * SLABB + (1 + r) * ROWB
+    static constexpr int TOTAL = ROWB + 2 * SLABB + 2 * EN_NW * EN_C * (int)sizeof(double);
+    static constexpr int CS_OFF = ROWB + 2 * SLABB;          // column sums of v * d (CSUM), doubles
+};
+
+// Registers the compiler may use: v0 .. v[EN_CVGPR - 1] (amdgpu_num_vgpr); everything above belongs to the
+// inline asm below: landing slots of the LDS reads just under v64, accumulators v[64:127] (f64: column j =
+// v[64 + 4 j : 64 + 4 j + 3]; f32: v[64 + 2 j : 64 + 2 j + 1]).  The index mode needs a base register
+// known when the code is written, and values the register allocator does not know about cannot be moved
+// or spilled by it (a first version passed the tuples as "+{v[64:95]}" operands: the allocator parked
+// them elsewhere between the asm statements and re-loaded all 64 from scratch in every batch).
+#if EN_NSLOT == 8
+constexpr int EN_CVGPR = 32;
+#else
+constexpr int EN_CVGPR = 48;
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t en_rsrc_t;
+__device__ __forceinline__ en_rsrc_t en_rsrc(const void *base, int64_t bytes) {
+    const unsigned nb = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ void en_buf_to_lds16(en_rsrc_t rs, void *lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff,
+                                             soff, 0, 0);
+}
+// landing registers: the EN_NSLOT slots below v64 (f64: 4 registers each, f32: 2)
+#if EN_NSLOT == 8
+#define EN_XD "32"
+#define EN_XF "48"
+#else
+#define EN_XD "48"
+#define EN_XF "56"
+#endif
+// entry I of the batch: its row of B -> landing slot I % EN_NSLOT
+template <typename F, int I>
+__device__ __forceinline__ void en_issue(unsigned kq, unsigned lane_off) {
+    unsigned tmp;
+    if constexpr (sizeof(F) == 8)
+        asm volatile("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+                     "ds_read_b128 v[" EN_XD "+4*%4:" EN_XD "+4*%4+3], %0"
+                     : "=&v"(tmp)
+                     : "v"(kq), "v"(lane_off), "n"(I), "n"(I % EN_NSLOT));
+    else
+        asm volatile("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+                     "ds_read_b64 v[" EN_XF "+2*%4:" EN_XF "+2*%4+1], %0"
+                     : "=&v"(tmp)
+                     : "v"(kq), "v"(lane_off), "n"(I), "n"(I % EN_NSLOT));
+}
+// entry I: wait until at most WAIT LDS reads are outstanding (the reads return in order), then
+// acc[column] += value * row under the index mode (SRC2 | DST: the accumulator, read and written)
+template <int I, int WAIT>
+__device__ __forceinline__ void en_fma(int sj, double a) {
+    asm volatile("s_waitcnt lgkmcnt(%2)\n\t"
+                 "s_set_gpr_idx_on %0, 0xc\n\t"
+                 "v_fmac_f64_dpp v[64:65], %1, v[" EN_XD "+4*%3:" EN_XD "+4*%3+1] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp v[66:67], %1, v[" EN_XD "+4*%3+2:" EN_XD "+4*%3+3] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_set_gpr_idx_off"
+                 :
+                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I)
+                 : "m0");
+}
+template <int I, int WAIT>
+__device__ __forceinline__ void en_fma(int sj, float a) {
+    asm volatile("s_waitcnt lgkmcnt(%2)\n\t"
+                 "s_set_gpr_idx_on %0, 0xc\n\t"
+                 "v_fmac_f32_dpp v64, %1, v[" EN_XF "+2*%3] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp v65, %1, v[" EN_XF "+2*%3+1] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_set_gpr_idx_off"
+                 :
+                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I)
+                 : "m0");
+}
+// all accumulators = 0; the clobber of the highest register is what sizes the wave's register allocation
+// (.amdhsa_next_free_vgpr): the compiler itself stays below EN_CVGPR
+template <typename F>
+__device__ __forceinline__ void en_zero_acc() {
+    if constexpr (sizeof(F) == 8) {
+        static_for<16>([&](auto jc) {
+            asm volatile("v_mov_b32 v[64+4*%0], 0\n\tv_mov_b32 v[64+4*%0+1], 0\n\t"
+                         "v_mov_b32 v[64+4*%0+2], 0\n\tv_mov_b32 v[64+4*%0+3], 0"
+                         :: "n"(decltype(jc)::value) : "v127");
+        });
+    } else {
+        static_for<16>([&](auto jc) {
+            asm volatile("v_mov_b32 v[64+2*%0], 0\n\tv_mov_b32 v[64+2*%0+1], 0" :: "n"(decltype(jc)::value) : "v95");
+        });
+    }
+}
+// accumulator register K (0 .. 63 / 0 .. 31) of this lane
+template <int K>
+__device__ __forceinline__ unsigned en_read_acc() {
+    unsigned x;
+    asm volatile("v_mov_b32 %0, v[64+%1]" : "=v"(x) : "n"(K));
+    return x;
+}
+template <int I>
+__device__ __forceinline__ int en_lane_to_s(unsigned v) {
+    int s;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(s) : "v"(v), "n"(I));
+    return s;
+}
+#else
+struct en_rsrc_t {};
+__device__ inline en_rsrc_t en_rsrc(const void *, int64_t) { return {}; }
+__device__ inline void en_buf_to_lds16(en_rsrc_t, void *, int, int) {}
+template <typename F, int I> __device__ void en_issue(unsigned, unsigned) {}
+template <int I, int WAIT, typename F> __device__ void en_fma(int, F) {}
+template <typename F> __device__ void en_zero_acc() {}
+template <int K> __device__ unsigned en_read_acc() { return 0u; }
+template <int I> __device__ int en_lane_to_s(unsigned) { return 0; }
+#endif
+
+// One batch of N = 16 (or 8: the odd unit at the end of a block) entries: a = value * d, kq = LDS address
+// of the entry's row (the zero row for padding / d == 0), jv = accumulator register offset of its column;
+// entry i lives in lane i of every row of 16 lanes.
+template <int N, typename F>
+__device__ __forceinline__ void en_batch(F a, unsigned kq, unsigned jv, unsigned lane_off) {
+    int sj[N];
+    static_for<N>([&](auto ic) { sj[decltype(ic)::value] = en_lane_to_s<decltype(ic)::value>(jv); });
+    // (no scalar load may be in flight: SMEM returns out of order and would make the counted waits unsafe)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<EN_NSLOT>([&](auto ic) { en_issue<F, decltype(ic)::value>(kq, lane_off); });
+    static_for<N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int wait = i + EN_NSLOT < N ? EN_NSLOT - 1 : N - 1 - i;
+        en_fma<i, wait>(sj[i], a);
+        if constexpr (i + EN_NSLOT < N) en_issue<F, i + EN_NSLOT>(kq, lane_off);
+    });
+}
+
+// CSUM = true: the column sums A^T d (length m, kernel column order) come out of the same pass
+// (StandardizedMatrix.sandwich: reference standardized_mat.py:149-150 calls transpose_matvec): lanes 0-15
+// add their entry's value * d to a per-wave LDS array of 16 doubles, one ds_add_f64 per batch.
+template <typename F, bool CSUM>
+__global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR))) void csr_dense_ent_kernel(
+    const F *__restrict__ vals, const unsigned short *__restrict__ meta, const unsigned *__restrict__ uptr,
+    int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
+    int nB, const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_csum, long long *__restrict__ prof) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using L = EnLds<F>;
+    constexpr int ROWB = L::ROWB;
+    constexpr int SLABB = L::SLABB;
+    constexpr int NV = SLABB / 16 / EN_THREADS;            // 1 KiB pieces copied per wave (4 / 2)
+    constexpr int RPP = 1024 / ROWB;                       // slab rows per piece (1 / 2)
+    constexpr int RSH = sizeof(F) == 8 ? 10 : 9;           // log2(ROWB)
+    constexpr int JSH = sizeof(F) == 8 ? 2 : 1;            // accumulator registers per column: 4 / 2
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l16 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = blockIdx.z * EN_NW + wave;
+    const bool active = group < n_groups;
+    const int j0 = blockIdx.y * EN_W;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int ns = (int)(min(s0 + slabs_per_block, n_slabs) - s0);   // slabs of this workgroup
+    const unsigned lane_off = (unsigned)lane * 16u / (sizeof(F) == 8 ? 1u : 2u);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_byte *)smem_raw;
+    double *cs_lds = reinterpret_cast<double *>(smem_raw + L::CS_OFF) + wave * EN_C;
+
+    en_zero_acc<F>();
+    // the zero row (and the column-sum slots)
+    for (int i = tid; i < ROWB / 4; i += EN_THREADS) reinterpret_cast<unsigned *>(smem_raw)[i] = 0u;
+    if (CSUM && lane < EN_C) cs_lds[lane] = 0.0;
+    if (ns <= 0) return;
+
+    // ---- slab copy (LDS-DMA, as in sparse_lg.hip): piece i of this wave = 1 KiB = RPP slab rows; B is read
+    // through a buffer descriptor rebuilt per slab (base = the slab's first byte, range = what is left of the
+    // array): rows beyond n - 1 in the ragged last slab read as 0 without per-lane clamping.
+    constexpr int VEC = 16 / (int)sizeof(F);
+    const int cc = min(j0 + ((lane * 16) % ROWB) / (int)sizeof(F), nB - VEC);
+    const int row0 = wave * NV * RPP + (lane * 16) / ROWB;
+    const unsigned boff0 = (unsigned)((row0 * r + cc) * (int64_t)sizeof(F));
+    const int64_t pstride = (int64_t)RPP * r * (int64_t)sizeof(F);
+    const int64_t bstride = (int64_t)EN_R * r * (int64_t)sizeof(F);
+    const char *bnext = reinterpret_cast<const char *>(B) + s0 * bstride;        // slab to copy next
+    int64_t bleft = n * r * (int64_t)sizeof(F) - s0 * bstride;                     // bytes from there on
+    auto issue_piece = [&](int buf, int i) {
+#if defined(EN_ABL_NOCOPY)            // timing only: the slab of B is never refreshed
+        if (bnext != reinterpret_cast<const char *>(B) + s0 * bstride) return;
+#endif
+        en_buf_to_lds16(en_rsrc(bnext, bleft), smem_raw + ROWB + buf * SLABB + (wave * NV + i) * RPP * ROWB,
+                        (int)boff0, (int)(i * pstride));
+    };
+
+    // ---- the wave's stream: fetch cursor (two batches ahead of the one worked on) ----
+    // window of block starts: lane l holds uptr[group][wbase + l]; units of slab s = lane s+1 - lane s
+    const unsigned *urow = uptr + (int64_t)(active ? group : 0) * (n_slabs + 1);
+    int64_t wbase = s0;
+    unsigned uwin = 0u;
+    // (a synchronous load written as asm: once per 63 slabs.  As a plain load the compiler cannot tell at the
+    // loop's merge points whether it is still in flight, and puts s_waitcnt vmcnt(0) in front of EVERY lookup
+    // -- right behind the requests of the stream and of d, whose latency is then paid once per slab)
+    auto load_window = [&]() {
+        const unsigned *p = urow + min(wbase + lane, n_slabs);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(uwin) : "v"(p) : "memory");
+#else
+        uwin = *p;
+#endif
+    };
+    load_window();
+    int fs = -1, fb = 0, fnb = 0, fnu = 0;          // slab (relative), batch inside it, its batches / units
+    int64_t fpos = active ? (int64_t)__builtin_amdgcn_readfirstlane((int)uwin) * EN_U : 0;   // slot of the cursor
+    // (unit indices are uint32; slots = units * 8 as int64)
+    fpos = active ? (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)uwin) * EN_U : 0;
+    auto units_of = [&](int s) -> int {             // units of slab s (relative) of this wave's group
+        int64_t a = s0 + s;
+        if (a - wbase >= 63) {
+            wbase = a;
+            load_window();
+        }
+        const int o = (int)(a - wbase);
+        return (int)((unsigned)__builtin_amdgcn_readlane((int)uwin, o + 1) -
+                     (unsigned)__builtin_amdgcn_readlane((int)uwin, o));
+    };
+    struct Desc { int slab; bool half; };
+    auto fetch = [&](F &v, unsigned &m, Desc &ds) {
+        while (fb >= fnb && fs < ns) {              // next non-empty slab
+            ++fs;
+            fb = 0;
+            fnu = (fs < ns && active) ? units_of(fs) : 0;
+            fnb = (fnu + 1) >> 1;
+        }
+        if (fs >= ns) {
+            ds.slab = ns;
+            ds.half = false;
+            v = F(0);
+            m = 0u;
+            return;
+        }
+        ds.slab = fs;
+        ds.half = fb == fnb - 1 && (fnu & 1);
+#if defined(EN_ABL_NOSTREAM)          // timing only: every batch re-reads the first 16 slots of the group's stream
+        v = vals[(int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)uwin) * 0 + l16];
+        m = meta[l16];
+#else
+        v = vals[fpos + l16];
+        m = meta[fpos + l16];
+#endif
+        fpos += ds.half ? EN_U : 2 * EN_U;
+        ++fb;
+    };
+    // pipeline of batches: P3 {v, m} requested; P2 {v, m} here, d requested; P1 {v, m, d} here; P0 folded
+    // {a = v * d, kq = LDS address of the row, jv = accumulator offset}.  Per batch worked on: stage A (the
+    // requests: d of P2, stream of P3), the copy pieces of the next slab, the batch, stage B (fold P1).  Every
+    // value is used one whole batch (~1500 cycles) after its request, and the s_waitcnt vmcnt(0) of the
+    // barrier that ends a slab finds only requests of that age.
+    F v3 = F(0), v2 = F(0), v1 = F(0), d2 = F(0), d1 = F(0), a0 = F(0);
+    unsigned m3 = 0u, m2 = 0u, m1 = 0u, kq0 = lds_base, jv0 = 0u;
+    Desc q3{-1, false}, q2{-1, false}, q1{-1, false}, q0{-1, false};
+    const F *dbase = d + s0 * EN_R;
+    auto stage_a = [&]() {
+        // P2 <- P3, its d requested (padding: row 0 of the slab, masked by rf == 0 at the fold)
+        v2 = v3;
+        m2 = m3;
+        q2 = q3;
+        if (q2.slab >= 0 && q2.slab < ns) {
+            const unsigned rf2 = (m2 >> 4) & 0x7fu;
+            d2 = dbase[(int64_t)q2.slab * EN_R + (int)(rf2 ? rf2 - 1u : 0u)];
+        } else {
+            d2 = F(0);
+        }
+        // P3 <- the batch at the cursor
+        fetch(v3, m3, q3);
+    };
+    auto stage_b = [&]() {
+        // P0 <- fold(P1); P1 <- P2
+        const unsigned rf = (m1 >> 4) & 0x7fu;
+        const bool ok = rf != 0u && d1 != F(0);
+        a0 = ok ? v1 * d1 : F(0);
+        kq0 = ok ? lds_base + (unsigned)(q1.slab & 1) * (unsigned)SLABB + (rf << RSH) : lds_base;
+        jv0 = (m1 & 15u) << JSH;
+        q0 = q1;
+        v1 = v2;
+        m1 = m2;
+        d1 = d2;
+        q1 = q2;
+    };
+
+    // prologue: slab 0 of the range into buffer 0; the pipeline filled
+#pragma unroll
+    for (int i = 0; i < NV; ++i) issue_piece(0, i);
+    bnext += bstride;
+    bleft -= bstride;
+    fetch(v3, m3, q3);
+    stage_a();
+    stage_b();
+    stage_a();
+    stage_b();
+    __syncthreads();
+
+#if defined(EN_PROF)                  // cycles per section (tm_tune_set("ent_prof", device pointer))
+    long long pt_a = 0, pt_p = 0, pt_x = 0, pt_b = 0, pt_bar = 0, pt_n = 0;
+    long long pt0 = clock64();
+    const long long pt_start = pt0;
+#define EN_TICK(acc) { const long long t_ = clock64(); acc += t_ - pt0; pt0 = t_; }
+#else
+#define EN_TICK(acc)
+#endif
+    for (int w = 0; w < ns; ++w) {
+        const int buf = w & 1;
+        const bool more = w + 1 < ns;
+        int pieces = 0;                              // copy pieces of the next slab issued so far
+        int bi = 0;
+        while (q0.slab == w) {
+            stage_a();
+            EN_TICK(pt_a)
+            // pieces before batch 0: half of them; one more before each later batch
+            const int want = more ? min(NV, NV / 2 + bi) : 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i >= pieces && i < want) issue_piece(buf ^ 1, i);
+            pieces = max(pieces, want);
+            EN_TICK(pt_p)
+            if constexpr (CSUM) {
+                // (the upper 8 lanes of a half batch hold the first entries of the NEXT block)
+                if (lane < (q0.half ? EN_U : 2 * EN_U)) atomic_add(cs_lds + (jv0 >> JSH), (double)a0);
+            }
+#if defined(EN_ABL_NOBATCH)           // timing only: the memory side alone
+            asm volatile("" ::"v"(a0), "v"(kq0), "v"(jv0));
+#else
+            if (q0.half)
+                en_batch<8, F>(a0, kq0, jv0, lane_off);
+            else
+                en_batch<16, F>(a0, kq0, jv0, lane_off);
+#endif
+            EN_TICK(pt_x)
+            stage_b();
+            EN_TICK(pt_b)
+#if defined(EN_PROF)
+            ++pt_n;
+#endif
+            ++bi;
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i >= pieces) issue_piece(buf ^ 1, i);
+            bnext += bstride;
+            bleft -= bstride;
+        }
+        EN_TICK(pt_p)
+#if defined(EN_ABL_NOBARRIER)         // timing only (wrong results): waves run free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        __syncthreads();
+#endif
+        EN_TICK(pt_bar)
+    }
+#if defined(EN_PROF)
+    if (prof != nullptr && lane == 0) {
+        long long *o = prof + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (EN_NW * 8) + wave * 8;
+        o[0] = pt_a; o[1] = pt_p; o[2] = pt_x; o[3] = pt_b; o[4] = pt_bar; o[5] = pt_n; o[6] = clock64() - pt_start; o[7] = ns;
+    }
+#endif
+
+    if (active) {
+        // ws layout: [part][block][n_groups * EN_C kernel columns][128]
+        F *dst = ws + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_groups + group) * (EN_C * EN_W);
+        static_for<EN_C>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (sizeof(F) == 8) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                const u4 o = u4{en_read_acc<4 * j>(), en_read_acc<4 * j + 1>(), en_read_acc<4 * j + 2>(),
+                                en_read_acc<4 * j + 3>()};
+                *reinterpret_cast<u4 *>(dst + j * EN_W + 2 * lane) = o;
+            } else {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 o = u2{en_read_acc<2 * j>(), en_read_acc<2 * j + 1>()};
+                *reinterpret_cast<u2 *>(dst + j * EN_W + 2 * lane) = o;
+            }
+        });
+        if constexpr (CSUM) {
+            if (blockIdx.y == 0 && lane < EN_C)
+                ws_csum[(int64_t)blockIdx.x * (n_groups * EN_C) + group * EN_C + lane] = (F)cs_lds[lane];
+        }
+    }
+}
+
+// tmp [part][m][128] -> out[m][nB]
+template <typename F>
+__global__ void en_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t nB, F *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * nB) return;
+    const int64_t i = e / nB, j = e % nB;
+    out[e] = tmp[((j / EN_W) * m + i) * EN_W + (j % EN_W)];
+}
+
+// column sums: csum[c] = sum over the workgroups (fixed order) of their partial sums
+template <typename F>
+__global__ void en_csum_kernel(const F *__restrict__ part, int nblk, int64_t m, F *__restrict__ csum) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)part[(int64_t)b * m + c];
+    csum[c] = (F)a;
+}
+
+template <typename F>
+static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n, int64_t m,
+                             const F *B, int64_t r, const F *d, F *out, F *colsum, hipStream_t st) {
+    const int64_t nB = r;
+    const int64_t total = m * nB;
+    if (total == 0) return TM_OK;
+    constexpr int VEC = 16 / (int)sizeof(F);
+    if ((reinterpret_cast<uintptr_t>(B) & 15) != 0 || r % VEC != 0 || nB < VEC) {
+        set_error("tm_csr_dense_sandwich_ent: B must be C-ordered with 16-byte aligned rows");
+        return TM_EUNSUPPORTED;
+    }
+    if (m % EN_C != 0) {
+        set_error("tm_csr_dense_sandwich_ent: m must be a multiple of tm_ent_group_cols()");
+        return TM_EINVAL;
+    }
+    const int64_t n_slabs = ceil_div(n, EN_R);
+    const int n_groups = (int)(m / EN_C);
+    const int n_parts = (int)ceil_div(nB, EN_W);
+    const int nz = (int)ceil_div(n_groups, EN_NW);
+    const bool want_csum = colsum != nullptr;
+    if (n_slabs == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        if (want_csum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(F) * (size_t)m, st));
+        return TM_OK;
+    }
+    int64_t nblk = std::max<int64_t>(1, tune("ent_rounds", 1) * NUM_CU / ((int64_t)n_parts * nz));
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const int64_t stride = m * EN_W;  // per (part, block)
+    const size_t tmp_bytes = (sizeof(F) * (size_t)(n_parts * stride) + 255) / 256 * 256;
+    const size_t part_bytes = (sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 255) / 256 * 256;
+    const size_t csum_bytes = ((want_csum ? sizeof(F) * (size_t)(nblk * m) : 0) + 255) / 256 * 256 + 256;
+    void *wsv = nullptr;
+    int rc = get_workspace(tmp_bytes + part_bytes + csum_bytes + 256, &wsv, st);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    F *ws_csum = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes + part_bytes);
+    const size_t lds = (size_t)EnLds<F>::TOTAL;
+    auto kern = want_csum ? &csr_dense_ent_kernel<F, true> : &csr_dense_ent_kernel<F, false>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(EN_THREADS), lds, st,
+                       vals, meta, uptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws, ws_csum,
+                       reinterpret_cast<long long *>((uintptr_t)tune("ent_prof", 0)));
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_parts, tmp, n_parts * stride, false, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((en_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, tmp, m,
+                       nB, out);
+    TM_LAUNCH_CHECK();
+    if (want_csum) {
+        hipLaunchKernelGGL((en_csum_kernel<F>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, ws_csum,
+                           (int)nblk, m, colsum);
+        TM_LAUNCH_CHECK();
+    }
+    return TM_OK;
+}
+
+}  // namespace tmh
+
+extern "C" {
+int tm_ent_rows(void) { return tmh::EN_R; }
+int tm_ent_group_cols(void) { return tmh::EN_C; }
+int tm_ent_unit_slots(void) { return tmh::EN_U; }
+
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+                                  int64_t m, const float *B, int64_t r, const float *d, float *out,
+                                  float *colsum, void *stream) {
+    return tmh::run_csr_dense_ent<float>(vals, meta, uptr, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+                                  int64_t m, const double *B, int64_t r, const double *d, double *out,
+                                  double *colsum, void *stream) {
+    return tmh::run_csr_dense_ent<double>(vals, meta, uptr, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
+}
+}  // extern "C"

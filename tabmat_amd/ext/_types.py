@@ -553,6 +553,86 @@ class SlabLg:
         return SlabLg(vals, koff, xptr, xvals, xkoff, inv, n, m, mpad, 2)
 
 
+@dataclass
+class SlabEnt:
+    """Entry twin of a sparse block for tm_csr_dense_sandwich_ent_* (csrc/sparse_ent.hip, round 4): rows in
+    slabs of R = 64, columns dealt to G groups of C = 16 (one wave each) in the order of their density
+    (rank r -> group r % G: the groups of a workgroup carry equal shares of every slab).  The entries
+    {value, (1 + row in slab) << 4 | column in group} of block (group, slab) are padded to units of 8
+    slots; blocks follow one another slab after slab, group after group; uptr[g, s] = first unit of the
+    block.  10 bytes per nonzero + padding (7 % at 5 % density).  Built once per block on the device."""
+
+    vals: torch.Tensor     # F[T + 16]
+    meta: torch.Tensor     # int16[T + 16] (read as uint16)
+    uptr: torch.Tensor     # int32[G, S + 1] (read as uint32)
+    inv: torch.Tensor      # int64[m]  kernel row of column c of the block
+    n: int
+    m: int
+    mk: int                # kernel rows = G * C
+
+    @property
+    def dtype(self):
+        return self.vals.dtype
+
+    @staticmethod
+    def from_csr(csr: CsrDev, max_pad: float = None) -> "SlabEnt":
+        """Returns None when the padded stream would exceed max_pad x nnz slots (very sparse blocks: every
+        non-empty (group, slab) block costs at least 8 slots)."""
+        from .._lib import lib
+
+        R = int(lib().tm_ent_rows())
+        C = int(lib().tm_ent_group_cols())
+        U = int(lib().tm_ent_unit_slots())
+        n, m = csr.n, csr.m
+        dev = csr.data.device
+        S = (n + R - 1) // R
+        G = max(1, (m + C - 1) // C)
+        nnz = int(csr.data.numel())
+        idx64 = csr.indices.to(torch.int64)
+        colcnt = torch.bincount(idx64, minlength=m) if nnz else torch.zeros(m, dtype=torch.int64, device=dev)
+        order = torch.sort(colcnt, descending=True, stable=True).indices
+        rank = torch.empty(m, dtype=torch.int64, device=dev)
+        rank[order] = torch.arange(m, device=dev, dtype=torch.int64)
+        grp_of = torch.remainder(rank, G)
+        jloc_of = torch.div(rank, G, rounding_mode="floor")
+        inv = grp_of * C + jloc_of
+        del order, colcnt, rank
+        if nnz == 0 or S == 0:
+            return SlabEnt(torch.zeros(16, dtype=csr.data.dtype, device=dev),
+                           torch.zeros(16, dtype=torch.int16, device=dev),
+                           torch.zeros((G, S + 1), dtype=torch.int32, device=dev), inv, n, m, G * C)
+        counts = csr.indptr[1:] - csr.indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
+        key = grp_of[idx64] * S + torch.div(rows, R, rounding_mode="floor")
+        cnt = torch.bincount(key, minlength=G * S)
+        units = torch.div(cnt + (U - 1), U, rounding_mode="floor")
+        total_units = int(units.sum().item())
+        if max_pad is not None and total_units * U > max_pad * nnz and total_units * U > (1 << 22):
+            return None
+        if total_units >= 2**31:
+            return None
+        ustart = torch.zeros(G * S + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(units, dim=0, out=ustart[1:])
+        del units
+        # stable: CSR order is row-sorted, entries of a block stay in (row, column) order
+        key_sorted, perm = torch.sort(key, stable=True)
+        del key
+        first = torch.cumsum(cnt, dim=0) - cnt
+        pos = ustart[key_sorted] * U + (torch.arange(nnz, device=dev, dtype=torch.int64) - first[key_sorted])
+        del first, cnt, key_sorted
+        T = total_units * U
+        vals = torch.zeros(T + 16, dtype=csr.data.dtype, device=dev)
+        meta = torch.zeros(T + 16, dtype=torch.int16, device=dev)
+        vals[pos] = csr.data[perm]
+        mt = ((torch.remainder(rows[perm], R) + 1) << 4) | jloc_of[idx64[perm]]
+        meta[pos] = mt.to(torch.int16)
+        del pos, mt, perm, rows, idx64
+        gi = torch.arange(G, device=dev, dtype=torch.int64)[:, None] * S + \
+            torch.arange(S + 1, device=dev, dtype=torch.int64)[None, :]
+        uptr = ustart[gi].to(torch.int32).contiguous()
+        return SlabEnt(vals, meta, uptr, inv, n, m, G * C)
+
+
 def onehot_slab(cats, n: int, dtype: torch.dtype):
     """Slab form of the STACKED one-hot encodings of several categorical blocks: a sparse
     matrix with (at most) one unit entry per row and categorical, columns = the categoricals'

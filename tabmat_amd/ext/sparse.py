@@ -6,7 +6,7 @@ import os
 
 from .. import _device as D
 from .._lib import call
-from ._types import CsrDev, DenseDev, SlabCsc, SlabEll, SlabLg
+from ._types import CsrDev, DenseDev, SlabCsc, SlabEll, SlabEnt, SlabLg
 
 
 def _csr_args(A: CsrDev):
@@ -144,6 +144,23 @@ def csr_dense_sandwich_lg(A: SlabLg, B: DenseDev, d, unc=None, want_colsum=False
         call("tm_csr_dense_sandwich_lg_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.koff), D.p(A.xptr),
              D.p(A.xvals), D.p(A.xkoff), A.n, A.mk, D.p(B.buf), B.m, D.p(d), u, D.p(out), D.stream_ptr())
     # kernel rows are the density-sorted columns
+    return (out[A.inv], cs[A.inv]) if want_colsum else out[A.inv]
+
+
+def csr_dense_sandwich_ent(A: SlabEnt, B: DenseDev, d, want_colsum=False):
+    """Fast path of ext/sparse.pyx:211-260 for an unrestricted product with a C-ordered B of more than 64
+    columns: entry twin, accumulators picked at run time (csrc/sparse_ent.hip, round 4).
+    want_colsum: returns (out, A' d) -- the column sums ride along in the same pass."""
+    assert B.n == A.n and ell_supported(B)
+    dt = A.dtype
+    if A.m == 0 or B.m == 0 or A.n == 0:
+        z = D.zeros((A.m, B.m), dt)
+        return (z, D.zeros((A.m,), dt)) if want_colsum else z
+    out = D.out_buf((A.mk, B.m), dt)
+    cs = D.out_buf((A.mk,), dt) if want_colsum else None
+    D.same_float("csr_dense_sandwich_ent", A.vals, B.buf, d)
+    call("tm_csr_dense_sandwich_ent_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.meta), D.p(A.uptr), A.n, A.mk,
+         D.p(B.buf), B.m, D.p(d), D.p(out), D.p(cs), D.stream_ptr())
     return (out[A.inv], cs[A.inv]) if want_colsum else out[A.inv]
 
 
