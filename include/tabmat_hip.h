@@ -357,21 +357,22 @@ int tm_csr_dense_sandwich_lgc_f64(const double *cvals, const uint32_t *cmap, con
  * nonzero is picked at run time (VGPR index mode), so the stream is a plain list of entries -- one LDS read
  * and two FMAs per nonzero, no padding to a partner column (csrc/sparse_ent.hip).  Rows in slabs of
  * R = tm_ent_rows() = 64, columns in groups of C = tm_ent_group_cols() = 16 (m a multiple of C; kernel
- * column = group * C + column in group), G = m / C groups, S = ceil(n / R) slabs.  The entries of block
- * (group, slab) are padded to a whole number of units of U = tm_ent_unit_slots() = 8 slots; the blocks of a
- * group follow one another slab after slab, group after group:
- *   vals F[8 * units + 16]         value (padding: 0; 16 slots of slack at the end are read, not used)
- *   meta uint16[8 * units + 16]    (1 + row in slab) << 4 | column in group; 0 = padding
- *   uptr uint32[G][S + 1]          first unit of block (group, slab); entry S = the end of the group's stream
+ * column = group * C + column in group), G = m / C groups, S = ceil(n / R) slabs, n < 2^28.  The entries of
+ * block (group, slab) are padded to whole batches of tm_ent_batch_slots() = 16 slots (padding: value 0 and
+ * the row of a real entry of the block); the blocks of a group follow one another slab after slab, group
+ * after group:
+ *   vals F[16 * batches + 192]        value (192 slots of slack at the end are read, not used: zeros)
+ *   meta uint32[16 * batches + 192]   row << 4 | column in group
+ *   bstart uint32[G][S + 1]           first batch of block (group, slab); entry S = the end of the group
  * colsum (length m, kernel column order, = A' d from the same pass; reference standardized_mat.py:149-150)
  * may be NULL.  out: (m, r), kernel column order, overwritten. */
 int tm_ent_rows(void);
 int tm_ent_group_cols(void);
-int tm_ent_unit_slots(void);
-int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+int tm_ent_batch_slots(void);
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const float *B, int64_t r, const float *d, float *out,
                                   float *colsum, void *stream);
-int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const double *B, int64_t r, const double *d, double *out,
                                   double *colsum, void *stream);
 

@@ -55,8 +55,8 @@ torch.cuda.synchronize(); t = time.time()
 ent = SlabEnt.from_csr(sm._dev())
 torch.cuda.synchronize()
 nnz = sm._dev().data.numel()
-print(f"ent twin: built in {time.time()-t:.2f} s, slots {(ent.vals.numel()-16)/nnz:.3f}x nnz, "
-      f"{(ent.vals.numel()*ent.vals.element_size()+ent.meta.numel()*2+ent.uptr.numel()*4)/1e9:.2f} GB", flush=True)
+print(f"ent twin: built in {time.time()-t:.2f} s, slots {(ent.vals.numel()-ent.SLACK)/nnz:.3f}x nnz, "
+      f"{ent.nbytes()/1e9:.2f} GB", flush=True)
 t1, out = timed(lambda: xs.csr_dense_sandwich_ent(ent, Bd, d))
 err = ((out - ref).abs().max() / ref.abs().max()).item()
 print(f"ent: {t1:.3f} ms  rel.diff vs lg {err:.2e}", flush=True)

@@ -20,16 +20,22 @@
 // 13.2 at BASELINE configs[3]; the LDS floor of one ds_read_b128 per nonzero is 4.4).
 //
 // Stream ("entry twin", built once per block by SlabEnt.from_csr): rows in slabs of EN_R = 64, columns
-// dealt to groups of EN_C = 16 = one wave.  The entries of a (group, slab) block are padded to a whole
-// number of UNITS of 8 slots (padding: value 0, meta 0); the blocks of a group follow one another, slab
-// after slab, so a wave walks ONE contiguous stream:
-//     vals F[T]            value
-//     meta uint16[T]       (1 + row in slab) << 4 | column in group;  0 = padding
-//     uptr uint32[G][S+1]  first unit of block (group, slab); the last one of a row = the group's end
-// 10 bytes per nonzero (+ 7 % padding at 5 % density) against 12 for CSR.  d is NOT staged in LDS: the
-// d of an entry's row is gathered from global memory (an L2-resident 512-byte line per slab) one batch
-// ahead, and v * d is folded before the batch is worked on; a row with d == 0 (or padding) reads the
-// all-zero LDS row, so inf * 0 of an excluded row cannot leak.
+// dealt to groups of EN_C = 16 = one wave.  The entries of a (group, slab) block are padded to whole
+// BATCHES of 16 slots (padding: value 0, the row of the block's first entry); the blocks of a group follow
+// one another, slab after slab, so a wave walks ONE contiguous stream:
+//     vals F[T]              value
+//     meta uint32[T]         row (of the whole block) << 4 | column in group
+//     bstart uint32[G][S+1]  first batch of block (group, slab); entry S = the end of the group's stream
+// 12 bytes per slot.  A wave takes its stream in SUPERBATCHES of 64 slots, lane <-> slot: one coalesced load
+// of the values and one of the meta words a whole superbatch (~5000 cycles) ahead, the d of every slot's row
+// gathered from global memory (L2-resident lines) half a superbatch ahead; then, still lane <-> slot, the
+// FOLD: a = value * d, kq = LDS address of the row of B (the all-zero row if value == 0 or d == 0, so inf * 0
+// of an excluded row cannot leak), jv = accumulator offset of the column -- 64 slots per instruction -- and
+// {a, kq, jv | slab << 8} goes to a 1 KiB per-wave LDS scratch, from where each batch fetches its 16 slots
+// with one ds_read_b128 (all four rows of 16 lanes read the same 16 addresses: the broadcast the DPP
+// row_newbcast operands need).  Slab boundaries come from the entries themselves.  (A first version walked
+// per-slab unit counts with a scalar state machine and folded batch by batch: ~150 wave instructions of
+// skeleton per batch of 16, as long as the batch itself -- profiles/r4_k3_ent.txt.)
 //
 // The accumulators (v[64:127]) and the landing registers of the LDS reads (below v64) are pinned with
 // physical-register constraints: the index mode needs a base register known when the code is written.
@@ -43,7 +49,8 @@ constexpr int EN_C = 16;            // sparse columns per wave
 constexpr int EN_NW = 16;           // waves per workgroup (256 sparse columns)
 constexpr int EN_THREADS = EN_NW * 64;
 constexpr int EN_W = 128;           // dense columns per part
-constexpr int EN_U = 8;             // slots per unit
+constexpr int EN_B = 16;            // slots per batch
+constexpr int EN_SB = 64;           // slots per superbatch (lane <-> slot)
 #ifndef EN_NSLOT
 #define EN_NSLOT 4                  // LDS reads in flight per wave (landing slots): 4 or 8
 #endif
@@ -55,8 +62,9 @@ struct EnLds {
     static constexpr int SLABB = EN_R * ROWB;
     // [zero row][buffer 0: EN_R rows][buffer 1: EN_R rows]; row r (0-based) of buffer b at
     // b * SLABB + (1 + r) * ROWB
-    static constexpr int TOTAL = ROWB + 2 * SLABB + 2 * EN_NW * EN_C * (int)sizeof(double);
-    static constexpr int CS_OFF = ROWB + 2 * SLABB;          // column sums of v * d (CSUM), doubles
+    static constexpr int SCR_OFF = ROWB + 2 * SLABB;         // per-wave scratch: 64 folded slots of 16 bytes
+    static constexpr int CS_OFF = SCR_OFF + EN_NW * EN_SB * 16;   // column sums of v * d (CSUM), doubles
+    static constexpr int TOTAL = CS_OFF + EN_NW * EN_C * (int)sizeof(double);
 };
 
 // Registers the compiler may use: v0 .. v[EN_CVGPR - 1] (amdgpu_num_vgpr); everything above belongs to the
@@ -65,10 +73,13 @@ struct EnLds {
 // known when the code is written, and values the register allocator does not know about cannot be moved
 // or spilled by it (a first version passed the tuples as "+{v[64:95]}" operands: the allocator parked
 // them elsewhere between the asm statements and re-loaded all 64 from scratch in every batch).
+// v[EN_CVGPR : EN_CVGPR + 7] receive the stream / d loads (en_take hands them to the compiler after the wait).
 #if EN_NSLOT == 8
-constexpr int EN_CVGPR = 32;
+constexpr int EN_CVGPR = 24;
+#define EN_LD "24"
 #else
-constexpr int EN_CVGPR = 48;
+constexpr int EN_CVGPR = 40;
+#define EN_LD "40"
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -151,11 +162,53 @@ __device__ __forceinline__ unsigned en_read_acc() {
     asm volatile("v_mov_b32 %0, v[64+%1]" : "=v"(x) : "n"(K));
     return x;
 }
+// Stream / d loads land in RESERVED registers (value v[LD : LD+1], meta v[LD+2], d v[LD+4 : LD+5]) and are
+// handed to the compiler only behind the wait, inside ONE asm statement.  (With the destinations as ordinary
+// "=v" outputs and the wait as a separate asm with "+v" operands the compiler is free to copy the
+// still-in-flight registers BEFORE the wait -- it did, in one of the three wait variants of the f32 kernel.)
+template <typename F>
+__device__ __forceinline__ void en_load_stream(unsigned voff_v, const F *vp, unsigned voff_m, const unsigned *mp) {
+    if constexpr (sizeof(F) == 8)
+        asm volatile("global_load_dwordx2 v[" EN_LD ":" EN_LD "+1], %0, %1\n\t"
+                     "global_load_dword v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
+    else
+        asm volatile("global_load_dword v[" EN_LD "], %0, %1\n\t"
+                     "global_load_dword v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
+}
+template <typename F>
+__device__ __forceinline__ void en_load_d(unsigned voff, const F *dp) {
+    if constexpr (sizeof(F) == 8)
+        asm volatile("global_load_dwordx2 v[" EN_LD "+4:" EN_LD "+5], %0, %1" :: "v"(voff), "s"(dp) : "memory");
+    else
+        asm volatile("global_load_dword v[" EN_LD "+4], %0, %1" :: "v"(voff), "s"(dp) : "memory");
+}
+// wait until at most N of the most recently issued vector-memory operations are outstanding (they complete
+// in order), then take the stream registers and the d register
+template <int N>
+__device__ __forceinline__ void en_take(double &v, unsigned &m, double &dd) {
+    unsigned vl, vh, dl, dh;
+    asm volatile("s_waitcnt vmcnt(%5)\n\t"
+                 "v_mov_b32 %0, v[" EN_LD "]\n\tv_mov_b32 %1, v[" EN_LD "+1]\n\tv_mov_b32 %2, v[" EN_LD "+2]\n\t"
+                 "v_mov_b32 %3, v[" EN_LD "+4]\n\tv_mov_b32 %4, v[" EN_LD "+5]"
+                 : "=v"(vl), "=v"(vh), "=v"(m), "=v"(dl), "=v"(dh) : "n"(N) : "memory");
+    v = __hiloint2double((int)vh, (int)vl);
+    dd = __hiloint2double((int)dh, (int)dl);
+}
+template <int N>
+__device__ __forceinline__ void en_take(float &v, unsigned &m, float &dd) {
+    unsigned vl, dl;
+    asm volatile("s_waitcnt vmcnt(%3)\n\t"
+                 "v_mov_b32 %0, v[" EN_LD "]\n\tv_mov_b32 %1, v[" EN_LD "+2]\n\tv_mov_b32 %2, v[" EN_LD "+4]"
+                 : "=v"(vl), "=v"(m), "=v"(dl) : "n"(N) : "memory");
+    v = __uint_as_float(vl);
+    dd = __uint_as_float(dl);
+}
+// (the builtin, not asm: the compiler's hazard recognizer does not look inside asm statements, and a
+// v_readlane right behind the VALU instruction that wrote its source read the OLD register -- lane 0 of the
+// f32 kernel, whose `jv = e & 0xff` happened to be scheduled directly in front of the first read)
 template <int I>
 __device__ __forceinline__ int en_lane_to_s(unsigned v) {
-    int s;
-    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(s) : "v"(v), "n"(I));
-    return s;
+    return __builtin_amdgcn_readlane((int)v, I);
 }
 #else
 struct en_rsrc_t {};
@@ -166,6 +219,9 @@ template <int I, int WAIT, typename F> __device__ void en_fma(int, F) {}
 template <typename F> __device__ void en_zero_acc() {}
 template <int K> __device__ unsigned en_read_acc() { return 0u; }
 template <int I> __device__ int en_lane_to_s(unsigned) { return 0; }
+template <typename F> __device__ void en_load_stream(unsigned, const F *, unsigned, const unsigned *) {}
+template <typename F> __device__ void en_load_d(unsigned, const F *) {}
+template <int N, typename F> __device__ void en_take(F &, unsigned &, F &) {}
 #endif
 
 // One batch of N = 16 (or 8: the odd unit at the end of a block) entries: a = value * d, kq = LDS address
@@ -175,8 +231,10 @@ template <int N, typename F>
 __device__ __forceinline__ void en_batch(F a, unsigned kq, unsigned jv, unsigned lane_off) {
     int sj[N];
     static_for<N>([&](auto ic) { sj[decltype(ic)::value] = en_lane_to_s<decltype(ic)::value>(jv); });
-    // (no scalar load may be in flight: SMEM returns out of order and would make the counted waits unsafe)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (no scalar load may be in flight: SMEM returns out of order and would make the counted waits unsafe;
+    // s_nop 1: a DPP operand needs two wait states behind the VALU write of its register, and the compiler does
+    // not know that the statements below read kq and a through DPP)
+    asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(0)" : "+v"(kq), "+v"(a) :: "memory");
     static_for<EN_NSLOT>([&](auto ic) { en_issue<F, decltype(ic)::value>(kq, lane_off); });
     static_for<N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -191,7 +249,7 @@ __device__ __forceinline__ void en_batch(F a, unsigned kq, unsigned jv, unsigned
 // add their entry's value * d to a per-wave LDS array of 16 doubles, one ds_add_f64 per batch.
 template <typename F, bool CSUM>
 __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR))) void csr_dense_ent_kernel(
-    const F *__restrict__ vals, const unsigned short *__restrict__ meta, const unsigned *__restrict__ uptr,
+    const F *__restrict__ vals, const unsigned *__restrict__ meta, const unsigned *__restrict__ bstart,
     int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
     int nB, const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_csum, long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -203,6 +261,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
     constexpr int RSH = sizeof(F) == 8 ? 10 : 9;           // log2(ROWB)
     constexpr int JSH = sizeof(F) == 8 ? 2 : 1;            // accumulator registers per column: 4 / 2
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int l16 = lane & 15;
@@ -214,6 +273,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
     const int ns = (int)(min(s0 + slabs_per_block, n_slabs) - s0);   // slabs of this workgroup
     const unsigned lane_off = (unsigned)lane * 16u / (sizeof(F) == 8 ? 1u : 2u);
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_byte *)smem_raw;
+    u4 *scratch = reinterpret_cast<u4 *>(smem_raw + L::SCR_OFF) + wave * EN_SB;
     double *cs_lds = reinterpret_cast<double *>(smem_raw + L::CS_OFF) + wave * EN_C;
 
     en_zero_acc<F>();
@@ -233,119 +293,82 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
     const int64_t bstride = (int64_t)EN_R * r * (int64_t)sizeof(F);
     const char *bnext = reinterpret_cast<const char *>(B) + s0 * bstride;        // slab to copy next
     int64_t bleft = n * r * (int64_t)sizeof(F) - s0 * bstride;                     // bytes from there on
-    auto issue_piece = [&](int buf, int i) {
+    auto issue_pieces = [&](int buf, int lo, int hi) {
 #if defined(EN_ABL_NOCOPY)            // timing only: the slab of B is never refreshed
         if (bnext != reinterpret_cast<const char *>(B) + s0 * bstride) return;
 #endif
-        en_buf_to_lds16(en_rsrc(bnext, bleft), smem_raw + ROWB + buf * SLABB + (wave * NV + i) * RPP * ROWB,
-                        (int)boff0, (int)(i * pstride));
-    };
-
-    // ---- the wave's stream: fetch cursor (two batches ahead of the one worked on) ----
-    // window of block starts: lane l holds uptr[group][wbase + l]; units of slab s = lane s+1 - lane s
-    const unsigned *urow = uptr + (int64_t)(active ? group : 0) * (n_slabs + 1);
-    int64_t wbase = s0;
-    unsigned uwin = 0u;
-    // (a synchronous load written as asm: once per 63 slabs.  As a plain load the compiler cannot tell at the
-    // loop's merge points whether it is still in flight, and puts s_waitcnt vmcnt(0) in front of EVERY lookup
-    // -- right behind the requests of the stream and of d, whose latency is then paid once per slab)
-    auto load_window = [&]() {
-        const unsigned *p = urow + min(wbase + lane, n_slabs);
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(uwin) : "v"(p) : "memory");
-#else
-        uwin = *p;
-#endif
-    };
-    load_window();
-    int fs = -1, fb = 0, fnb = 0, fnu = 0;          // slab (relative), batch inside it, its batches / units
-    int64_t fpos = active ? (int64_t)__builtin_amdgcn_readfirstlane((int)uwin) * EN_U : 0;   // slot of the cursor
-    // (unit indices are uint32; slots = units * 8 as int64)
-    fpos = active ? (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)uwin) * EN_U : 0;
-    auto units_of = [&](int s) -> int {             // units of slab s (relative) of this wave's group
-        int64_t a = s0 + s;
-        if (a - wbase >= 63) {
-            wbase = a;
-            load_window();
-        }
-        const int o = (int)(a - wbase);
-        return (int)((unsigned)__builtin_amdgcn_readlane((int)uwin, o + 1) -
-                     (unsigned)__builtin_amdgcn_readlane((int)uwin, o));
-    };
-    struct Desc { int slab; bool half; };
-    auto fetch = [&](F &v, unsigned &m, Desc &ds) {
-        while (fb >= fnb && fs < ns) {              // next non-empty slab
-            ++fs;
-            fb = 0;
-            fnu = (fs < ns && active) ? units_of(fs) : 0;
-            fnb = (fnu + 1) >> 1;
-        }
-        if (fs >= ns) {
-            ds.slab = ns;
-            ds.half = false;
-            v = F(0);
-            m = 0u;
-            return;
-        }
-        ds.slab = fs;
-        ds.half = fb == fnb - 1 && (fnu & 1);
-#if defined(EN_ABL_NOSTREAM)          // timing only: every batch re-reads the first 16 slots of the group's stream
-        v = vals[(int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)uwin) * 0 + l16];
-        m = meta[l16];
-#else
-        v = vals[fpos + l16];
-        m = meta[fpos + l16];
-#endif
-        fpos += ds.half ? EN_U : 2 * EN_U;
-        ++fb;
-    };
-    // pipeline of batches: P3 {v, m} requested; P2 {v, m} here, d requested; P1 {v, m, d} here; P0 folded
-    // {a = v * d, kq = LDS address of the row, jv = accumulator offset}.  Per batch worked on: stage A (the
-    // requests: d of P2, stream of P3), the copy pieces of the next slab, the batch, stage B (fold P1).  Every
-    // value is used one whole batch (~1500 cycles) after its request, and the s_waitcnt vmcnt(0) of the
-    // barrier that ends a slab finds only requests of that age.
-    F v3 = F(0), v2 = F(0), v1 = F(0), d2 = F(0), d1 = F(0), a0 = F(0);
-    unsigned m3 = 0u, m2 = 0u, m1 = 0u, kq0 = lds_base, jv0 = 0u;
-    Desc q3{-1, false}, q2{-1, false}, q1{-1, false}, q0{-1, false};
-    const F *dbase = d + s0 * EN_R;
-    auto stage_a = [&]() {
-        // P2 <- P3, its d requested (padding: row 0 of the slab, masked by rf == 0 at the fold)
-        v2 = v3;
-        m2 = m3;
-        q2 = q3;
-        if (q2.slab >= 0 && q2.slab < ns) {
-            const unsigned rf2 = (m2 >> 4) & 0x7fu;
-            d2 = dbase[(int64_t)q2.slab * EN_R + (int)(rf2 ? rf2 - 1u : 0u)];
-        } else {
-            d2 = F(0);
-        }
-        // P3 <- the batch at the cursor
-        fetch(v3, m3, q3);
-    };
-    auto stage_b = [&]() {
-        // P0 <- fold(P1); P1 <- P2
-        const unsigned rf = (m1 >> 4) & 0x7fu;
-        const bool ok = rf != 0u && d1 != F(0);
-        a0 = ok ? v1 * d1 : F(0);
-        kq0 = ok ? lds_base + (unsigned)(q1.slab & 1) * (unsigned)SLABB + (rf << RSH) : lds_base;
-        jv0 = (m1 & 15u) << JSH;
-        q0 = q1;
-        v1 = v2;
-        m1 = m2;
-        d1 = d2;
-        q1 = q2;
-    };
-
-    // prologue: slab 0 of the range into buffer 0; the pipeline filled
 #pragma unroll
-    for (int i = 0; i < NV; ++i) issue_piece(0, i);
+        for (int i = 0; i < NV; ++i)
+            if (i >= lo && i < hi)
+            en_buf_to_lds16(en_rsrc(bnext, bleft), smem_raw + ROWB + buf * SLABB + (wave * NV + i) * RPP * ROWB,
+                            (int)boff0, (int)(i * pstride));
+    };
+
+    // ---- the wave's stream: batches [b0, b0 + nbw) of its group ----
+    const unsigned *brow = bstart + (int64_t)(active ? group : 0) * (n_slabs + 1);
+    const unsigned b0 = active ? brow[s0] : 0u;
+    const int nbw = active ? (int)(brow[s0 + ns] - b0) : 0;
+    // superbatch k = slots (b0 + 4 k) * 16 + lane; registers: X {vx, mx} = the superbatch being loaded,
+    // Y {vy, my} = the one that has arrived (folded next), dy = the d of Y's rows (being gathered)
+    const F *vbase = vals + (int64_t)b0 * EN_B;
+    const unsigned *mbase = meta + (int64_t)b0 * EN_B;
+    F vx = F(0), vy = F(0), dy = F(0);
+    unsigned mx = 0u, my = 0u;
+    const unsigned lane_v = (unsigned)lane * (unsigned)sizeof(F), lane_m = (unsigned)lane * 4u;
+    // (the loads are written as asm so that THIS code places the waits: the compiler would wait with
+    // vmcnt(0) at every use, i.e. also for the copy pieces of the next slab issued a moment before)
+    auto request_stream = [&](int k) {
+        en_load_stream<F>(lane_v, vbase + (int64_t)k * EN_SB, lane_m, mbase + (int64_t)k * EN_SB);
+    };
+    auto request_d = [&]() {          // d of Y's rows (row < 2^28: a 32-bit byte offset)
+        en_load_d<F>((my >> 4) * (unsigned)sizeof(F), d);
+    };
+    auto wait_loads = [&](auto nc) { en_take<decltype(nc)::value>(vx, mx, dy); };
+    int psince = 0;                    // copy pieces issued since the last requests
+    int lsince = 0;                    // stream / d loads requested since the last copy pieces
+    (void)lsince;
+    const unsigned s0u = (unsigned)s0;
+    // boundary k: fold superbatch k (= Y, dy) into the scratch, Y <- X = superbatch k + 1, requests
+    auto boundary = [&](int k) {
+        // (everything requested before the last `psince` pieces has arrived once at most that many operations
+        // are outstanding; a smaller count only waits longer)
+        if (psince == 0) wait_loads(std::integral_constant<int, 0>{});
+        else if (psince < NV) wait_loads(std::integral_constant<int, NV / 2>{});
+        else if (psince < 2 * NV) wait_loads(std::integral_constant<int, NV>{});
+        else wait_loads(std::integral_constant<int, 2 * NV>{});
+        const unsigned rowg = my >> 4;
+        const unsigned srel = (rowg >> 6) - s0u;
+        const bool ok = vy != F(0) && dy != F(0);
+        const F a = ok ? vy * dy : F(0);
+        const unsigned kq = ok ? lds_base + (srel & 1u) * (unsigned)SLABB + (((rowg & 63u) + 1u) << RSH) : lds_base;
+        const unsigned jvs = ((my & 15u) << JSH) | (srel << 8);
+        u4 e;
+        if constexpr (sizeof(F) == 8) {
+            e = u4{(unsigned)__double2loint(a), (unsigned)__double2hiint(a), kq, jvs};
+        } else {
+            e = u4{__float_as_uint(a), 0u, kq, jvs};
+        }
+        scratch[lane] = e;
+        if constexpr (CSUM) {
+            if (4 * k * EN_B + lane < nbw * EN_B) atomic_add(cs_lds + (my & 15u), (double)a);
+        }
+        vy = vx;
+        my = mx;
+        request_d();
+        request_stream(k + 2);
+        psince = 0;
+        lsince += 3;
+    };
+    // prologue: slab 0 of the range into buffer 0; superbatches 0 (arrived) and 1 (requested), d of 0
+    issue_pieces(0, 0, NV);
     bnext += bstride;
     bleft -= bstride;
-    fetch(v3, m3, q3);
-    stage_a();
-    stage_b();
-    stage_a();
-    stage_b();
+    request_stream(0);
+    wait_loads(std::integral_constant<int, 0>{});
+    vy = vx;
+    my = mx;
+    request_d();
+    request_stream(1);
     __syncthreads();
 
 #if defined(EN_PROF)                  // cycles per section (tm_tune_set("ent_prof", device pointer))
@@ -356,56 +379,89 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #else
 #define EN_TICK(acc)
 #endif
-    for (int w = 0; w < ns; ++w) {
-        const int buf = w & 1;
+    int w = 0;                         // slab being worked on (relative)
+    int ncopied = 0;                   // pieces of slab w + 1 issued so far
+    auto end_slab = [&]() {
         const bool more = w + 1 < ns;
-        int pieces = 0;                              // copy pieces of the next slab issued so far
-        int bi = 0;
-        while (q0.slab == w) {
-            stage_a();
-            EN_TICK(pt_a)
-            // pieces before batch 0: half of them; one more before each later batch
-            const int want = more ? min(NV, NV / 2 + bi) : 0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (i >= pieces && i < want) issue_piece(buf ^ 1, i);
-            pieces = max(pieces, want);
-            EN_TICK(pt_p)
-            if constexpr (CSUM) {
-                // (the upper 8 lanes of a half batch hold the first entries of the NEXT block)
-                if (lane < (q0.half ? EN_U : 2 * EN_U)) atomic_add(cs_lds + (jv0 >> JSH), (double)a0);
-            }
-#if defined(EN_ABL_NOBATCH)           // timing only: the memory side alone
-            asm volatile("" ::"v"(a0), "v"(kq0), "v"(jv0));
-#else
-            if (q0.half)
-                en_batch<8, F>(a0, kq0, jv0, lane_off);
-            else
-                en_batch<16, F>(a0, kq0, jv0, lane_off);
-#endif
-            EN_TICK(pt_x)
-            stage_b();
-            EN_TICK(pt_b)
-#if defined(EN_PROF)
-            ++pt_n;
-#endif
-            ++bi;
-        }
         if (more) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (i >= pieces) issue_piece(buf ^ 1, i);
+            if (ncopied < NV) {
+                issue_pieces((w & 1) ^ 1, ncopied, NV);
+                psince += NV - ncopied;
+                lsince = 0;
+            }
             bnext += bstride;
             bleft -= bstride;
         }
         EN_TICK(pt_p)
-#if defined(EN_ABL_NOBARRIER)         // timing only (wrong results): waves run free
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        __syncthreads();
+        // the copy pieces of the next slab must have landed; the stream / d requests issued AFTER them may
+        // stay in flight (a plain __syncthreads() waits with vmcnt(0): for a request of a moment ago that is
+        // a full HBM round trip in front of the barrier, once per slab on average)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lsince == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (lsince == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
         EN_TICK(pt_bar)
+        ncopied = 0;
+        ++w;
+    };
+    u4 enext = u4{0u, 0u, 0u, 0u};
+    for (int b = 0; b < nbw; ++b) {
+        const int q = b & 3;
+        u4 e;
+        if (q == 0) {
+            boundary(b >> 2);
+            e = scratch[l16];
+        } else {
+            e = enext;
+        }
+        // (the folded slots of the next batch are fetched behind this batch's LDS reads; batch 0 of a
+        // superbatch has to wait for the fold)
+        if (q != 3) enext = scratch[(q + 1) * EN_B + l16];
+        EN_TICK(pt_a)
+#if defined(EN_DEBUG)
+        if (prof != nullptr && b == 0 && wave == 0 && blockIdx.x == 0) {
+            unsigned *o = reinterpret_cast<unsigned *>(prof) + lane * 8;
+            o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3];
+            o[4] = (unsigned)__builtin_amdgcn_readlane((int)(e[3] & 0xffu), 0);
+            o[5] = (unsigned)__builtin_amdgcn_readlane((int)(e[3] & 0xffu), 1);
+            o[6] = my; o[7] = lds_base;
+        }
+#endif
+        const int slab = __builtin_amdgcn_readfirstlane((int)(e[3] >> 8));
+        while (w < slab) end_slab();
+#if defined(EN_PIECE_SPLIT)           // half of the pieces with the first batch of a slab, half with the second
+        if (ncopied < NV && w + 1 < ns) {
+            issue_pieces((w & 1) ^ 1, ncopied, ncopied + NV / 2);
+            ncopied += NV / 2;
+            psince += NV / 2;
+            lsince = 0;
+        }
+#else
+        if (ncopied == 0 && w + 1 < ns) {   // first batch of the slab: the copy of the next one starts now
+            issue_pieces((w & 1) ^ 1, 0, NV);
+            ncopied = NV;
+            psince += NV;
+            lsince = 0;
+        }
+#endif
+        EN_TICK(pt_p)
+        F a;
+        if constexpr (sizeof(F) == 8) a = __hiloint2double((int)e[1], (int)e[0]);
+        else a = __uint_as_float(e[0]);
+#if defined(EN_ABL_NOBATCH)           // timing only: the memory side alone
+        asm volatile("" ::"v"(a), "v"(e[2]), "v"(e[3]));
+#else
+        en_batch<EN_B, F>(a, e[2], e[3] & 0xffu, lane_off);
+#endif
+        EN_TICK(pt_x)
+#if defined(EN_PROF)
+        ++pt_n;
+#endif
     }
+    while (w < ns) end_slab();
+    // (requests still in flight must land before the wave ends: their registers are this wave's)
+    wait_loads(std::integral_constant<int, 0>{});
 #if defined(EN_PROF)
     if (prof != nullptr && lane == 0) {
         long long *o = prof + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (EN_NW * 8) + wave * 8;
@@ -419,7 +475,6 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         static_for<EN_C>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (sizeof(F) == 8) {
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
                 const u4 o = u4{en_read_acc<4 * j>(), en_read_acc<4 * j + 1>(), en_read_acc<4 * j + 2>(),
                                 en_read_acc<4 * j + 3>()};
                 *reinterpret_cast<u4 *>(dst + j * EN_W + 2 * lane) = o;
@@ -456,7 +511,7 @@ __global__ void en_csum_kernel(const F *__restrict__ part, int nblk, int64_t m, 
 }
 
 template <typename F>
-static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n, int64_t m,
+static int run_csr_dense_ent(const F *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n, int64_t m,
                              const F *B, int64_t r, const F *d, F *out, F *colsum, hipStream_t st) {
     const int64_t nB = r;
     const int64_t total = m * nB;
@@ -469,6 +524,10 @@ static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t
     if (m % EN_C != 0) {
         set_error("tm_csr_dense_sandwich_ent: m must be a multiple of tm_ent_group_cols()");
         return TM_EINVAL;
+    }
+    if (n >= (1ll << 28)) {      // meta = row << 4 | column
+        set_error("tm_csr_dense_sandwich_ent: at most 2^28 - 1 rows per block (work in row parts)");
+        return TM_EUNSUPPORTED;
     }
     const int64_t n_slabs = ceil_div(n, EN_R);
     const int n_groups = (int)(m / EN_C);
@@ -500,7 +559,7 @@ static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_parts, (unsigned)nz), dim3(EN_THREADS), lds, st,
-                       vals, meta, uptr, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws, ws_csum,
+                       vals, meta, bstart, n_groups, n_slabs, spb, B, n, r, (int)nB, d, ws, ws_csum,
                        reinterpret_cast<long long *>((uintptr_t)tune("ent_prof", 0)));
     prof_end(st);
     TM_LAUNCH_CHECK();
@@ -522,16 +581,16 @@ static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t
 extern "C" {
 int tm_ent_rows(void) { return tmh::EN_R; }
 int tm_ent_group_cols(void) { return tmh::EN_C; }
-int tm_ent_unit_slots(void) { return tmh::EN_U; }
+int tm_ent_batch_slots(void) { return tmh::EN_B; }
 
-int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const float *B, int64_t r, const float *d, float *out,
                                   float *colsum, void *stream) {
-    return tmh::run_csr_dense_ent<float>(vals, meta, uptr, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
+    return tmh::run_csr_dense_ent<float>(vals, meta, bstart, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
 }
-int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *uptr, int64_t n,
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const double *B, int64_t r, const double *d, double *out,
                                   double *colsum, void *stream) {
-    return tmh::run_csr_dense_ent<double>(vals, meta, uptr, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
+    return tmh::run_csr_dense_ent<double>(vals, meta, bstart, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
 }
 }  // extern "C"

@@ -558,32 +558,40 @@ class SlabEnt:
     """Entry twin of a sparse block for tm_csr_dense_sandwich_ent_* (csrc/sparse_ent.hip, round 4): rows in
     slabs of R = 64, columns dealt to G groups of C = 16 (one wave each) in the order of their density
     (rank r -> group r % G: the groups of a workgroup carry equal shares of every slab).  The entries
-    {value, (1 + row in slab) << 4 | column in group} of block (group, slab) are padded to units of 8
-    slots; blocks follow one another slab after slab, group after group; uptr[g, s] = first unit of the
-    block.  10 bytes per nonzero + padding (7 % at 5 % density).  Built once per block on the device."""
+    {value, row << 4 | column in group} of block (group, slab) are padded to whole batches of 16 slots
+    (padding: value 0, the row of the block's first entry); blocks follow one another slab after slab, group
+    after group; bstart[g, s] = first batch of the block.  12 bytes per slot, 1.16 slots per nonzero at 5 %
+    density and 512 columns.  Built once per block on the device."""
 
-    vals: torch.Tensor     # F[T + 16]
-    meta: torch.Tensor     # int16[T + 16] (read as uint16)
-    uptr: torch.Tensor     # int32[G, S + 1] (read as uint32)
+    vals: torch.Tensor     # F[T + 192]
+    meta: torch.Tensor     # int32[T + 192]
+    bstart: torch.Tensor   # int32[G, S + 1] (read as uint32)
     inv: torch.Tensor      # int64[m]  kernel row of column c of the block
     n: int
     m: int
     mk: int                # kernel rows = G * C
 
+    SLACK = 192            # slots past the end that the kernel's look-ahead loads may touch
+
     @property
     def dtype(self):
         return self.vals.dtype
 
+    def nbytes(self) -> int:
+        return sum(int(t.numel()) * t.element_size() for t in (self.vals, self.meta, self.bstart))
+
     @staticmethod
     def from_csr(csr: CsrDev, max_pad: float = None) -> "SlabEnt":
         """Returns None when the padded stream would exceed max_pad x nnz slots (very sparse blocks: every
-        non-empty (group, slab) block costs at least 8 slots)."""
+        non-empty (group, slab) block costs at least 16 slots) or the block has 2^28 rows or more."""
         from .._lib import lib
 
         R = int(lib().tm_ent_rows())
         C = int(lib().tm_ent_group_cols())
-        U = int(lib().tm_ent_unit_slots())
+        U = int(lib().tm_ent_batch_slots())
         n, m = csr.n, csr.m
+        if n >= (1 << 28):
+            return None
         dev = csr.data.device
         S = (n + R - 1) // R
         G = max(1, (m + C - 1) // C)
@@ -597,40 +605,46 @@ class SlabEnt:
         jloc_of = torch.div(rank, G, rounding_mode="floor")
         inv = grp_of * C + jloc_of
         del order, colcnt, rank
+        SL = SlabEnt.SLACK
         if nnz == 0 or S == 0:
-            return SlabEnt(torch.zeros(16, dtype=csr.data.dtype, device=dev),
-                           torch.zeros(16, dtype=torch.int16, device=dev),
+            return SlabEnt(torch.zeros(SL, dtype=csr.data.dtype, device=dev),
+                           torch.zeros(SL, dtype=torch.int32, device=dev),
                            torch.zeros((G, S + 1), dtype=torch.int32, device=dev), inv, n, m, G * C)
         counts = csr.indptr[1:] - csr.indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
         key = grp_of[idx64] * S + torch.div(rows, R, rounding_mode="floor")
         cnt = torch.bincount(key, minlength=G * S)
-        units = torch.div(cnt + (U - 1), U, rounding_mode="floor")
-        total_units = int(units.sum().item())
-        if max_pad is not None and total_units * U > max_pad * nnz and total_units * U > (1 << 22):
+        nb = torch.div(cnt + (U - 1), U, rounding_mode="floor")
+        total_b = int(nb.sum().item())
+        if max_pad is not None and total_b * U > max_pad * nnz and total_b * U > (1 << 22):
             return None
-        if total_units >= 2**31:
+        if total_b >= 2**31 // U:
             return None
-        ustart = torch.zeros(G * S + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(units, dim=0, out=ustart[1:])
-        del units
+        bst = torch.zeros(G * S + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nb, dim=0, out=bst[1:])
         # stable: CSR order is row-sorted, entries of a block stay in (row, column) order
         key_sorted, perm = torch.sort(key, stable=True)
         del key
         first = torch.cumsum(cnt, dim=0) - cnt
-        pos = ustart[key_sorted] * U + (torch.arange(nnz, device=dev, dtype=torch.int64) - first[key_sorted])
-        del first, cnt, key_sorted
-        T = total_units * U
-        vals = torch.zeros(T + 16, dtype=csr.data.dtype, device=dev)
-        meta = torch.zeros(T + 16, dtype=torch.int16, device=dev)
+        pos = bst[key_sorted] * U + (torch.arange(nnz, device=dev, dtype=torch.int64) - first[key_sorted])
+        del key_sorted
+        T = total_b * U
+        rows_p = rows[perm]
+        del rows
+        # padding slots: value 0, the row of the block's first entry (a valid row of the same slab)
+        nz = cnt > 0
+        frow = (rows_p[first[nz]] << 4).to(torch.int32)
+        meta = torch.zeros(T + SL, dtype=torch.int32, device=dev)
+        meta[:T] = torch.repeat_interleave(frow, nb[nz] * U)
+        del frow, nz, first, cnt, nb
+        vals = torch.zeros(T + SL, dtype=csr.data.dtype, device=dev)
         vals[pos] = csr.data[perm]
-        mt = ((torch.remainder(rows[perm], R) + 1) << 4) | jloc_of[idx64[perm]]
-        meta[pos] = mt.to(torch.int16)
-        del pos, mt, perm, rows, idx64
+        meta[pos] = ((rows_p << 4) | jloc_of[idx64[perm]]).to(torch.int32)
+        del pos, perm, rows_p, idx64
         gi = torch.arange(G, device=dev, dtype=torch.int64)[:, None] * S + \
             torch.arange(S + 1, device=dev, dtype=torch.int64)[None, :]
-        uptr = ustart[gi].to(torch.int32).contiguous()
-        return SlabEnt(vals, meta, uptr, inv, n, m, G * C)
+        bstart = bst[gi].to(torch.int32).contiguous()
+        return SlabEnt(vals, meta, bstart, inv, n, m, G * C)
 
 
 def onehot_slab(cats, n: int, dtype: torch.dtype):

@@ -159,7 +159,7 @@ def csr_dense_sandwich_ent(A: SlabEnt, B: DenseDev, d, want_colsum=False):
     out = D.out_buf((A.mk, B.m), dt)
     cs = D.out_buf((A.mk,), dt) if want_colsum else None
     D.same_float("csr_dense_sandwich_ent", A.vals, B.buf, d)
-    call("tm_csr_dense_sandwich_ent_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.meta), D.p(A.uptr), A.n, A.mk,
+    call("tm_csr_dense_sandwich_ent_" + D.fsuf(A.vals), D.p(A.vals), D.p(A.meta), D.p(A.bstart), A.n, A.mk,
          D.p(B.buf), B.m, D.p(d), D.p(out), D.p(cs), D.stream_ptr())
     return (out[A.inv], cs[A.inv]) if want_colsum else out[A.inv]
 
