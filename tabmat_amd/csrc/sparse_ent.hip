@@ -51,6 +51,9 @@ constexpr int EN_THREADS = EN_NW * 64;
 constexpr int EN_W = 128;           // dense columns per part
 constexpr int EN_B = 16;            // slots per batch
 constexpr int EN_SB = 64;           // slots per superbatch (lane <-> slot)
+#ifndef EN_PIECE_AT
+#define EN_PIECE_AT 0               // a wave issues its copy pieces in front of this batch of a slab
+#endif
 #ifndef EN_NSLOT
 #define EN_NSLOT 4                  // LDS reads in flight per wave (landing slots): 4 or 8
 #endif
@@ -139,6 +142,36 @@ __device__ __forceinline__ void en_fma(int sj, float a) {
                  : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I)
                  : "m0");
 }
+// entry I's two FMAs and the LDS read of entry NX = I + EN_NSLOT in ONE asm statement (between two asm
+// statements the compiler puts an s_nop 0 -- two issue slots per entry of ten)
+template <int I, int WAIT, int NX>
+__device__ __forceinline__ void en_step(int sj, double a, unsigned kq, unsigned lane_off) {
+    unsigned tmp;
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
+                 "s_set_gpr_idx_on %1, 0xc\n\t"
+                 "v_fmac_f64_dpp v[64:65], %2, v[" EN_XD "+4*%4:" EN_XD "+4*%4+1] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp v[66:67], %2, v[" EN_XD "+4*%4+2:" EN_XD "+4*%4+3] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "v_add_u32_dpp %0, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "ds_read_b128 v[" EN_XD "+4*%4:" EN_XD "+4*%4+3], %0"
+                 : "=&v"(tmp)
+                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I), "v"(kq), "v"(lane_off), "n"(NX)
+                 : "m0");
+}
+template <int I, int WAIT, int NX>
+__device__ __forceinline__ void en_step(int sj, float a, unsigned kq, unsigned lane_off) {
+    unsigned tmp;
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
+                 "s_set_gpr_idx_on %1, 0xc\n\t"
+                 "v_fmac_f32_dpp v64, %2, v[" EN_XF "+2*%4] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp v65, %2, v[" EN_XF "+2*%4+1] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_set_gpr_idx_off\n\t"
+                 "v_add_u32_dpp %0, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "ds_read_b64 v[" EN_XF "+2*%4:" EN_XF "+2*%4+1], %0"
+                 : "=&v"(tmp)
+                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I), "v"(kq), "v"(lane_off), "n"(NX)
+                 : "m0");
+}
 // all accumulators = 0; the clobber of the highest register is what sizes the wave's register allocation
 // (.amdhsa_next_free_vgpr): the compiler itself stays below EN_CVGPR
 template <typename F>
@@ -217,6 +250,7 @@ __device__ inline void en_buf_to_lds16(en_rsrc_t, void *, int, int) {}
 template <typename F, int I> __device__ void en_issue(unsigned, unsigned) {}
 template <int I, int WAIT, typename F> __device__ void en_fma(int, F) {}
 template <typename F> __device__ void en_zero_acc() {}
+template <int I, int WAIT, int NX, typename F> __device__ void en_step(int, F, unsigned, unsigned) {}
 template <int K> __device__ unsigned en_read_acc() { return 0u; }
 template <int I> __device__ int en_lane_to_s(unsigned) { return 0; }
 template <typename F> __device__ void en_load_stream(unsigned, const F *, unsigned, const unsigned *) {}
@@ -239,8 +273,8 @@ __device__ __forceinline__ void en_batch(F a, unsigned kq, unsigned jv, unsigned
     static_for<N>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int wait = i + EN_NSLOT < N ? EN_NSLOT - 1 : N - 1 - i;
-        en_fma<i, wait>(sj[i], a);
-        if constexpr (i + EN_NSLOT < N) en_issue<F, i + EN_NSLOT>(kq, lane_off);
+        if constexpr (i + EN_NSLOT < N) en_step<i, wait, i + EN_NSLOT>(sj[i], a, kq, lane_off);
+        else en_fma<i, wait>(sj[i], a);
     });
 }
 
@@ -381,6 +415,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #endif
     int w = 0;                         // slab being worked on (relative)
     int ncopied = 0;                   // pieces of slab w + 1 issued so far
+    int bis = 0;                       // batches of slab w worked on so far
     auto end_slab = [&]() {
         const bool more = w + 1 < ns;
         if (more) {
@@ -403,6 +438,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #endif
         EN_TICK(pt_bar)
         ncopied = 0;
+        bis = 0;
         ++w;
     };
     u4 enext = u4{0u, 0u, 0u, 0u};
@@ -438,7 +474,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
             lsince = 0;
         }
 #else
-        if (ncopied == 0 && w + 1 < ns) {   // first batch of the slab: the copy of the next one starts now
+        if (ncopied == 0 && w + 1 < ns && bis >= EN_PIECE_AT) {   // the copy of the next slab starts here
             issue_pieces((w & 1) ^ 1, 0, NV);
             ncopied = NV;
             psince += NV;
@@ -455,6 +491,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         en_batch<EN_B, F>(a, e[2], e[3] & 0xffu, lane_off);
 #endif
         EN_TICK(pt_x)
+        ++bis;
 #if defined(EN_PROF)
         ++pt_n;
 #endif

@@ -10,7 +10,7 @@ from scipy import sparse as sps
 
 from . import _device as D
 from .ext import sparse as xs
-from .ext._types import CsrDev, SlabCsc, SlabEll, SlabLg
+from .ext._types import CsrDev, SlabCsc, SlabEll, SlabEnt, SlabLg
 from .matrix_base import MatrixBase
 from .util import (
     check_indexer,
@@ -158,6 +158,15 @@ class SparseMatrix(MatrixBase):
             self._lgblk = twin if twin is not None else False
         return self._lgblk if self._lgblk is not False else None
 
+    def _ent(self) -> SlabEnt:
+        """Entry twin for the run-time-indexed sparse x dense kernel (round 4, csrc/sparse_ent.hip; C-ordered B
+        with more than 64 columns); None when the block is so sparse that whole batches of 16 slots per
+        (slab, column group) would exceed ELL_MAX_PAD x the nonzeros, or has 2^28 rows or more."""
+        if getattr(self, "_entblk", None) is None:
+            twin = SlabEnt.from_csr(self._dev(), max_pad=ELL_MAX_PAD)
+            self._entblk = twin if twin is not None else False
+        return self._entblk if self._entblk is not False else None
+
     def to_device(self, dense_width=None):
         """Upload and build the twins now (otherwise the first product does it).  dense_width:
         columns of the dense block this one will be crossed with (SplitMatrix.to_device passes it)
@@ -165,7 +174,7 @@ class SparseMatrix(MatrixBase):
         self._dev().chunk_major()
         self._slab()
         if dense_width is not None and dense_width > 0:
-            if dense_width <= 64 or self._lg() is None:
+            if dense_width <= 64 or (self._ent() is None and self._lg() is None):
                 self._ell(wide=dense_width > 64)
         return self
 
@@ -404,11 +413,18 @@ class SparseMatrix(MatrixBase):
                     if R_cols is not None:
                         res = res[:, R_cols.to(torch.int64)]
                     return res
-                lg = self._lg() if (Bd.m > 64 and xs.ell_supported(Bd)) else None
+                wide = Bd.m > 64 and xs.ell_supported(Bd)
+                ent = self._ent() if wide else None
+                lg = self._lg() if (wide and ent is None) else None
                 ell = None
-                if lg is None and xs.ell_supported(Bd):
+                if ent is None and lg is None and xs.ell_supported(Bd):
                     ell = self._ell(wide=Bd.m > 64)
-                if lg is not None and colsum_box is not None:
+                if ent is not None and colsum_box is not None:
+                    res, cs = xs.csr_dense_sandwich_ent(ent, Bd, d, want_colsum=True)
+                    colsum_box.append(cs if L_cols is None else cs[L_cols.to(torch.int64)])
+                elif ent is not None:
+                    res = xs.csr_dense_sandwich_ent(ent, Bd, d)
+                elif lg is not None and colsum_box is not None:
                     res, cs = xs.csr_dense_sandwich_lg(lg, Bd, d, want_colsum=True)
                     colsum_box.append(cs if L_cols is None else cs[L_cols.to(torch.int64)])
                 elif lg is not None:

@@ -196,7 +196,8 @@ def _spy_xtd(mat, d):
 def test_xtd_in_one_pass_without_a_complete_categorical(design):
     """X' d of the dense block comes out of the syrk's own pass
     (tm_dense_sandwich_i8_xtd_f64 / tm_dense_sandwich_co_f64) and X' d of the sparse block out of the gather's stream loop
-    (tm_csr_dense_sandwich_lg_xtd_*): no transpose_matvec entry point runs even when no categorical
+    (tm_csr_dense_sandwich_ent_* with a colsum pointer since round 4; tm_csr_dense_sandwich_lg_xtd_* / lgc
+    before): no transpose_matvec entry point runs even when no categorical
     block is complete (reference: standardized_mat.py:149-150 makes a second pass)."""
     import tabmat_amd as tm
 
@@ -216,7 +217,8 @@ def test_xtd_in_one_pass_without_a_complete_categorical(design):
     assert not any(s.startswith(("tm_dense_rmatvec", "tm_csr_rmatvec", "tm_dense_matvec",
                                  "tm_csr_matvec")) for s in seen), seen
     assert any(s.startswith("tm_dense_sandwich_i8_") or s == "tm_dense_sandwich_co_f64" for s in seen)
-    assert any(s.startswith(("tm_csr_dense_sandwich_lgc_", "tm_csr_dense_sandwich_lg_xtd")) for s in seen)
+    assert any(s.startswith(("tm_csr_dense_sandwich_ent_", "tm_csr_dense_sandwich_lgc_",
+                             "tm_csr_dense_sandwich_lg_xtd")) for s in seen)
     want = mat.transpose_matvec(d)
     assert float((xtd - want).abs().max() / want.abs().max()) < 1e-12
     full = mat.sandwich(d)

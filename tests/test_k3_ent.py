@@ -1,0 +1,175 @@
+"""Entry twin of a sparse block (tabmat_amd/ext/_types.py::SlabEnt) and the run-time-indexed sparse x dense
+kernel on it (csrc/sparse_ent.hip, round 4; reference: ext/sparse.pyx:211-260 csr_dense_sandwich ->
+ext/sparse_helpers-tmpl.cpp:23-146).
+
+CPU part: the twin builder is plain torch, so its output is decoded here exactly the way the kernel walks it
+(groups, batches of 16 slots, meta = row << 4 | column, bstart) and compared with the matrix.  GPU part: the
+kernel through the C ABI against the oracle's csr_dense_sandwich -- float64 within 1e-10 (observed 1e-15),
+float32 within 2e-5 of the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse as sps
+
+from tabmat_amd.ext._types import CsrDev, SlabEnt
+
+R, C, U = 64, 16, 16
+
+
+def _csr_cpu(S, dtype):
+    S = sps.csr_matrix(S).astype(dtype)
+    S.sort_indices()
+    return CsrDev(torch.from_numpy(S.data.copy()), torch.from_numpy(S.indices.astype(np.int32)),
+                  torch.from_numpy(S.indptr.astype(np.int64)), S.shape[0], S.shape[1])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,density", [(300, 40, 0.05), (64, 16, 0.5), (129, 33, 0.2), (1000, 512, 0.02),
+                                         (5, 3, 1.0), (200, 20, 0.0)])
+def test_twin_decodes_to_the_matrix(n, m, density, dtype):
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
+    S.data += 0.5          # no explicit zeros
+    tw = SlabEnt.from_csr(_csr_cpu(S, dtype))
+    G = tw.mk // C
+    nS = (n + R - 1) // R
+    assert tw.bstart.shape == (G, nS + 1)
+    vals, meta, bst = tw.vals.numpy(), tw.meta.numpy().view(np.uint32), tw.bstart.numpy().view(np.uint32)
+    assert vals.shape[0] == meta.shape[0] == int(bst[-1, -1]) * U + SlabEnt.SLACK
+    assert not vals[int(bst[-1, -1]) * U:].any() and not meta[int(bst[-1, -1]) * U:].any()    # the slack
+    dense = np.zeros((tw.mk, n))
+    prev_end = 0
+    for g in range(G):
+        assert bst[g, 0] == prev_end                      # groups follow one another
+        for s in range(nS):
+            b0, b1 = int(bst[g, s]), int(bst[g, s + 1])
+            assert b1 >= b0
+            real = 0
+            for q in range(b0 * U, b1 * U):
+                row, col = int(meta[q]) >> 4, int(meta[q]) & 15
+                assert s * R <= row < min((s + 1) * R, n)  # every slot (padding too) names a row of ITS slab
+                if vals[q] != 0:
+                    assert dense[g * C + col, row] == 0
+                    dense[g * C + col, row] = vals[q]
+                    real += 1
+            assert (b1 - b0) == (real + U - 1) // U        # whole batches, no empty ones
+        prev_end = int(bst[g, nS])
+    np.testing.assert_array_equal(dense[tw.inv.numpy()].T, S.toarray().astype(dtype))
+
+
+def test_twin_refuses_what_the_kernel_cannot_index():
+    S = sps.random(4000, 2048, density=0.0005, format="csr", random_state=np.random.default_rng(0))
+    assert SlabEnt.from_csr(_csr_cpu(S, np.float64), max_pad=8.0) is not None    # small: always built
+    csr = _csr_cpu(sps.csr_matrix((1, 4)), np.float64)
+    csr.n = 1 << 28
+    assert SlabEnt.from_csr(csr) is None
+
+
+# ------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def _ent_vs_oracle(n, m, k, density, dtype, seed, d_zero_every=0, want_colsum=False, poison=False):
+    from oracle import oracle as orc
+    from tabmat_amd.ext import sparse as xs
+    from tabmat_amd.ext._types import DenseDev
+
+    rng = np.random.default_rng(seed)
+    S = sps.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
+    S.data = rng.standard_normal(S.data.shape[0])
+    S = S.astype(dtype)
+    S.sort_indices()
+    B = rng.standard_normal((n, k)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    if d_zero_every:
+        d[::d_zero_every] = 0
+        if poison:                      # a row with d == 0 may hold anything: inf * 0 must not leak
+            B[::d_zero_every] = np.inf
+    csr = CsrDev(torch.from_numpy(S.data.copy()).cuda(), torch.from_numpy(S.indices.astype(np.int32)).cuda(),
+                 torch.from_numpy(S.indptr.astype(np.int64)).cuda(), n, m)
+    tw = SlabEnt.from_csr(csr)
+    Bd = DenseDev(torch.from_numpy(B).cuda(), n, k, 0)
+    res = xs.csr_dense_sandwich_ent(tw, Bd, torch.from_numpy(d).cuda(), want_colsum=want_colsum)
+    Bref = B.astype(np.float64)
+    if poison:
+        Bref[::d_zero_every] = 0.0
+    ref = orc.csr_dense_sandwich(S.astype(np.float64).tocsr(), Bref, d.astype(np.float64), None, None, None)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    out = res[0] if want_colsum else res
+    scale = max(np.abs(ref).max(), 1e-300)
+    assert np.abs(out.cpu().numpy().astype(np.float64) - ref).max() / scale < tol
+    if want_colsum:
+        cref = S.astype(np.float64).T @ d.astype(np.float64)
+        assert np.abs(res[1].cpu().numpy() - cref).max() / max(np.abs(cref).max(), 1e-300) < tol
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,k,density", [
+    (1000, 40, 128, 0.3),        # many batches per block
+    (5003, 100, 136, 0.05),      # ragged last slab, ragged second dense part
+    (70, 16, 128, 0.9),          # one group, almost dense
+    (20011, 512, 256, 0.02),     # two workgroups of column groups, two dense parts
+    (64 * 300 + 1, 300, 128, 0.004),   # most blocks empty: slabs without a batch
+    (3, 1, 128, 1.0),
+])
+def test_ent_kernel_vs_oracle(n, m, k, density, dtype):
+    _ent_vs_oracle(n, m, k, density, dtype, seed=n + m)
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ent_kernel_zero_weights_and_colsum(dtype):
+    _ent_vs_oracle(9000, 200, 128, 0.05, dtype, seed=5, d_zero_every=3, want_colsum=True)
+    _ent_vs_oracle(9000, 200, 128, 0.05, dtype, seed=6, d_zero_every=5, want_colsum=False, poison=True)
+
+
+@gpu
+def test_ent_kernel_explicit_zero_values_and_empty_matrix():
+    from tabmat_amd.ext import sparse as xs
+    from tabmat_amd.ext._types import DenseDev
+
+    n, m, k = 500, 32, 128
+    rng = np.random.default_rng(1)
+    S = sps.random(n, m, density=0.2, format="csr", random_state=rng, dtype=np.float64)
+    S.data[::4] = 0.0                    # stored zeros stay harmless
+    S.sort_indices()
+    B = rng.standard_normal((n, k))
+    d = rng.random(n)
+    for mat in (S, sps.csr_matrix((n, m))):
+        csr = CsrDev(torch.from_numpy(mat.data.copy()).cuda(), torch.from_numpy(mat.indices.astype(np.int32)).cuda(),
+                     torch.from_numpy(mat.indptr.astype(np.int64)).cuda(), n, m)
+        tw = SlabEnt.from_csr(csr)
+        out = xs.csr_dense_sandwich_ent(tw, DenseDev(torch.from_numpy(B).cuda(), n, k, 0), torch.from_numpy(d).cuda())
+        ref = mat.T @ (d[:, None] * B)
+        assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0)
+
+
+@gpu
+def test_sparse_matrix_takes_the_entry_kernel():
+    """SparseMatrix x DenseMatrix of more than 64 C-ordered columns runs on the entry twin."""
+    import tabmat_amd as tm
+    from tabmat_amd import _lib
+
+    rng = np.random.default_rng(2)
+    n = 4000
+    S = sps.random(n, 100, density=0.05, format="csc", random_state=rng)
+    X = rng.standard_normal((n, 128))
+    sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(X)
+    d = rng.random(n)
+    seen = []
+    orig = _lib.call
+
+    def spy(name, *a):
+        seen.append(name)
+        return orig(name, *a)
+
+    import tabmat_amd.ext.sparse as xs_mod
+    xs_mod.call = spy
+    try:
+        out = sm._cross_sandwich(dm, d, None, None, None)
+    finally:
+        xs_mod.call = orig
+    assert any(s.startswith("tm_csr_dense_sandwich_ent_") for s in seen), seen
+    ref = S.T @ (d[:, None] * X)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-12
