@@ -40,6 +40,27 @@ __device__ __forceinline__ void issue_read(u32x32 &X, unsigned kq, unsigned lane
                  : "+{v[32:63]}"(X), "=&v"(tmp)
                  : "v"(kq), "v"(lane_off), "n"(I), "n"(I % 8));
 }
+// MODE 6: the batch's 16 LDS addresses are formed first; the index mode then stays ON over the whole batch
+// (s_set_gpr_idx_idx changes the index only; DS instructions are not indexed)
+template <int I>
+__device__ __forceinline__ unsigned make_addr(unsigned kq, unsigned lane_off) {
+    unsigned r;
+    asm volatile("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(kq), "v"(lane_off), "n"(I));
+    return r;
+}
+template <int I>
+__device__ __forceinline__ void read_at(u32x32 &X, unsigned addr) {
+    asm volatile("ds_read_b128 v[32+4*%2:32+4*%2+3], %1" : "+{v[32:63]}"(X) : "v"(addr), "n"(I % 8));
+}
+template <int I, int WAIT>
+__device__ __forceinline__ void fma_idx(d16 &T0, d16 &T1, u32x32 &X, int sj, double a) {
+    asm volatile("s_waitcnt lgkmcnt(%6)\n\t"
+                 "s_set_gpr_idx_idx %3\n\t"
+                 "v_fmac_f64_dpp v[64:65], %4, v[32+4*%5:32+4*%5+1] row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp v[66:67], %4, v[32+4*%5+2:32+4*%5+3] row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                 : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
+                 : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
+}
 template <int I>
 __device__ __forceinline__ int lane_to_s(unsigned v) {
     int s;
@@ -62,6 +83,23 @@ __device__ __forceinline__ void fma_entry(d16 &T0, d16 &T1, u32x32 &X, int sj, d
                      "v_fmac_f64_dpp v[66:67], %4, v[32+4*%5+2:32+4*%5+3] row_newbcast:%7 row_mask:0xf bank_mask:0xf"
                      : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
                      : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
+    } else if constexpr (MODE == 3) {      // static accumulator, plain fmac (no DPP)
+        asm volatile("s_waitcnt lgkmcnt(%6)\n\t"
+                     "v_fmac_f64 v[64:65], %4, v[32+4*%5:32+4*%5+1]\n\t"
+                     "v_fmac_f64 v[66:67], %4, v[32+4*%5+2:32+4*%5+3]"
+                     : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
+                     : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
+    } else if constexpr (MODE == 4) {      // LDS reads only
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
+                     : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
+    } else if constexpr (MODE == 5) {      // index mode + fmac_dpp, no waiting for LDS (issue only)
+        asm volatile("s_set_gpr_idx_on %3, 0xc\n\t"
+                     "v_fmac_f64_dpp v[64:65], %4, v[32+4*%5:32+4*%5+1] row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp v[66:67], %4, v[32+4*%5+2:32+4*%5+3] row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_set_gpr_idx_off"
+                     : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
+                     : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
     } else {
         long long sv = ((long long)(unsigned)shi << 32) | (unsigned)slo;
         asm volatile("s_waitcnt lgkmcnt(%6)\n\t"
@@ -75,6 +113,9 @@ __device__ __forceinline__ void fma_entry(d16 &T0, d16 &T1, u32x32 &X, int sj, d
 }
 #else
 template <int I> void issue_read(u32x32 &, unsigned, unsigned) {}
+template <int I> unsigned make_addr(unsigned, unsigned) { return 0; }
+template <int I> void read_at(u32x32 &, unsigned) {}
+template <int I, int WAIT> void fma_idx(d16 &, d16 &, u32x32 &, int, double) {}
 template <int I> int lane_to_s(unsigned) { return 0; }
 template <int MODE, int I, int WAIT> void fma_entry(d16 &, d16 &, u32x32 &, int, double, int, int) {}
 #endif
@@ -122,13 +163,27 @@ __global__ __launch_bounds__(1024) void kidx(double *out, const double *vals_all
                     slo[i] = shi[i] = 0;
                 }
             });
-            sfor<8>([&](auto ic) { issue_read<decltype(ic)::value>(X, kq, lane_off); });
+            if constexpr (MODE == 6) {
+                unsigned ad[16];
+                sfor<16>([&](auto ic) { ad[decltype(ic)::value] = make_addr<decltype(ic)::value>(kq, lane_off); });
+                sfor<8>([&](auto ic) { read_at<decltype(ic)::value>(X, ad[decltype(ic)::value]); });
+                asm volatile("s_set_gpr_idx_on %0, 0xc" :: "s"(sj[0]) : "m0");
+                sfor<16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int wait = i <= 8 ? 7 : 15 - i;
+                    fma_idx<i, wait>(T0, T1, X, sj[i], a);
+                    if constexpr (i + 8 < 16) read_at<i + 8>(X, ad[i + 8]);
+                });
+                asm volatile("s_set_gpr_idx_off");
+            } else {
+            if constexpr (MODE != 5) sfor<8>([&](auto ic) { issue_read<decltype(ic)::value>(X, kq, lane_off); });
             sfor<16>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int wait = i <= 8 ? 7 : 15 - i;
                 fma_entry<MODE, i, wait>(T0, T1, X, sj[i], a, slo[i], shi[i]);
-                if constexpr (i + 8 < 16) issue_read<i + 8>(X, kq, lane_off);
+                if constexpr (i + 8 < 16 && MODE != 5) issue_read<i + 8>(X, kq, lane_off);
             });
+            }
         }
     }
     double *o = out + ((size_t)blockIdx.x * (nth / 64) + wave) * 16 * 128;
@@ -193,6 +248,10 @@ int main() {
         run(kidx<0>, "index mode, fmac_dpp", nw, true);
         run(kidx<1>, "static accumulator (wrong sums)", nw, false);
         run(kidx<2>, "index mode, VOP3 fma, SGPR value", nw, true);
+        run(kidx<6>, "index mode on over the batch, idx_idx", nw, true);
+        run(kidx<3>, "static accumulator, fmac without DPP", nw, false);
+        run(kidx<4>, "LDS reads only (no FMA)", nw, false);
+        run(kidx<5>, "index mode + fmac_dpp only (no LDS)", nw, false);
     }
     return 0;
 }

@@ -258,7 +258,7 @@ template <typename F> __device__ void en_load_d(unsigned, const F *) {}
 template <int N, typename F> __device__ void en_take(F &, unsigned &, F &) {}
 #endif
 
-// One batch of N = 16 (or 8: the odd unit at the end of a block) entries: a = value * d, kq = LDS address
+// One batch of N = 16 (or 4 / 8 / 12: the end of a block) entries: a = value * d, kq = LDS address
 // of the entry's row (the zero row for padding / d == 0), jv = accumulator register offset of its column;
 // entry i lives in lane i of every row of 16 lanes.
 template <int N, typename F>
@@ -431,10 +431,15 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         // the copy pieces of the next slab must have landed; the stream / d requests issued AFTER them may
         // stay in flight (a plain __syncthreads() waits with vmcnt(0): for a request of a moment ago that is
         // a full HBM round trip in front of the barrier, once per slab on average)
+#if defined(EN_ABL_NOBARRIER)         // timing only (wrong results): the waves of a workgroup run free
+#define EN_BAR ""
+#else
+#define EN_BAR "\n\ts_barrier"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (lsince == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (lsince == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (lsince == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" EN_BAR ::: "memory");
+        else if (lsince == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" EN_BAR ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" EN_BAR ::: "memory");
 #endif
         EN_TICK(pt_bar)
         ncopied = 0;
@@ -488,7 +493,15 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #if defined(EN_ABL_NOBATCH)           // timing only: the memory side alone
         asm volatile("" ::"v"(a), "v"(e[2]), "v"(e[3]));
 #else
-        en_batch<EN_B, F>(a, e[2], e[3] & 0xffu, lane_off);
+        // Slots behind the batch's last one with a != 0 add nothing (the padding of a block sits at its end:
+        // 7.5 of 59 slots per block at BASELINE configs[3]): the batch is worked on in quads of 4 slots.
+        const unsigned live = (unsigned)__builtin_amdgcn_ballot_w64(a != F(0)) & 0xffffu;
+        const int nq = live ? ((31 - __builtin_clz(live)) >> 2) + 1 : 0;
+        const unsigned jv = e[3] & 0xffu;
+        if (nq == 4) en_batch<16, F>(a, e[2], jv, lane_off);
+        else if (nq == 3) en_batch<12, F>(a, e[2], jv, lane_off);
+        else if (nq == 2) en_batch<8, F>(a, e[2], jv, lane_off);
+        else if (nq == 1) en_batch<4, F>(a, e[2], jv, lane_off);
 #endif
         EN_TICK(pt_x)
         ++bis;
