@@ -34,6 +34,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (AMD datasheet; not in the guide's table)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 (MI355X_MICROARCH.md; 2:1-sparsity figures are never used)
+# LDS: "Aggregate with every CU streaming (~2.4 GHz): ~150 TB/s for ds_read_b64/b128" (MI355X_MICROARCH.md, LDS
+# section; 64 banks x 4 B x 256 CUs x 2.4 GHz = 157 TB/s is the array's width)
+LDS_PEAK_GBS = 150000.0
 
 
 def _baseline_metric():
@@ -188,6 +191,34 @@ def op_algorithmic_bytes(mat, name):
     i = int("".join(ch for ch in a if ch.isdigit()))
     j = int("".join(ch for ch in b if ch.isdigit()))
     return blk_bytes(mats[i]) + blk_bytes(mats[j]) + n * isz + mats[i].shape[1] * mats[j].shape[1] * isz
+
+
+def op_lds_bytes(mat, name):
+    """Algorithmic LDS bytes of ONE launch of the named op's main kernel, for the kernels whose inner loop is
+    an LDS gather / scatter ("the bounding roofline"): sparse x dense = one row of the dense
+    operand (its columns x itemsize) read from the LDS slab per nonzero; sparse self = one 8-byte LDS atomic per
+    pair of nonzeros of a row (lower triangle).  None for the streaming kernels."""
+    import tabmat_amd as tm
+
+    mats = mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat]
+    isz = np.dtype(mat.dtype).itemsize
+    if name.endswith(".self"):
+        i = int("".join(ch for ch in name.split(".")[0] if ch.isdigit()))
+        if isinstance(mats[i], tm.SparseMatrix):
+            c = (mats[i]._dev().indptr[1:] - mats[i]._dev().indptr[:-1]).to(torch.float64)
+            return float((c * (c + 1) / 2).sum().item()) * 8.0
+        return None
+    if name.startswith("allcats_x_"):
+        return None
+    a, b = name.split("x")
+    i = int("".join(ch for ch in a if ch.isdigit()))
+    j = int("".join(ch for ch in b if ch.isdigit()))
+    pair = {type(mats[i]), type(mats[j])}
+    if pair == {tm.SparseMatrix, tm.DenseMatrix}:
+        sp = mats[i] if isinstance(mats[i], tm.SparseMatrix) else mats[j]
+        dn = mats[j] if sp is mats[i] else mats[i]
+        return float(sp._dev().data.numel()) * dn.shape[1] * isz
+    return None
 
 
 def op_flops(mat, name):
@@ -469,6 +500,35 @@ def main():
         per_step.append(e0.elapsed_time(e1))
     ms_min = min(per_step)
 
+    # what arithmetic the dense self term ran in, and the same step with the int8-sliced syrk switched off
+    dense_term, handovers, ms_f64_only = None, None, None
+    if tdt == torch.float64 and not use_graph:
+        dms = [m for m in (mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat])
+               if isinstance(m, tm.DenseMatrix)]
+        took_i8 = [m for m in dms if getattr(m, "_i8_hist", None) is not None]
+        if dms:
+            dense_term = ("int8x5 (40-bit fixed point per column on the int8 matrix cores, K1e; hand-over to "
+                          "the f64 MFMA kernel outside its envelope)") if took_i8 else "f64 MFMA"
+        if took_i8:
+            hist = took_i8[0]._i8_history().cpu().tolist()       # {consecutive envelope misses, calls}
+            handovers = {"consecutive_envelope_misses": int(hist[0]), "calls": int(hist[1])}
+            was = tm.set_strict_f64(True)
+            try:
+                for _ in range(max(1, args.warmup)):
+                    step()
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                ms_f64_only = (time.perf_counter() - t1) / args.steps * 1e3
+            finally:
+                tm.set_strict_f64(was)
+
     alg_bytes = synth.algorithmic_bytes(mat)
     flops = synth.algorithmic_flops(mat) if isinstance(mat, tm.SplitMatrix) else (
         float(n_local) * p * (p + 1) if isinstance(mat, tm.DenseMatrix) else float(n_local))
@@ -496,13 +556,22 @@ def main():
             mfma_note = ("f32 syrk as 6 bf16 piece products (3-piece split, f32 accumulation): achieved = "
                          "6 x n k (k + 1) bf16 flop / kernel time, peak = dense bf16 MFMA")
         mfma_time = (dom_flops / (peak_tf * 1e12)) if dom_flops else 0.0
-        if mfma_time > hbm_time:
+        dom_lds = op_lds_bytes(mat, dom)
+        lds_time = (dom_lds / (LDS_PEAK_GBS * 1e9)) if dom_lds else 0.0
+        # the bounding roofline of the dominant kernel: the largest of its HBM, MFMA and LDS times
+        if lds_time > max(hbm_time, mfma_time):
+            roof = {"bound": "lds", "achieved": round(dom_lds / (dom_ms * 1e-3) / 1e9, 1),
+                    "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                    "algorithmic_lds_bytes_per_launch": int(dom_lds)}
+        elif mfma_time > hbm_time:
             roof = {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 3),
                     "peak": peak_tf, "unit": "TFLOP/s"}
         else:
             roof = {"bound": "hbm", "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        # (the same kernel against the HBM roofline, whatever binds it)
+        roof["frac_hbm"] = round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # HBM bytes per launch of that kernel, measured NOW: rocprofv3 --pmc passes over a child
         # run that launches the same op (null when rocprofv3 is unavailable or N > 1)
         roof["traffic"] = None
@@ -555,6 +624,9 @@ def main():
                                            flops * (6.0 if mfma_note else 1.0) / world / (peak_tf * 1e12)) * 1e3, 4),
             "mfma_frac_of_spec": mfma_frac,
             "sum_kernel_ms": round(sum(bd.values()), 4),
+            "dense_term": dense_term,
+            "dense_term_handover": handovers,
+            "ms_per_step_f64_only": None if ms_f64_only is None else round(ms_f64_only, 4),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,

@@ -1,3 +1,6 @@
+# NOTE (round 4): the guest-stream / stream-fan hooks this harness drives (split_matrix.OVERLAP, _StreamFan) were
+# removed from the product path after rounds 2-3 measured them at 0.0-0.3 ms (profiles/r3_coresidency.txt);
+# it runs against the tree of commit 60e1c99.
 """One cfg4 step under rocprofv3 --kernel-trace: start / end of every kernel of the last step."""
 import os
 import sys

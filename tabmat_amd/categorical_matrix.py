@@ -159,7 +159,11 @@ class CategoricalMatrix(MatrixBase):
         return self._dev_codes
 
     def to_device(self):
+        """Upload the codes and take the ingest-time statistics now (the hot-level count that chooses the
+        categorical x categorical kernel: a host synchronisation that must not happen inside a product -- a HIP
+        graph capture, or a solver's timed loop)."""
         self._dev()
+        self._hot_count()
         return self
 
     def _onehot(self, tdt=None):
@@ -219,12 +223,17 @@ class CategoricalMatrix(MatrixBase):
             kind, *arg = device_row_index(row, self.shape[0])
             codes = self._dev_codes[arg[0]:arg[1]] if kind == "slice" else \
                 self._dev_codes[D.idx_dev(arg[0], torch.int64)]
-            return CategoricalMatrix(codes.contiguous(), categories=self.categories,
-                                     drop_first=self.drop_first, dtype=self.dtype,
-                                     column_name=self._colname, term_name=self._term,
-                                     column_name_format=self._colname_format,
-                                     cat_missing_method=self._missing_method,
-                                     cat_missing_name=self._missing_category, _validated=True)
+            out = CategoricalMatrix(codes.contiguous(), categories=self.categories,
+                                    drop_first=self.drop_first, dtype=self.dtype,
+                                    column_name=self._colname, term_name=self._term,
+                                    column_name_format=self._colname_format,
+                                    cat_missing_method=self._missing_method,
+                                    cat_missing_name=self._missing_category, _validated=True)
+            # (the parent's hot-level count bounds the slice's when no row is repeated: no new count, no sync)
+            if getattr(self, "_hot", None) is not None and (
+                    kind == "slice" or np.unique(arg[0]).size == len(arg[0])):
+                out._hot = min(self._hot, out.shape[0])
+            return out
         if full:
             if isinstance(row, np.ndarray):
                 row = row.ravel()

@@ -64,7 +64,20 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
     const int4 w = wg_tab[2 * blockIdx.x], x = wg_tab[2 * blockIdx.x + 1];
     const int part = __builtin_amdgcn_readfirstlane(w.x), slot = __builtin_amdgcn_readfirstlane(w.y);
     const int b0 = __builtin_amdgcn_readfirstlane(w.z), b1 = __builtin_amdgcn_readfirstlane(w.w);
-    const int bfull = __builtin_amdgcn_readfirstlane(x.x), wfull = __builtin_amdgcn_readfirstlane(x.y);
+    const int bfull = __builtin_amdgcn_readfirstlane(x.x);
+    // waves on the FULL list: the table is built for KB_WAVES waves; a launch with fewer (tm_tune_set
+    // "k2b_waves") rescales the split -- at least one wave per non-empty list, or blocks would be skipped
+    int wfull = __builtin_amdgcn_readfirstlane(x.y);
+    {
+        const int nwv = (int)(blockDim.x >> 6);
+        if (nwv != KB_WAVES) {
+            wfull = (wfull * nwv + KB_WAVES / 2) / KB_WAVES;
+            if (bfull > b0) wfull = max(wfull, 1);
+            if (b1 > bfull) wfull = min(wfull, nwv - 1);
+            if (bfull == b0) wfull = 0;
+            if (b1 == bfull) wfull = nwv;
+        }
+    }
     int I = (int)((sqrtf(8.0f * (float)part + 1.0f) - 1.0f) * 0.5f);
     while ((I + 1) * (I + 2) / 2 <= part) ++I;
     while (I * (I + 1) / 2 > part) --I;

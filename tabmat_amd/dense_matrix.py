@@ -34,6 +34,24 @@ SYRK_I8 = os.environ.get("TABMAT_AMD_SYRK_I8", "1") != "0"
 I8_MIN_ROWS = 4096
 
 
+def set_strict_f64(flag: bool = True) -> bool:
+    """strict = True: every float64 sandwich runs on the float64 MFMA / vector units.  By default the dense
+    self term of a qualifying block (C-ordered, 66..128 even columns, >= 4096 rows, finite) is computed in
+    40-bit fixed point per column on the int8 matrix cores (K1e, csrc/syrk_i8.hip): entry-wise error below
+    1e-10 * sqrt(S_ii S_jj) by its on-device envelope check (observed 2e-14 of max|S|), the bar BASELINE.json
+    sets -- but not IEEE float64 to the last bits, and StandardizedMatrix amplifies it by (mean / std)^2 of
+    uncentred columns.  Takes effect at the next call (no cache to clear); returns the previous setting.
+    TABMAT_AMD_SYRK_I8=0 sets strict mode at import."""
+    global SYRK_I8
+    old = not SYRK_I8
+    SYRK_I8 = not flag
+    return old
+
+
+def strict_f64() -> bool:
+    return not SYRK_I8
+
+
 class DenseMatrix(MatrixBase):
     """Dense block.  Construct from a numpy array (kept on the host, uploaded lazily on the
     first product) or from an (n, m) torch cuda tensor (no host copy)."""
@@ -179,11 +197,14 @@ class DenseMatrix(MatrixBase):
         if hit is None:
             hit = False
             blk = self._dev_c()
-            if (SYRK_I8 and not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= 128
+            if (not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= 128
                     and blk.m % 2 == 0 and blk.n >= I8_MIN_ROWS and blk.buf.data_ptr() % 16 == 0):
-                cmax = blk.as_2d().abs().amax(dim=0)
-                if bool(torch.isfinite(cmax).all().item()):
-                    hit = cmax.contiguous()
+                # (two reductions, no |X| copy of the block: it is 10 GB at BASELINE configs[3]; a NaN
+                # propagates through amax / amin, +-inf shows in one of them)
+                x = blk.as_2d()
+                hi, lo = x.amax(dim=0), x.amin(dim=0)
+                if bool((torch.isfinite(hi) & torch.isfinite(lo)).all().item()):
+                    hit = torch.maximum(hi, -lo).contiguous()
             self._i8_ok = hit
         return None if hit is False else hit
 
@@ -195,7 +216,7 @@ class DenseMatrix(MatrixBase):
         return h
 
     def _sandwich_dev(self, d, rows, cols):
-        if rows is None and cols is None and d.dtype == torch.float64:
+        if SYRK_I8 and rows is None and cols is None and d.dtype == torch.float64:
             cmax = self._i8_colmax()
             if cmax is not None:
                 return xd.dense_sandwich_i8(self._dev_c(), d, cmax, history=self._i8_history())
@@ -207,7 +228,7 @@ class DenseMatrix(MatrixBase):
         standardized_mat.py:149-150): the int8-sliced syrk (K1e) inside its envelope, else the f64
         syrk with the column sums of its A-side fragments (K1c)."""
         blk = self._dev_c()
-        if d.dtype == torch.float64:
+        if SYRK_I8 and d.dtype == torch.float64:
             cmax = self._i8_colmax()
             if cmax is not None:
                 return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True, history=self._i8_history())

@@ -49,6 +49,19 @@ def shard(mat, world_size: Optional[int] = None, rank: Optional[int] = None, gro
     return RowShardedMatrix(mat[lo:hi], group, bounds=(lo, hi), n_global=n, always_reduce=always_reduce)
 
 
+class PendingReduce:
+    """Handle of an all-reduce in flight (RowShardedMatrix.sandwich_async)."""
+
+    def __init__(self, value, work, finish):
+        self._value, self._work, self._finish = value, work, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._value if self._finish is None else self._finish(self._value)
+
+
 class RowShardedMatrix:
     """Wraps the LOCAL row shard (any MatrixBase) of a matrix that is row-partitioned over the
     ranks of `group`.  d / v passed to the products are the local slices (length = local rows);
@@ -96,6 +109,25 @@ class RowShardedMatrix:
     def sandwich(self, d, rows=None, cols=None):
         """rows: LOCAL row ids of this shard (use bucket_rows for a global list)."""
         return self._all_reduce(self._sandwich(d, rows, cols))
+
+    def sandwich_async(self, d, rows=None, cols=None) -> "PendingReduce":
+        """The local partial is computed and its all-reduce STARTED (async_op): RCCL runs it on its own
+        stream, ordered behind the kernels queued so far, while the caller's next launches -- typically the
+        transpose_matvec of the same IRLS iteration, which does not depend on the Hessian -- proceed on the
+        current stream.  `.wait()` orders the current stream behind the collective and returns the sum.
+        The collective needs the COMPLETE p x p partial (every block product scatters into it), so inside one
+        sandwich there is nothing to overlap it with; across the two products of an iteration there is."""
+        x = self._sandwich(d, rows, cols)
+        if not dist.is_initialized() or (self.world_size == 1 and not self.always_reduce):
+            return PendingReduce(x, None, None)
+        if isinstance(x, torch.Tensor):
+            return PendingReduce(x, dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None)
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        on_dev = dist.get_backend(self.group) == "nccl"
+        if on_dev:
+            t = t.cuda()
+        return PendingReduce(t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                             (lambda y: y.cpu().numpy()) if on_dev else (lambda y: y.numpy()))
 
     def transpose_matvec(self, v, rows=None, cols=None):
         return self._all_reduce(self._tmv(v, rows, cols))

@@ -32,23 +32,11 @@ from .util import (
 )
 
 
-# TABMAT_AMD_STREAMS=k (k > 1): the independent block products of one sandwich are issued on k HIP
-# streams (every stream has its own library workspace) and joined before the result is returned.
-# Measured at cfg4 (profiles/r2_microbench.txt): 17.5 ms with one stream, 18.7 / 19.2 / 18.3 ms with
-# 2 / 4 / 8 -- the big kernels cannot share a CU (each takes the whole LDS or register file), so
-# nothing overlaps but their tails, and interleaved workgroups of different kernels break the L2
-# pairing the kernels are laid out for.  Off by default; kept as the evidence for that choice.
-N_STREAMS = max(1, int(os.environ.get("TABMAT_AMD_STREAMS", "1")))
-# TABMAT_AMD_OVERLAP=1: the dense self sandwich as a GUEST kernel on a side stream
-# (tm_dense_sandwich_co_f64): it shares the compute units with the categorical cross terms and the
-# sparse self sandwich, which are launched with 12 instead of 16 waves so that its registers fit.
-# Measured (profiles/r3_coresidency.txt): the workgroups DO share compute units (placement log:
-# every guest workgroup beside a partner workgroup on its CU), but the pair gains 0.2-0.3 ms at
-# best -- v_mfma_f64 runs at the vector f64 rate on gfx950 and queues in the same VALU issue slots
-# as the partners' instructions -- and the step is no faster than with the same kernel run in
-# line (16.06 vs 16.05 ms).  Off by default; kept as the measurement harness for that result.
-OVERLAP = os.environ.get("TABMAT_AMD_OVERLAP", "0") == "1"
-OVERLAP_KNOBS = {"k2_waves": 12, "catdense_waves": 12, "catsparse_waves": 12}
+# (Rounds 2 and 3 measured two ways of running the block products of one sandwich concurrently -- k HIP streams,
+# and the dense syrk as a co-resident guest kernel -- at 0.0-0.3 ms gain for a 15 ms step: every big kernel fills
+# a compute unit's LDS or registers, and the f64 syrk queues in the same VALU issue slots as its partners
+# (profiles/r2_microbench.txt, profiles/r3_coresidency.txt).  The harnesses live in scripts/dev/overlap_step.py;
+# the product path launches its kernels in line on the current stream.)
 # row lists shorter than this share of n take the row-list form of the fused categorical x sparse term
 ROW_LIST_FRACTION_CATSPARSE = float(os.environ.get("TABMAT_AMD_ROW_LIST_CATSPARSE", "0.04"))
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
@@ -60,6 +48,10 @@ CAT_PAIRS_FUSED = os.environ.get("TABMAT_AMD_CAT_PAIRS", "1") != "0"
 # columns only, so the entries are the same; the unrestricted kernels are the tuned ones).  matvec:
 # zeros in the coefficient vector instead.
 FULL_THEN_SELECT = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT", "0.5"))
+# ... but only while the full (p, p) result stays small and the blocks WITHOUT a selected column (skipped by the
+# restricted path, as by the reference) are at most this share of the product's work (_full_product_pays)
+FULL_RESULT_MAX_BYTES = 256 << 20
+FULL_UNSELECTED_SHARE = 0.2
 # matvec / transpose_matvec stream all of X whatever the selection (row-major dense rows, CSR): the
 # unrestricted kernels are never slower (cfg4 shape, 2M rows, 5 % of the columns: 0.88 / 0.99 ms
 # restricted, 0.55 / 0.60 ms unrestricted + selection), so they always take this form
@@ -75,69 +67,6 @@ NARROW_COLS = int(os.environ.get("TABMAT_AMD_NARROW_COLS", "128"))
 # twins of its own -- 288 GB of HBM hold blocks of several 10^9 nonzeros.
 from . import categorical_matrix as _cm
 from . import sparse_matrix as _spm      # PART_NNZ lives there (also used by SparseMatrix itself)
-
-
-class _StreamFan:
-    """Round-robin side streams for independent launches; join() makes the current stream wait."""
-
-    def __init__(self, k):
-        self.k = k
-        self.i = 0
-        if k > 1:
-            self.main = torch.cuda.current_stream()
-            self.start = torch.cuda.Event()
-            self.start.record(self.main)
-            pool = getattr(_StreamFan, "_pool", None)
-            if pool is None or len(pool) < k:
-                pool = _StreamFan._pool = [torch.cuda.Stream() for _ in range(k)]
-            self.streams = pool[:k]
-            self.used = set()
-
-    def lane(self):
-        if self.k <= 1:
-            import contextlib
-
-            return contextlib.nullcontext()
-        s = self.streams[self.i % self.k]
-        self.i += 1
-        if s not in self.used:
-            s.wait_event(self.start)
-            self.used.add(s)
-        return torch.cuda.stream(s)
-
-    def join(self):
-        if self.k > 1:
-            for s in self.used:
-                self.main.wait_stream(s)
-
-
-class _Guest:
-    """The side stream of the co-resident dense syrk: fork() makes it wait for everything the
-    current stream has queued so far, join() makes the current stream wait for it."""
-
-    _streams: dict = {}
-
-    def __init__(self):
-        dev = torch.cuda.current_device()
-        st = _Guest._streams.get(dev)
-        if st is None:
-            st = _Guest._streams[dev] = torch.cuda.Stream()
-        self.side = st
-        self.main = torch.cuda.current_stream()
-
-    def fork(self):
-        self.side.wait_stream(self.main)
-        return torch.cuda.stream(self.side)
-
-    def join(self):
-        self.main.wait_stream(self.side)
-
-
-def _set_knobs(values):
-    from ._lib import call
-
-    for k, v in values.items():
-        call("tm_tune_set", k.encode(), int(v))
 
 
 def as_tabmat(a):
@@ -585,6 +514,39 @@ class SplitMatrix(MatrixBase):
             out = D.zeros((n_cols, n_cols), torch.float64)
         return out
 
+    def _full_product_pays(self, sub_h) -> bool:
+        """May a column selection be computed as the UNRESTRICTED product followed by a selection of rows and
+        columns of the result?  Only when that wastes little: the blocks without any selected column (which
+        the reference's restricted loops, and the restricted path here, skip altogether -- a glum active set
+        that leaves out a high-cardinality categorical or a wide sparse block) must be a small share of the
+        product's work, and the full (p, p) float64 result must be small (a categorical with 1e5 levels
+        would make it 80 GB).  Work per block ~ the entries a row pass touches: dense columns, mean nonzeros
+        per row, one code (+ its share of the level tables) per categorical."""
+        p = self.shape[1]
+        if p * p * 8 > FULL_RESULT_MAX_BYTES:
+            return False
+        n = max(self.shape[0], 1)
+        tot = unsel = 0.0
+        for b, mb in enumerate(self.matrices):
+            if isinstance(mb, DenseMatrix):
+                wb = float(mb.shape[1])
+            elif isinstance(mb, SparseMatrix):
+                nnz = mb._devblk.data.numel() if mb._devblk is not None else mb._host().nnz
+                wb = max(1.0, float(nnz) / n)
+            else:
+                wb = 1.0 + mb.shape[1] / 256.0
+            tot += wb
+            if len(sub_h[b]) == 0:
+                unsel += wb
+        return unsel <= FULL_UNSELECTED_SHARE * tot
+
+    def _full_product_pays_cols(self, cols_host) -> bool:
+        key = np.asarray(cols_host).tobytes()
+        hit = self.__dict__.get("_fpp_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_fpp_cache"] = (key, self._full_product_pays(self._split_col_subsets(cols_host)[1]))
+        return hit[1]
+
     def _narrow_plan(self, cols_host):
         """Bookkeeping of the dense-block form of a narrow column selection (see NARROW_COLS), or
         None when it does not apply.  The last selection is cached."""
@@ -596,7 +558,9 @@ class SplitMatrix(MatrixBase):
         pos_h, sub_h, n_cols = self._split_col_subsets(cols_host)
         mats = self.matrices
         noncat = [b for b, mb in enumerate(mats) if not isinstance(mb, CategoricalMatrix)]
-        cat = [b for b, mb in enumerate(mats) if isinstance(mb, CategoricalMatrix)]
+        # (a categorical without a selected column takes no part: the reference's restricted loops skip it,
+        # and its levels would only enlarge the intermediate result)
+        cat = [b for b, mb in enumerate(mats) if isinstance(mb, CategoricalMatrix) and len(sub_h[b]) > 0]
         w = sum(len(sub_h[b]) for b in noncat)
         itemsize = np.dtype(self.dtype).itemsize
         if (noncat and 0 < w <= NARROW_COLS and self.shape[0] > 0
@@ -635,7 +599,7 @@ class SplitMatrix(MatrixBase):
             indices = [np.arange(w_pad)] + [cat_off[i] + np.arange(mats[i].shape[1]) for i in cat]
             nar = dict(w=w, w_pad=w_pad, parts=parts, cat=cat, cat_sub=cat_sub, indices=indices,
                        sel=D.to_dev(sel), tmp=None, n_cols=n_cols)
-        elif noncat and w > NARROW_COLS and FULL_THEN_SELECT <= 1.0:
+        elif noncat and w > NARROW_COLS and FULL_THEN_SELECT <= 1.0 and self._full_product_pays(sub_h):
             nar = "wide"
         self.__dict__["_narrow_cache"] = (key, nar)
         return nar
@@ -683,7 +647,7 @@ class SplitMatrix(MatrixBase):
         colsum: optional list (one slot per block) that receives X_block' d[rows] (restricted to
         the block's columns) wherever it falls out of the sandwich for free."""
         if cols_host is not None and len(cols_host) >= FULL_THEN_SELECT * self.shape[1] \
-                and len(cols_host) > 0:
+                and len(cols_host) > 0 and self._full_product_pays_cols(cols_host):
             pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
             cs_full = [None] * len(self.matrices) if colsum is not None else None
             full = self._sandwich_dev(d, rows, None, None, cs_full)
@@ -719,40 +683,10 @@ class SplitMatrix(MatrixBase):
         mats = self.matrices
         empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
         done = set()
-        fan = _StreamFan(N_STREAMS)
-        self_done = set()
-        guest = None
-        if (OVERLAP and rows is None and N_STREAMS == 1 and d.dtype == torch.float64
-                and sum(1 for e in empty if not e) > 1):
-            from .ext import dense as xd
-            for i, mi in enumerate(mats):
-                if not (isinstance(mi, DenseMatrix) and sub_d[i] is None and not empty[i]):
-                    continue
-                Bd = mi._dev_c()
-                if mi.dtype != np.float64 or not xd.co_supported(Bd, d):
-                    continue
-                guest = _Guest()
-                with guest.fork():
-                    res = xd.dense_sandwich_co(Bd, d, want_colsum=colsum is not None)
-                    if colsum is not None:
-                        res, colsum[i] = res
-                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
-                self_done.add(i)
-                break
-        if guest is not None:
-            _set_knobs(OVERLAP_KNOBS)
-        try:
-            return self._sandwich_terms(d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done,
-                                        fan, self_done)
-        finally:
-            if guest is not None:
-                _set_knobs({k: -2**63 for k in OVERLAP_KNOBS})      # (INT64_MIN: back to the defaults)
-                guest.join()
+        return self._sandwich_terms(d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done)
 
-    def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done, fan,
-                        self_done):
-        """The block products of one sandwich on the current stream (everything but a dense self
-        term that `_sandwich_dev` gave to the guest stream)."""
+    def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done):
+        """The block products of one sandwich, in line on the current stream."""
         from .ext import dense as xd
 
         mats = self.matrices
@@ -775,29 +709,28 @@ class SplitMatrix(MatrixBase):
             for w, mw in enumerate(mats):
                 if empty[w] or mw.dtype != self.dtype or d.dtype != D.torch_dtype(self.dtype):
                     continue
-                with fan.lane():
-                    stacked = self._fused_cats(mw, cats, grp, d_eff, rows, total, budget, d)
-                    if stacked is None:
-                        continue
-                    # no column restriction: the stacked result goes out in ONE scatter (24
-                    # categoricals x 2 operands were 48 launches of ~5 us)
-                    whole = cols_host is None and len(grp) > 1
-                    if whole:
-                        cache = self.__dict__.setdefault("_group_pos", {})
-                        gpos = cache.get(tuple(grp))
-                        if gpos is None:
-                            gpos = cache[tuple(grp)] = torch.cat([pos_d[i] for i in grp])
-                        xsplit.scatter_block(stacked.contiguous(), gpos, pos_d[w], out, mirror=True)
-                    for ci, i in enumerate(grp):
-                        res = stacked[int(offs[ci]):int(offs[ci + 1])]
-                        if (colsum is not None and colsum[w] is None and not mats[i].drop_first
-                                and not mats[i]._has_missings):
-                            cs = res.sum(dim=0)           # all levels of a complete categorical
-                            colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
-                        if not whole:
-                            res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
-                            xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
-                        done.add((min(i, w), max(i, w)))
+                stacked = self._fused_cats(mw, cats, grp, d_eff, rows, total, budget, d)
+                if stacked is None:
+                    continue
+                # no column restriction: the stacked result goes out in ONE scatter (24
+                # categoricals x 2 operands were 48 launches of ~5 us)
+                whole = cols_host is None and len(grp) > 1
+                if whole:
+                    cache = self.__dict__.setdefault("_group_pos", {})
+                    gpos = cache.get(tuple(grp))
+                    if gpos is None:
+                        gpos = cache[tuple(grp)] = torch.cat([pos_d[i] for i in grp])
+                    xsplit.scatter_block(stacked.contiguous(), gpos, pos_d[w], out, mirror=True)
+                for ci, i in enumerate(grp):
+                    res = stacked[int(offs[ci]):int(offs[ci + 1])]
+                    if (colsum is not None and colsum[w] is None and not mats[i].drop_first
+                            and not mats[i]._has_missings):
+                        cs = res.sum(dim=0)           # all levels of a complete categorical
+                        colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
+                    if not whole:
+                        res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
+                        xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
+                    done.add((min(i, w), max(i, w)))
         # ---- all categorical x categorical tables that fit an LDS tile, and the categorical
         #      diagonals, in ONE pass over the codes (tm_multi_cat_pairs_*): a design with k
         #      categoricals has k (k - 1) / 2 of them, one launch each was ~30 us apiece
@@ -807,7 +740,7 @@ class SplitMatrix(MatrixBase):
         # (csrc/cat_det.hip), not from LDS-atomic tables -- no fused plan, no row-sum shortcut
         det = _cm.DETERMINISTIC
         plan = self._cat_pairs_plan() if CAT_PAIRS_FUSED and not det else None
-        if (plan is not None and plan.n_pairs > 0 and N_STREAMS == 1
+        if (plan is not None and plan.n_pairs > 0
                 and d.dtype in (torch.float32, torch.float64)
                 and d.dtype == D.torch_dtype(self.dtype)):
             cl = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in plan.cat_ids]
@@ -836,60 +769,52 @@ class SplitMatrix(MatrixBase):
             for j in range(i + 1, len(mats)):
                 if empty[j] or not isinstance(mats[j], CategoricalMatrix) or (i, j) in done:
                     continue
-                with fan.lane():
-                    res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
-                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
-                    done.add((i, j))
-                    if DIAG_FROM_PAIRS and not det and complete[j] and i not in cat_diag:
-                        cat_diag[i] = res.sum(dim=1)
-                    if DIAG_FROM_PAIRS and not det and complete[i] and j not in cat_diag:
-                        cat_diag[j] = res.sum(dim=0)
-        # self terms first, then the remaining cross terms: the guest syrk shares its compute units
-        # with the sparse self sandwich (K2), not with the sparse x dense gather (K3)
+                res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
+                xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
+                done.add((i, j))
+                if DIAG_FROM_PAIRS and not det and complete[j] and i not in cat_diag:
+                    cat_diag[i] = res.sum(dim=1)
+                if DIAG_FROM_PAIRS and not det and complete[i] and j not in cat_diag:
+                    cat_diag[j] = res.sum(dim=0)
+        # self terms first, then the remaining cross terms
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
-            with fan.lane():
-                if i in self_done:
-                    pass
-                elif isinstance(mi, CategoricalMatrix):
-                    diag = cat_diag[i] if (i in cat_diag and N_STREAMS == 1) else \
-                        mi._sandwich_diag_dev(d, rows, sub_d[i])
-                    if colsum is not None:
-                        colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
-                    if i not in diag_scattered:
-                        xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
-                elif (colsum is not None and colsum[i] is None and isinstance(mi, DenseMatrix)
-                      and rows is None and sub_d[i] is None
-                      and (both := mi._sandwich_xtd_dev(d)) is not None):
-                    # X_dense' d comes out of the syrk's own pass (csrc/syrk_i8.hip, csrc/syrk_co.hip)
-                    res, colsum[i] = both
-                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
-                else:
-                    res = mi._sandwich_dev(d, rows, sub_d[i])
-                    xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+            if isinstance(mi, CategoricalMatrix):
+                diag = cat_diag[i] if i in cat_diag else mi._sandwich_diag_dev(d, rows, sub_d[i])
+                if colsum is not None:
+                    colsum[i] = diag          # one-hot entries are 0 / 1: C' d = diag(C' D C)
+                if i not in diag_scattered:
+                    xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
+            elif (colsum is not None and colsum[i] is None and isinstance(mi, DenseMatrix)
+                  and rows is None and sub_d[i] is None
+                  and (both := mi._sandwich_xtd_dev(d)) is not None):
+                # X_dense' d comes out of the syrk's own pass (csrc/syrk_i8.hip, csrc/syrk_co.hip)
+                res, colsum[i] = both
+                xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+            else:
+                res = mi._sandwich_dev(d, rows, sub_d[i])
+                xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
         for i, mi in enumerate(mats):
             if empty[i]:
                 continue
             for j in range(i + 1, len(mats)):
                 if empty[j] or (i, j) in done:
                     continue
-                with fan.lane():
-                    # sparse x dense: X_sparse' d rides along in the gather's stream loop
-                    si, di = (i, j) if isinstance(mi, SparseMatrix) else (j, i)
-                    if (colsum is not None and colsum[si] is None and isinstance(mats[si], SparseMatrix)
-                            and isinstance(mats[di], DenseMatrix)):
-                        box = []
-                        res = mats[si]._cross_sandwich_dev(mats[di], d, rows, sub_d[si], sub_d[di],
-                                                           colsum_box=box)
-                        if box:
-                            colsum[si] = box[0]
-                        if si != i:
-                            res = res.T
-                    else:
-                        res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
-                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
-        fan.join()
+                # sparse x dense: X_sparse' d rides along in the gather's stream loop
+                si, di = (i, j) if isinstance(mi, SparseMatrix) else (j, i)
+                if (colsum is not None and colsum[si] is None and isinstance(mats[si], SparseMatrix)
+                        and isinstance(mats[di], DenseMatrix)):
+                    box = []
+                    res = mats[si]._cross_sandwich_dev(mats[di], d, rows, sub_d[si], sub_d[di],
+                                                       colsum_box=box)
+                    if box:
+                        colsum[si] = box[0]
+                    if si != i:
+                        res = res.T
+                else:
+                    res = mi._cross_sandwich_dev(mats[j], d, rows, sub_d[i], sub_d[j])
+                xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[j], out, mirror=True)
         return out
 
     def sandwich_graph(self, d, rows=None, cols=None):

@@ -41,3 +41,22 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.abs(b).max(), 1e-300) if b.size else 1.0
     return float(np.abs(a - b).max() / den) if b.size else 0.0
+
+
+def nat_err(a, b):
+    """Entry-wise error of a sandwich at its NATURAL scale: max_ij |a_ij - b_ij| / sqrt(b_ii b_jj) (for a
+    nonnegative weight vector |S_ij| <= sqrt(S_ii S_jj), so this is the error relative to the largest value the
+    entry could have taken).  A wrong small block -- a categorical x categorical cell, a sparse x categorical
+    strip -- cannot hide under the magnitude of the dense block the way it can under max|b| (rel_err); the
+    reference's own tests compare entry by entry (tests/test_split_matrix.py:170-189).  An entry whose row or
+    column has a zero diagonal must be reproduced exactly."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape and a.ndim == 2 and a.shape[0] == a.shape[1]
+    if not b.size:
+        return 0.0
+    dg = np.sqrt(np.abs(np.diag(b)))
+    den = np.outer(dg, dg)
+    err = np.abs(a - b)
+    out = np.where(den > 0, err / np.where(den > 0, den, 1.0), np.where(err == 0, 0.0, np.inf))
+    return float(out.max())

@@ -68,7 +68,13 @@ def _worker(rank, world, port, q):
         got = sh.sandwich(d[lo:hi])
         got_rows = sh.sandwich(d[lo:hi], bucket_rows(rows_g, lo, hi))
         got_tmv = sh.transpose_matvec(w[lo:hi])
+        # the collective started, another product issued meanwhile, then waited for
+        pending = sh.sandwich_async(d[lo:hi])
+        tmv2 = sh.transpose_matvec(w[lo:hi])
+        got_async = pending.wait()
         ok = (np.allclose(got, full, rtol=1e-12, atol=1e-12)
+              and np.allclose(got_async, full, rtol=1e-12, atol=1e-12)
+              and np.allclose(tmv2, full_tmv, rtol=1e-12, atol=1e-12)
               and np.allclose(got_rows, full_rows, rtol=1e-12, atol=1e-12)
               and np.allclose(got_tmv, full_tmv, rtol=1e-12, atol=1e-12))
         q.put((rank, bool(ok), (lo, hi)))

@@ -126,3 +126,28 @@ def test_rccl_all_reduce_world2_two_devices():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two visible GPUs (RCCL refuses two ranks on one device)")
     _run(2, True, "nccl", 2)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gloo():
+    """`python bench.py --gpus 2` end to end on ONE GPU: the script spawns its own two ranks through
+    torch.distributed.run, the ranks share the device over the gloo backend (TABMAT_BENCH_BACKEND=gloo; RCCL
+    refuses two ranks on one device), every rank times its own shard between barriers and rank 0 prints the
+    one JSON line with the whole-job value (the 8-GPU job runs the same code over RCCL)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, TABMAT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "200000",
+                          "--steps", "3", "--warmup", "1", "--no-traffic", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
+    assert r["config"]["sharding"] == "rows" and r["config"]["collective"].startswith("all_reduce")
+    assert r["config"]["rows_per_gpu"] == 200000
+    assert np.isfinite(r["value"]) and r["value"] > 0 and r["ms_per_step"] > 0
+    assert r["roofline"]["kernel_ms"] > 0

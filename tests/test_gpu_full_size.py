@@ -8,7 +8,7 @@ import torch
 from scipy import sparse as sps
 
 import _cases as cs
-from _gpu_util import rel_err
+from _gpu_util import nat_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -121,9 +121,11 @@ def test_cfg4_split_sandwich_10M():
         blocks = [cs.to_oracle_block(sp) for sp in _subset_specs(X, rows_t)]
         ref = _orc().split_sandwich(blocks, [np.asarray(i) for i in X.indices], ds.cpu().numpy())
         assert rel_err(got, ref) < 1e-10
+        assert nat_err(got, ref) < 1e-10          # entry by entry at the natural scale sqrt(S_ii S_jj)
         tot_gpu = got if tot_gpu is None else tot_gpu + got
         tot_ref = ref if tot_ref is None else tot_ref + ref
     assert rel_err(tot_gpu, tot_ref) < 1e-10
+    assert nat_err(tot_gpu, tot_ref) < 1e-10
     # true oracle comparison on a random row subset via rows=
     rows = np.sort(rng.choice(n, size=20_000, replace=False)).astype(np.int32)
     rows_t = torch.as_tensor(rows.astype(np.int64), device="cuda")
@@ -131,6 +133,7 @@ def test_cfg4_split_sandwich_10M():
     blocks = [cs.to_oracle_block(s) for s in _subset_specs(X, rows_t)]
     ref = _orc().split_sandwich(blocks, [np.asarray(i) for i in X.indices], d1[rows_t].cpu().numpy())
     assert rel_err(sub.cpu().numpy(), ref) < 1e-10
+    assert nat_err(sub.cpu().numpy(), ref) < 1e-10
 
 
 def test_cfg2_dense_f32_10M_x_256():

@@ -78,29 +78,38 @@ def test_random_split_products(seed):
         assert a.shape == b.shape
         assert float(np.abs(a - b).max()) / scale < tol
 
-    close(X.sandwich(d), E.T @ (d64[:, None] * E))
+    def close_sand(a, b):
+        """close() + entry by entry at the natural scale sqrt(S_ii S_jj) (d >= 0 here): a wrong small block
+        cannot hide under the largest one."""
+        from _gpu_util import nat_err
+
+        close(a, b)
+        a = np.asarray(a.toarray() if sps.issparse(a) else a, dtype=np.float64)
+        assert nat_err(a, b) < (1e-10 if dtype == np.float64 else 2e-3)
+
+    close_sand(X.sandwich(d), E.T @ (d64[:, None] * E))
     close(X.matvec(v), E @ v64)
     close(X.transpose_matvec(w), E.T @ w64)
     rows = np.sort(rng.choice(n, size=max(1, n // 2), replace=False)).astype(np.int32)
     cols = np.sort(rng.choice(p, size=max(1, (2 * p) // 3), replace=False)).astype(np.int32)
     Er = E[np.ix_(rows, cols)]
-    close(X.sandwich(d, rows, cols), Er.T @ (d64[rows, None] * Er))
+    close_sand(X.sandwich(d, rows, cols), Er.T @ (d64[rows, None] * Er))
     close(X.matvec(v, cols), E[:, cols] @ v64[cols])
     close(X.transpose_matvec(w, rows, cols), Er.T @ w64[rows])
     # a narrow selection (below the share from which the unrestricted product + selection is used)
     few_c = np.sort(rng.choice(p, size=max(1, p // 5), replace=False)).astype(np.int32)
     Ec = E[:, few_c]
-    close(X.sandwich(d, None, few_c), Ec.T @ (d64[:, None] * Ec))
-    close(X.sandwich(d, rows, few_c), Ec[rows].T @ (d64[rows, None] * Ec[rows]))
+    close_sand(X.sandwich(d, None, few_c), Ec.T @ (d64[:, None] * Ec))
+    close_sand(X.sandwich(d, rows, few_c), Ec[rows].T @ (d64[rows, None] * Ec[rows]))
     close(X.transpose_matvec(w, None, few_c), Ec.T @ w64)
     close(X.sandwich(d, cols=np.arange(p)), E.T @ (d64[:, None] * E))
     # a short row list (row-list kernels: cost proportional to len(rows)), with repeats allowed
     few = rng.choice(n, size=max(1, n // 9), replace=False).astype(np.int64)
     Ef = E[few]
-    close(X.sandwich(d, few), Ef.T @ (d64[few, None] * Ef))
+    close_sand(X.sandwich(d, few), Ef.T @ (d64[few, None] * Ef))
     if isinstance(X, tm.SplitMatrix):
         Xd = X.to_device()
-        close(Xd.sandwich(d), E.T @ (d64[:, None] * E))
+        close_sand(Xd.sandwich(d), E.T @ (d64[:, None] * E))
         # the standardized view on the same blocks (one pass for the inner sandwich and X' d)
         shift = rng.standard_normal(p)
         mult = rng.random(p) + 0.5

@@ -54,3 +54,25 @@ def test_blocks_path_is_taken_by_sparse_matrix_sandwich(monkeypatch):
     rows = np.sort(rng.choice(30_000, 20_000, replace=False))
     Sr = S.tocsr()[rows]
     assert rel_err(sm.sandwich(d, rows), (Sr.T.multiply(d[rows])).dot(Sr).toarray()) < 1e-10
+
+
+@pytest.mark.parametrize("waves", [2, 5, 8, 12])
+def test_wave_knob_does_not_change_the_result(waves):
+    """tm_tune_set("k2b_waves") launches fewer waves than the block table's FULL / HALF split was
+    built for (16): the kernel rescales the split instead of skipping blocks."""
+    import tabmat_amd as tm
+    from tabmat_amd import _device as D
+    from tabmat_amd import _lib
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(3)
+    S = sps.random(9_000, 300, density=0.08, format="csc", random_state=rng, dtype=np.float64)
+    d = rng.random(9_000)
+    A = tm.SparseMatrix(S)._dev()
+    want = (S.T.multiply(d)).dot(S).toarray()
+    _lib.call("tm_tune_set", b"k2b_waves", waves)
+    try:
+        got = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
+    finally:
+        _lib.call("tm_tune_set", b"k2b_waves", -2**63)
+    assert rel_err(got, want) < 1e-10

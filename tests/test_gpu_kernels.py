@@ -7,7 +7,7 @@ import pytest
 from scipy import sparse as sps
 
 import _cases as cs
-from _gpu_util import rel_err, to_tm_block, to_tm_split
+from _gpu_util import nat_err, rel_err, to_tm_block, to_tm_split
 
 pytestmark = pytest.mark.gpu
 
@@ -541,10 +541,15 @@ def test_split_mixed_cfg4_shape(dtype, order):
     ref = orc.split_sandwich(blocks, idx, d)
     tol = F64_TOL if dtype == np.float64 else 5e-5
     assert rel_err(res, ref) < tol
+    # entry by entry at the natural scale sqrt(S_ii S_jj): every block of the result, not just the largest
+    assert nat_err(res, ref) < tol
     assert np.array_equal(res, res.T)
     rows = _rows_subset(rng, n)
     cols = np.sort(rng.choice(p, size=300, replace=False))
-    assert rel_err(mat.sandwich(d, rows, cols), orc.split_sandwich(blocks, idx, d, rows, cols)) < tol
+    ref_rc = orc.split_sandwich(blocks, idx, d, rows, cols)
+    got_rc = mat.sandwich(d, rows, cols)
+    assert rel_err(got_rc, ref_rc) < tol
+    assert nat_err(got_rc, ref_rc) < tol
     v = rng.standard_normal(p).astype(dtype)
     w = rng.standard_normal(n).astype(dtype)
     mtol = F64_TOL if dtype == np.float64 else 1e-4
@@ -891,3 +896,45 @@ def test_sparse_narrow_column_selection(dtype):
     finally:
         spm.NARROW_COLS = old
     assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def test_column_selection_skips_unselected_heavy_blocks():
+    """a selection that leaves out a high-cardinality categorical (a glum active set) must not
+    compute -- or allocate the (p, p) result of -- the full product: the restricted path skips blocks without
+    a selected column, like the reference (split_matrix.py:324-356)."""
+    import tabmat_amd as tm
+    import tabmat_amd.split_matrix as smod
+
+    rng = np.random.default_rng(11)
+    n = 6000
+    X = rng.standard_normal((n, 140))
+    S = sps.random(n, 60, density=0.1, format="csc", random_state=rng)
+    big = rng.integers(0, 9000, n)
+    small = rng.integers(0, 7, n)
+    mat = tm.SplitMatrix([tm.DenseMatrix(X), tm.SparseMatrix(S),
+                          tm.CategoricalMatrix(big, categories=np.arange(9000)),
+                          tm.CategoricalMatrix(small, categories=np.arange(7))])
+    p = mat.shape[1]
+    # everything but the 9000-level categorical: > 128 dense + sparse columns and < half of all columns
+    cols = np.concatenate([np.arange(200), np.arange(200 + 9000, p)]).astype(np.int32)
+    assert not mat._full_product_pays(mat._split_col_subsets(cols)[1])
+    seen = []
+    orig = smod.D.zeros
+
+    def spy(shape, dtype):
+        seen.append(tuple(shape))
+        return orig(shape, dtype)
+
+    smod.D.zeros = spy
+    try:
+        d = rng.random(n)
+        got = mat.sandwich(d, cols=cols)
+    finally:
+        smod.D.zeros = orig
+    assert (p, p) not in seen, "the full (p, p) result was allocated"
+    E = np.hstack([X, S.toarray(), np.eye(7)[small]])
+    assert rel_err(got, E.T @ (d[:, None] * E)) < F64_TOL
+    assert nat_err(got, E.T @ (d[:, None] * E)) < F64_TOL
+    # a selection that covers every block still takes the tuned full product + selection
+    cols2 = np.sort(rng.choice(p, size=int(0.7 * p), replace=False)).astype(np.int32)
+    assert mat._full_product_pays(mat._split_col_subsets(cols2)[1]) == (p * p * 8 <= smod.FULL_RESULT_MAX_BYTES)

@@ -9,7 +9,7 @@ import pytest
 from scipy import sparse as sps
 
 import _cases as cs
-from _gpu_util import sub, to_tm_block, to_tm_split
+from _gpu_util import nat_err, sub, to_tm_block, to_tm_split
 
 pytestmark = pytest.mark.gpu
 
@@ -246,6 +246,8 @@ def test_real_matrix_golden(name, idx64):
     X = tm.SplitMatrix(blocks, idx)
     np.testing.assert_array_equal(X.toarray(), z["design"])
     np.testing.assert_allclose(X.sandwich(z["d"]), z["sandwich"], rtol=1e-12, atol=1e-12)
+    assert nat_err(X.sandwich(z["d"]), z["sandwich"]) < 1e-10
+    assert nat_err(X.sandwich(z["d"], z["rows"], z["cols"]), z["sandwich_rows_cols"]) < 1e-10
     np.testing.assert_allclose(X.matvec(z["v"]), z["matvec"], rtol=1e-12)
     np.testing.assert_allclose(X.transpose_matvec(z["w"]), z["transpose_matvec"], rtol=1e-12,
                                atol=1e-12)

@@ -101,23 +101,6 @@ def test_zero_weight_rows_and_empty(knobs):
     assert tm.DenseMatrix(np.zeros((0, 64))).sandwich(np.zeros(0)).shape == (64, 64)
 
 
-def test_guest_stream_sandwich_matches_in_line(monkeypatch):
-    """TABMAT_AMD_OVERLAP: the dense term on the side stream, partners with 12 waves."""
-    import tabmat_amd.split_matrix as sm
-
-    specs, idx = cs.mixed_specs(30_000, 128, 512, (256, 96, 32), seed=5)
-    mat = to_tm_split(specs, idx)
-    blocks = [cs.to_oracle_block(s) for s in specs]
-    d = np.random.default_rng(6).random(30_000)
-    ref = _orc().split_sandwich(blocks, idx, d)
-    monkeypatch.setattr(sm, "OVERLAP", False)
-    a = mat.sandwich(d)
-    monkeypatch.setattr(sm, "OVERLAP", True)
-    b = mat.sandwich(d)
-    b2 = mat.sandwich(d)
-    assert rel_err(a, ref) < F64_TOL and rel_err(b, ref) < F64_TOL and rel_err(b2, ref) < F64_TOL
-
-
 def test_placement_log(knobs):
     """The instrumented kernels append one record per workgroup to the "wg_log" buffer."""
     import torch
