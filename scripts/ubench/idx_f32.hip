@@ -14,8 +14,12 @@ __global__ __attribute__((amdgpu_num_vgpr(40))) void probe(float *out, int mode)
                          :: "s"(idx), "v"(a), "v"(x) : "m0");
         else if (mode == 1)
             asm volatile("s_set_gpr_idx_on %0, 0xc\n\tv_fmac_f32 v64, %1, %2\n\ts_set_gpr_idx_off" :: "s"(idx), "v"(a), "v"(x) : "m0");
-        else
+        else if (mode == 2)
             asm volatile("s_set_gpr_idx_on %0, 0x8\n\tv_mov_b32 v64, %2\n\ts_set_gpr_idx_off" :: "s"(idx), "v"(a), "v"(x) : "m0");
+        else if (mode == 3)      // mode switched on with index 0, then s_set_gpr_idx_idx
+            asm volatile("s_set_gpr_idx_on %3, 0xc\n\ts_set_gpr_idx_idx %0\n\tv_fmac_f32 v64, %1, %2\n\ts_set_gpr_idx_off" :: "s"(idx), "v"(a), "v"(x), "s"(0) : "m0");
+        else                     // ... with an LDS read between the index change and the FMA
+            asm volatile("s_set_gpr_idx_on %3, 0xc\n\ts_set_gpr_idx_idx %0\n\tds_read_b32 v40, %4\n\ts_waitcnt lgkmcnt(0)\n\tv_fmac_f32 v64, %1, %2\n\tv_add_f32 v64, v64, v40\n\ts_set_gpr_idx_off" :: "s"(idx), "v"(a), "v"(x), "s"(0), "v"(0) : "m0", "v40");
     }
     float r[32];
 #define RD(K) asm volatile("v_mov_b32 %0, v[64+" #K "]" : "=v"(r[K]));
@@ -26,10 +30,10 @@ __global__ __attribute__((amdgpu_num_vgpr(40))) void probe(float *out, int mode)
 int main() {
     float *out; hipMalloc(&out, 4 * 32 * 64);
     float h[32 * 64];
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, out, mode);
         hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
-        printf("mode %d (%s): register k holds (lane 5): ", mode, mode == 0 ? "fmac_f32_dpp" : mode == 1 ? "fmac_f32" : "mov_b32");
+        printf("mode %d (%s): register k holds (lane 5): ", mode, mode == 0 ? "fmac_f32_dpp" : mode == 1 ? "fmac_f32" : mode == 2 ? "mov_b32" : mode == 3 ? "idx_idx + fmac" : "idx_idx + ds_read + fmac + add");
         for (int k = 0; k < 32; ++k) printf("%g ", h[k * 64 + 5]);
         printf("\n");
     }

@@ -54,10 +54,7 @@ constexpr int EN_SB = 64;           // slots per superbatch (lane <-> slot)
 #ifndef EN_PIECE_AT
 #define EN_PIECE_AT 0               // a wave issues its copy pieces in front of this batch of a slab
 #endif
-#ifndef EN_NSLOT
-#define EN_NSLOT 4                  // LDS reads in flight per wave (landing slots): 4 or 8
-#endif
-static_assert(EN_NSLOT == 4 || EN_NSLOT == 8, "landing slots");
+// (four LDS reads in flight per wave: landing slots v[48 : 63]; eight measured no faster)
 
 template <typename F>
 struct EnLds {
@@ -76,14 +73,11 @@ struct EnLds {
 // known when the code is written, and values the register allocator does not know about cannot be moved
 // or spilled by it (a first version passed the tuples as "+{v[64:95]}" operands: the allocator parked
 // them elsewhere between the asm statements and re-loaded all 64 from scratch in every batch).
-// v[EN_CVGPR : EN_CVGPR + 7] receive the stream / d loads (en_take hands them to the compiler after the wait).
-#if EN_NSLOT == 8
+// Register map: compiler v0 .. v23; LDS addresses of a batch v[24 : 39]; stream / d loads v[40 : 45] (en_take
+// hands them to the compiler behind the wait); landing slots of the LDS reads v[48 : 63] (f32: v[56 : 63]);
+// accumulators from v64 up.  scripts/gen_ent_batch.py writes the batch code against the same map.
 constexpr int EN_CVGPR = 24;
-#define EN_LD "24"
-#else
-constexpr int EN_CVGPR = 40;
 #define EN_LD "40"
-#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t en_rsrc_t;
@@ -94,83 +88,6 @@ __device__ __forceinline__ en_rsrc_t en_rsrc(const void *base, int64_t bytes) {
 __device__ __forceinline__ void en_buf_to_lds16(en_rsrc_t rs, void *lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds, 16, voff,
                                              soff, 0, 0);
-}
-// landing registers: the EN_NSLOT slots below v64 (f64: 4 registers each, f32: 2)
-#if EN_NSLOT == 8
-#define EN_XD "32"
-#define EN_XF "48"
-#else
-#define EN_XD "48"
-#define EN_XF "56"
-#endif
-// entry I of the batch: its row of B -> landing slot I % EN_NSLOT
-template <typename F, int I>
-__device__ __forceinline__ void en_issue(unsigned kq, unsigned lane_off) {
-    unsigned tmp;
-    if constexpr (sizeof(F) == 8)
-        asm volatile("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
-                     "ds_read_b128 v[" EN_XD "+4*%4:" EN_XD "+4*%4+3], %0"
-                     : "=&v"(tmp)
-                     : "v"(kq), "v"(lane_off), "n"(I), "n"(I % EN_NSLOT));
-    else
-        asm volatile("v_add_u32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
-                     "ds_read_b64 v[" EN_XF "+2*%4:" EN_XF "+2*%4+1], %0"
-                     : "=&v"(tmp)
-                     : "v"(kq), "v"(lane_off), "n"(I), "n"(I % EN_NSLOT));
-}
-// entry I: wait until at most WAIT LDS reads are outstanding (the reads return in order), then
-// acc[column] += value * row under the index mode (SRC2 | DST: the accumulator, read and written)
-template <int I, int WAIT>
-__device__ __forceinline__ void en_fma(int sj, double a) {
-    asm volatile("s_waitcnt lgkmcnt(%2)\n\t"
-                 "s_set_gpr_idx_on %0, 0xc\n\t"
-                 "v_fmac_f64_dpp v[64:65], %1, v[" EN_XD "+4*%3:" EN_XD "+4*%3+1] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp v[66:67], %1, v[" EN_XD "+4*%3+2:" EN_XD "+4*%3+3] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_set_gpr_idx_off"
-                 :
-                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I)
-                 : "m0");
-}
-template <int I, int WAIT>
-__device__ __forceinline__ void en_fma(int sj, float a) {
-    asm volatile("s_waitcnt lgkmcnt(%2)\n\t"
-                 "s_set_gpr_idx_on %0, 0xc\n\t"
-                 "v_fmac_f32_dpp v64, %1, v[" EN_XF "+2*%3] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp v65, %1, v[" EN_XF "+2*%3+1] row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_set_gpr_idx_off"
-                 :
-                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I)
-                 : "m0");
-}
-// entry I's two FMAs and the LDS read of entry NX = I + EN_NSLOT in ONE asm statement (between two asm
-// statements the compiler puts an s_nop 0 -- two issue slots per entry of ten)
-template <int I, int WAIT, int NX>
-__device__ __forceinline__ void en_step(int sj, double a, unsigned kq, unsigned lane_off) {
-    unsigned tmp;
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
-                 "s_set_gpr_idx_on %1, 0xc\n\t"
-                 "v_fmac_f64_dpp v[64:65], %2, v[" EN_XD "+4*%4:" EN_XD "+4*%4+1] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp v[66:67], %2, v[" EN_XD "+4*%4+2:" EN_XD "+4*%4+3] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_set_gpr_idx_off\n\t"
-                 "v_add_u32_dpp %0, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-                 "ds_read_b128 v[" EN_XD "+4*%4:" EN_XD "+4*%4+3], %0"
-                 : "=&v"(tmp)
-                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I), "v"(kq), "v"(lane_off), "n"(NX)
-                 : "m0");
-}
-template <int I, int WAIT, int NX>
-__device__ __forceinline__ void en_step(int sj, float a, unsigned kq, unsigned lane_off) {
-    unsigned tmp;
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t"
-                 "s_set_gpr_idx_on %1, 0xc\n\t"
-                 "v_fmac_f32_dpp v64, %2, v[" EN_XF "+2*%4] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp v65, %2, v[" EN_XF "+2*%4+1] row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_set_gpr_idx_off\n\t"
-                 "v_add_u32_dpp %0, %6, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-                 "ds_read_b64 v[" EN_XF "+2*%4:" EN_XF "+2*%4+1], %0"
-                 : "=&v"(tmp)
-                 : "s"(sj), "v"(a), "n"(WAIT), "n"(I % EN_NSLOT), "n"(I), "v"(kq), "v"(lane_off), "n"(NX)
-                 : "m0");
 }
 // all accumulators = 0; the clobber of the highest register is what sizes the wave's register allocation
 // (.amdhsa_next_free_vgpr): the compiler itself stays below EN_CVGPR
@@ -236,47 +153,32 @@ __device__ __forceinline__ void en_take(float &v, unsigned &m, float &dd) {
     v = __uint_as_float(vl);
     dd = __uint_as_float(dl);
 }
-// (the builtin, not asm: the compiler's hazard recognizer does not look inside asm statements, and a
-// v_readlane right behind the VALU instruction that wrote its source read the OLD register -- lane 0 of the
-// f32 kernel, whose `jv = e & 0xff` happened to be scheduled directly in front of the first read)
-template <int I>
-__device__ __forceinline__ int en_lane_to_s(unsigned v) {
-    return __builtin_amdgcn_readlane((int)v, I);
-}
 #else
 struct en_rsrc_t {};
 __device__ inline en_rsrc_t en_rsrc(const void *, int64_t) { return {}; }
 __device__ inline void en_buf_to_lds16(en_rsrc_t, void *, int, int) {}
-template <typename F, int I> __device__ void en_issue(unsigned, unsigned) {}
-template <int I, int WAIT, typename F> __device__ void en_fma(int, F) {}
 template <typename F> __device__ void en_zero_acc() {}
-template <int I, int WAIT, int NX, typename F> __device__ void en_step(int, F, unsigned, unsigned) {}
 template <int K> __device__ unsigned en_read_acc() { return 0u; }
-template <int I> __device__ int en_lane_to_s(unsigned) { return 0; }
 template <typename F> __device__ void en_load_stream(unsigned, const F *, unsigned, const unsigned *) {}
 template <typename F> __device__ void en_load_d(unsigned, const F *) {}
 template <int N, typename F> __device__ void en_take(F &, unsigned &, F &) {}
 #endif
 
-// One batch of N = 16 (or 4 / 8 / 12: the end of a block) entries: a = value * d, kq = LDS address
-// of the entry's row (the zero row for padding / d == 0), jv = accumulator register offset of its column;
-// entry i lives in lane i of every row of 16 lanes.
+// One batch of N = 4 / 8 / 12 / 16 entries as ONE asm statement (generated: scripts/gen_ent_batch.py): a = value * d
+// and kq = LDS address of the row of B (the zero row for padding / d == 0) with entry i in lane i of every row
+// of 16 lanes; p0 .. p3 = the accumulator register offsets of the entries of quad 0 .. 3, one byte each.  Per entry:
+// s_waitcnt / s_set_gpr_idx_idx / 2 x v_fmac_dpp (value by row_newbcast, accumulator by the index) / the LDS read
+// of the entry four further on; the N LDS addresses (v_add_u32_dpp) are formed before the index mode is switched
+// on, because while it is on every vector-ALU instruction is indexed.
 template <int N, typename F>
-__device__ __forceinline__ void en_batch(F a, unsigned kq, unsigned jv, unsigned lane_off) {
-    int sj[N];
-    static_for<N>([&](auto ic) { sj[decltype(ic)::value] = en_lane_to_s<decltype(ic)::value>(jv); });
-    // (no scalar load may be in flight: SMEM returns out of order and would make the counted waits unsafe;
-    // s_nop 1: a DPP operand needs two wait states behind the VALU write of its register, and the compiler does
-    // not know that the statements below read kq and a through DPP)
-    asm volatile("s_nop 1\n\ts_waitcnt lgkmcnt(0)" : "+v"(kq), "+v"(a) :: "memory");
-    static_for<EN_NSLOT>([&](auto ic) { en_issue<F, decltype(ic)::value>(kq, lane_off); });
-    static_for<N>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int wait = i + EN_NSLOT < N ? EN_NSLOT - 1 : N - 1 - i;
-        if constexpr (i + EN_NSLOT < N) en_step<i, wait, i + EN_NSLOT>(sj[i], a, kq, lane_off);
-        else en_fma<i, wait>(sj[i], a);
-    });
-}
+__device__ __forceinline__ void en_batch_asm(unsigned &p0, unsigned &p1, unsigned &p2, unsigned &p3, F a, unsigned kq,
+                                             unsigned lane_off);
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "sparse_ent_batch.inc"
+#else
+template <int N, typename F>
+__device__ void en_batch_asm(unsigned &, unsigned &, unsigned &, unsigned &, F, unsigned, unsigned) {}
+#endif
 
 // CSUM = true: the column sums A^T d (length m, kernel column order) come out of the same pass
 // (StandardizedMatrix.sandwich: reference standardized_mat.py:149-150 calls transpose_matvec): lanes 0-15
@@ -375,7 +277,13 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         const bool ok = vy != F(0) && dy != F(0);
         const F a = ok ? vy * dy : F(0);
         const unsigned kq = ok ? lds_base + (srel & 1u) * (unsigned)SLABB + (((rowg & 63u) + 1u) << RSH) : lds_base;
-        const unsigned jvs = ((my & 15u) << JSH) | (srel << 8);
+        // accumulator offsets of a quad of slots packed into the dword of its first lane (byte q = slot 4 k + q);
+        // the other lanes of the quad carry the slab -- a batch reads both back with five v_readlane
+        const unsigned jv = (my & 15u) << JSH;
+        const unsigned j1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)jv, 0x101, 0xf, 0xf, true);   // row_shl:1
+        const unsigned j2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)jv, 0x102, 0xf, 0xf, true);
+        const unsigned j3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)jv, 0x103, 0xf, 0xf, true);
+        const unsigned jvs = (lane & 3) == 0 ? (jv | (j1 << 8) | (j2 << 16) | (j3 << 24)) : srel;
         u4 e;
         if constexpr (sizeof(F) == 8) {
             e = u4{(unsigned)__double2loint(a), (unsigned)__double2hiint(a), kq, jvs};
@@ -384,7 +292,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         }
         scratch[lane] = e;
         if constexpr (CSUM) {
-            if (4 * k * EN_B + lane < nbw * EN_B) atomic_add(cs_lds + (my & 15u), (double)a);
+            if (4 * k * EN_B + lane < nbw * EN_B) atomic_add(cs_lds + (jv >> JSH), (double)a);
         }
         vy = vx;
         my = mx;
@@ -469,7 +377,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
             o[6] = my; o[7] = lds_base;
         }
 #endif
-        const int slab = __builtin_amdgcn_readfirstlane((int)(e[3] >> 8));
+        const int slab = __builtin_amdgcn_readlane((int)e[3], 1);
         while (w < slab) end_slab();
 #if defined(EN_PIECE_SPLIT)           // half of the pieces with the first batch of a slab, half with the second
         if (ncopied < NV && w + 1 < ns) {
@@ -497,11 +405,14 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         // 7.5 of 59 slots per block at BASELINE configs[3]): the batch is worked on in quads of 4 slots.
         const unsigned live = (unsigned)__builtin_amdgcn_ballot_w64(a != F(0)) & 0xffffu;
         const int nq = live ? ((31 - __builtin_clz(live)) >> 2) + 1 : 0;
-        const unsigned jv = e[3] & 0xffu;
-        if (nq == 4) en_batch<16, F>(a, e[2], jv, lane_off);
-        else if (nq == 3) en_batch<12, F>(a, e[2], jv, lane_off);
-        else if (nq == 2) en_batch<8, F>(a, e[2], jv, lane_off);
-        else if (nq == 1) en_batch<4, F>(a, e[2], jv, lane_off);
+        unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)e[3], 0);
+        unsigned p1 = (unsigned)__builtin_amdgcn_readlane((int)e[3], 4);
+        unsigned p2 = (unsigned)__builtin_amdgcn_readlane((int)e[3], 8);
+        unsigned p3 = (unsigned)__builtin_amdgcn_readlane((int)e[3], 12);
+        if (nq == 4) en_batch_asm<16, F>(p0, p1, p2, p3, a, e[2], lane_off);
+        else if (nq == 3) en_batch_asm<12, F>(p0, p1, p2, p3, a, e[2], lane_off);
+        else if (nq == 2) en_batch_asm<8, F>(p0, p1, p2, p3, a, e[2], lane_off);
+        else if (nq == 1) en_batch_asm<4, F>(p0, p1, p2, p3, a, e[2], lane_off);
 #endif
         EN_TICK(pt_x)
         ++bis;
