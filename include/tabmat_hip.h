@@ -135,6 +135,11 @@ int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double
                              double *out, void *stream);
 int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                  double *out, double *colsum, void *stream);
+/* Blocks of 130 .. 512 (even) columns: 128-column panels -- the diagonal panels on the int8 matrix cores in
+ * place (each with its own envelope check and f64 hand-over), the off-diagonal panel pairs on the float64
+ * MFMA (the j-panels of ext/dense_helpers-tmpl.cpp:289).  colmax: length m.  out (m, m) is overwritten. */
+int tm_dense_sandwich_i8_wide_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                  double *out, void *stream);
 /* The same with a per-matrix HISTORY (int32[2] in device memory, zeroed by the caller once; colsum may be
  * NULL): [0] counts consecutive calls whose weights left the envelope after the product, [1] the calls.
  * After three misses in a row the int8 kernel is skipped on the device (the f64 kernel alone runs

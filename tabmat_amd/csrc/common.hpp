@@ -64,6 +64,11 @@ inline bool syrk_co_ok(const void *X, int64_t m) {
 // stay with the syrk_kernel instantiations of 16 / 32 / 64 columns
 inline bool syrk_co_pays(int64_t m) { return m > 64; }
 
+// K1e (syrk_i8.hip): the float64 syrk on the int8 matrix cores, for a block of <= 128 even columns or -- through
+// the row strides ldx / ldo of X / out -- for a 128-column panel of a wider block in place.
+int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, const double *colmax,
+                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st);
+
 // K1d (syrk_bf16.hip): X' diag(d) X of an unrestricted C-ordered f32 block of 4 k <= 256 columns on the
 // bf16 matrix cores (three-piece split, f32 accumulation); it pays above 128 columns.
 int run_syrk_bf16x3(const float *X, int64_t n, int64_t m, const float *d, float *out, hipStream_t st);

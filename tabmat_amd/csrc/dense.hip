@@ -572,6 +572,48 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     return TM_OK;
 }
 
+// Wide float64 blocks (130 .. 512 even columns, C order, unrestricted): 128-column panels.  The DIAGONAL
+// panels run on the int8 matrix cores in place (K1e through its row strides; every panel has its own
+// envelope check and f64 hand-over), the off-diagonal panel pairs on the rectangular f64 MFMA tile set.
+// 2M x 256: two int8 panels + one rectangle instead of three f64 passes (profiles/r4_regimes.txt).
+static int run_dense_sandwich_i8_wide(const double *X, int64_t n, int64_t m, const double *d,
+                                      const double *colmax, double *out, hipStream_t st) {
+    TM_REQUIRE(m > 128 && m <= 512 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
+               "a 16-byte aligned C-ordered float64 block of 130 .. 512 (even) columns");
+    if (n == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(m * m), st));
+        return TM_OK;
+    }
+    const int PW = 128;
+    const int np = (int)ceil_div(m, PW);
+    for (int a = 0; a < np; ++a) {
+        const int wa = (int)std::min<int64_t>(PW, m - (int64_t)a * PW);
+        int rc = run_syrk_i8_panel(X + (int64_t)a * PW, m, n, wa, d, colmax + (int64_t)a * PW,
+                                   out + ((int64_t)a * PW) * m + (int64_t)a * PW, m, nullptr, nullptr, st);
+        if (rc) return rc;
+    }
+    void *wsv = nullptr;
+    const size_t idx_bytes = 4096;
+    int rc = get_workspace(idx_bytes + syrk_ws_bytes<double>(256), &wsv, st);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(wsv);
+    int32_t *vpos = reinterpret_cast<int32_t *>(base) + 256;
+    for (int a = 0; a < np; ++a) {
+        hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos, (const int32_t *)nullptr,
+                           a * PW, PW);
+        for (int b = a + 1; b < np; ++b) {
+            const int wb = (int)std::min<int64_t>(PW, m - (int64_t)b * PW);
+            hipLaunchKernelGGL(iota_or_copy_i32_kernel, dim3(1), dim3(128), 0, st, vpos + PW,
+                               (const int32_t *)nullptr, b * PW, wb);
+            TM_LAUNCH_CHECK();
+            rc = launch_syrk<double, 16, true>(X, n, m, 0, d, nullptr, n, nullptr, PW + wb, vpos, out, m, base,
+                                               idx_bytes, st, (int64_t)a * PW, (int64_t)b * PW);
+            if (rc) return rc;
+        }
+    }
+    return TM_OK;
+}
+
 // -------------------------------------------------------------------------------------------
 // K5  matvec / rmatvec
 // -------------------------------------------------------------------------------------------
@@ -1068,6 +1110,11 @@ static int run_scatter(const F *src, int64_t nr, int64_t nc, const int64_t *ri, 
 using namespace tmh;
 
 extern "C" {
+
+int tm_dense_sandwich_i8_wide_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                  double *out, void *stream) {
+    return tmh::run_dense_sandwich_i8_wide(X, n, m, d, colmax, out, tmh::as_stream(stream));
+}
 
 #define TM_DENSE_ENTRY(NAME, F, RUN)                                                              \
     int NAME(const F *X, int64_t n, int64_t m, int order_f, const F *dv, const int32_t *rows,     \

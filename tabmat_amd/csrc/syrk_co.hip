@@ -267,15 +267,17 @@ size_t syrk_co_ws_bytes() {
     return 256 + sizeof(double) * grid * (CO_T * 256 + CO_W);
 }
 
-static int run_syrk_co_impl(const double *X, int64_t n, int64_t m, const double *d, double *out,
-                            double *colsum, const unsigned *only_if, void *ws_given, hipStream_t st) {
+// ldx / ldo: row strides (in elements) of X and out -- a 128-column panel of a wider block runs in place
+static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
+                            int64_t ldo, double *colsum, const unsigned *only_if, void *ws_given,
+                            hipStream_t st) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m),
                "the co-resident syrk takes a 16-byte aligned C-ordered block of an even number of "
                "columns <= 128");
     if (m == 0) return TM_OK;
     if (n == 0) {
-        TM_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(m * m), st));
+        TM_HIP(hipMemset2DAsync(out, sizeof(double) * (size_t)ldo, 0, sizeof(double) * (size_t)m, (size_t)m, st));
         if (colsum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(double) * (size_t)m, st));
         return TM_OK;
     }
@@ -297,12 +299,12 @@ static int run_syrk_co_impl(const double *X, int64_t n, int64_t m, const double 
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_co_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS));
     prof_begin(st);
-    hipLaunchKernelGGL(syrk_co_kernel, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, m,
+    hipLaunchKernelGGL(syrk_co_kernel, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, ldx,
                        (int)m, d, n_items, counter, part, cpart, wg_log_ptr(), only_if);
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_co_finish_kernel, dim3(CO_T, 4), dim3(64, 16), 0, st, part, grid, (int)m,
-                       out, m, only_if);
+                       out, ldo, only_if);
     TM_LAUNCH_CHECK();
     if (colsum) {
         hipLaunchKernelGGL(syrk_co_colsum_kernel, dim3(1), dim3(CO_W), 0, st, cpart, grid, (int)m,
@@ -314,13 +316,13 @@ static int run_syrk_co_impl(const double *X, int64_t n, int64_t m, const double 
 
 int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
                 hipStream_t st) {
-    return run_syrk_co_impl(X, n, m, d, out, colsum, nullptr, nullptr, st);
+    return run_syrk_co_impl(X, m, n, m, d, out, m, colsum, nullptr, nullptr, st);
 }
 
 // the same launches, live only when *flag != 0 (device memory): the int8 syrk's fallback
-int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
-                        const unsigned *flag, void *ws, hipStream_t st) {
-    return run_syrk_co_impl(X, n, m, d, out, colsum, flag, ws, st);
+int run_syrk_co_flagged(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
+                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st) {
+    return run_syrk_co_impl(X, ldx, n, m, d, out, ldo, colsum, flag, ws, st);
 }
 
 }  // namespace tmh

@@ -246,7 +246,7 @@ __global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, I8Info
 // (reference: standardized_mat.py:149-150 calls transpose_matvec).
 template <bool CSUM>
 __global__ __launch_bounds__(I8_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const double *__restrict__ d,
+void syrk_i8_kernel(const double *__restrict__ X, int64_t ldx, int64_t n, int64_t m, const double *__restrict__ d,
                     const double *__restrict__ sigma, const I8Info *__restrict__ info, int n_items,
                     unsigned *__restrict__ counter, double *__restrict__ part, double *__restrict__ colsum) {
     if (info->flag != 0) return;                                          // the f64 kernel takes this call
@@ -289,10 +289,11 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
     auto issue_half = [&](int rb) -> unsigned {
         const unsigned id = idL;
         const int64_t tb = (int64_t)id * I8_ITEM_ROWS + (int64_t)hL * I8_HS;
-        const int64_t left = min((n - tb) * m * 8, (int64_t)I8_HS * m * 8);
+        // (ldx = row stride of X in elements: a 128-column panel of a wider block is read in place)
+        const int64_t left = min((n - tb) * ldx * 8, (int64_t)I8_HS * ldx * 8);
         // (the 64-bit products above are computed on the vector unit: without the readfirstlane the
         // descriptor counts as divergent and every copy sits in a waterfall loop)
-        const uint64_t xb = (uint64_t)(uintptr_t)(X + tb * m);
+        const uint64_t xb = (uint64_t)(uintptr_t)(X + tb * ldx);
         const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xb);
         const unsigned xhi = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
         const unsigned nbytes = __builtin_amdgcn_readfirstlane(
@@ -303,7 +304,7 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t n, int64_t m, const do
 #if !defined(I8_ABLATE_NO_DMA)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            i8_dma16(rs, raw + rb * I8_RAWBUF + (8 * wave + j) * I8_RAWSTR, (int)((8 * wave + j) * m * 8) + dma_voff);
+            i8_dma16(rs, raw + rb * I8_RAWBUF + (8 * wave + j) * I8_RAWSTR, (int)((8 * wave + j) * ldx * 8) + dma_voff);
 #endif
         if (++hL == 2 * I8_CPI) {
             hL = 0;
@@ -745,18 +746,20 @@ __global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, 
 }
 
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
-int run_syrk_co_flagged(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
-                        const unsigned *flag, void *ws, hipStream_t st);
+int run_syrk_co_flagged(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
+                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st);
 size_t syrk_co_ws_bytes();
 
-int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
-                double *colsum, int *history, hipStream_t st) {
+// X: first element of the block (or of a 128-column panel of a wider one), ldx / ldo: row strides of X / out
+int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, const double *colmax,
+                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    TM_REQUIRE(ldx >= m && ldx % 2 == 0 && ldo >= m, "row strides");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m), "the int8 syrk takes a 16-byte aligned C-ordered f64 block of an "
                                            "even number of columns <= 128");
     if (m == 0) return TM_OK;
     if (n == 0) {
-        TM_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(m * m), st));
+        TM_HIP(hipMemset2DAsync(out, sizeof(double) * (size_t)ldo, 0, sizeof(double) * (size_t)m, (size_t)m, st));
         if (colsum) TM_HIP(hipMemsetAsync(colsum, 0, sizeof(double) * (size_t)m, st));
         return TM_OK;
     }
@@ -784,22 +787,27 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
     TM_LAUNCH_CHECK();
     prof_begin(st);
     if (colsum)
-        hipLaunchKernelGGL(syrk_i8_kernel<true>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma,
+        hipLaunchKernelGGL(syrk_i8_kernel<true>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, ldx, n, m, d, sigma,
                            info, n_items, counter, part, colsum);
     else
-        hipLaunchKernelGGL(syrk_i8_kernel<false>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, n, m, d, sigma,
-                           info, n_items, counter, part, colsum);
+        hipLaunchKernelGGL(syrk_i8_kernel<false>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, ldx, n, m, d,
+                           sigma, info, n_items, counter, part, colsum);
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
-                       out, m);
-    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, m, colmax, (int)m, n, info, history);
+                       out, ldo);
+    hipLaunchKernelGGL(i8_envelope_kernel, dim3(1), dim3(I8_W), 0, st, out, ldo, colmax, (int)m, n, info, history);
     TM_LAUNCH_CHECK();
     // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
     prof_hold(true);               // (the event pair stays on the int8 kernel)
-    rc = run_syrk_co_flagged(X, n, m, d, out, colsum, &info->flag, wb + own_bytes, st);
+    rc = run_syrk_co_flagged(X, ldx, n, m, d, out, ldo, colsum, &info->flag, wb + own_bytes, st);
     prof_hold(false);
     return rc;
+}
+
+int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
+                double *colsum, int *history, hipStream_t st) {
+    return run_syrk_i8_panel(X, m, n, m, d, colmax, out, m, colsum, history, st);
 }
 
 }  // namespace tmh

@@ -32,6 +32,9 @@ ROW_MAJOR_TWIN = os.environ.get("TABMAT_AMD_ROW_MAJOR_TWIN", "1") != "0"
 # the float64 syrk on the int8 matrix cores (Ozaki-style slicing, csrc/syrk_i8.hip) for blocks it suits
 SYRK_I8 = os.environ.get("TABMAT_AMD_SYRK_I8", "1") != "0"
 I8_MIN_ROWS = 4096
+I8_MAX_COLS = 512      # above 128 columns: 128-column panels (diagonal panels int8, panel pairs f64 MFMA)
+# a row restriction that keeps at least this share of the rows runs the unrestricted int8 syrk on a masked d
+I8_MASKED_ROWS_SHARE = 0.25
 
 
 def set_strict_f64(flag: bool = True) -> bool:
@@ -197,7 +200,7 @@ class DenseMatrix(MatrixBase):
         if hit is None:
             hit = False
             blk = self._dev_c()
-            if (not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= 128
+            if (not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= I8_MAX_COLS
                     and blk.m % 2 == 0 and blk.n >= I8_MIN_ROWS and blk.buf.data_ptr() % 16 == 0):
                 # (two reductions, no |X| copy of the block: it is 10 GB at BASELINE configs[3]; a NaN
                 # propagates through amax / amin, +-inf shows in one of them)
@@ -216,9 +219,18 @@ class DenseMatrix(MatrixBase):
         return h
 
     def _sandwich_dev(self, d, rows, cols):
-        if SYRK_I8 and rows is None and cols is None and d.dtype == torch.float64:
+        if (SYRK_I8 and cols is None and d.dtype == torch.float64
+                and (rows is None or D.nlen(rows) >= I8_MASKED_ROWS_SHARE * self.shape[0])):
             cmax = self._i8_colmax()
             if cmax is not None:
+                if rows is not None:
+                    # excluded rows get d = 0 (the block is finite: checked once in _i8_colmax), one full pass
+                    dm = torch.zeros_like(d)
+                    r64 = rows.to(torch.int64)
+                    dm[r64] = d[r64]
+                    d = dm
+                if self.shape[1] > 128:
+                    return xd.dense_sandwich_i8_wide(self._dev_c(), d, cmax)
                 return xd.dense_sandwich_i8(self._dev_c(), d, cmax, history=self._i8_history())
         return xd.dense_sandwich(self._dev_c(), d, rows, cols)
 
@@ -228,7 +240,7 @@ class DenseMatrix(MatrixBase):
         standardized_mat.py:149-150): the int8-sliced syrk (K1e) inside its envelope, else the f64
         syrk with the column sums of its A-side fragments (K1c)."""
         blk = self._dev_c()
-        if SYRK_I8 and d.dtype == torch.float64:
+        if SYRK_I8 and d.dtype == torch.float64 and blk.m <= 128:
             cmax = self._i8_colmax()
             if cmax is not None:
                 return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True, history=self._i8_history())

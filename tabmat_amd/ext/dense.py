@@ -142,3 +142,15 @@ def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False, history=None):
         return out, cs
     call("tm_dense_sandwich_i8_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.stream_ptr())
     return out
+
+
+def dense_sandwich_i8_wide(X: DenseDev, d, colmax):
+    """X' diag(d) X of an unrestricted C-ordered float64 block of 130 .. 512 (even) columns: the diagonal
+    128-column panels on the int8 matrix cores in place, the off-diagonal panel pairs on the f64 MFMA
+    (tm_dense_sandwich_i8_wide_f64; reference: the j-panels of ext/dense_helpers-tmpl.cpp:289)."""
+    import torch
+
+    out = D.out_buf((X.m, X.m), torch.float64)
+    D.same_float("dense_sandwich_i8_wide", X.buf, d, colmax)
+    call("tm_dense_sandwich_i8_wide_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.stream_ptr())
+    return out

@@ -143,3 +143,57 @@ def test_i8_history_skips_the_attempt_after_three_misses():
     hist[1] = 32
     xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist)
     assert hist.cpu().numpy()[0] == 0
+
+
+@pytest.mark.parametrize("n", [1, 2049, 70_001])
+@pytest.mark.parametrize("m", [130, 200, 256, 384, 512])
+def test_i8_wide_panels_vs_oracle(n, m):
+    """blocks of 130 .. 512 columns as 128-column panels (diagonal panels int8 in place,
+    panel pairs f64 MFMA), entry-wise < 1e-10 at the natural scale (ext/dense_helpers-tmpl.cpp:266-311)."""
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext._types import DenseDev
+
+    rng = np.random.default_rng(n + m)
+    X = rng.standard_normal((n, m)) * rng.lognormal(0, 2, m)
+    d = rng.random(n)
+    d[::5] = 0.0
+    cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
+    out = xd.dense_sandwich_i8_wide(DenseDev.from_host(X), torch.from_numpy(d).cuda(), cmax).cpu().numpy()
+    ref = _orc().dense_sandwich(X, d, None, None)
+    assert rel_err(out, ref) < 1e-10
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
+    assert float((np.abs(out - ref) / scale).max()) < 1e-10
+    assert np.allclose(out, out.T, rtol=0, atol=0) or float((np.abs(out - out.T) / scale).max()) < 1e-12
+
+
+def test_i8_wide_hand_over_and_dense_matrix_dispatch(monkeypatch):
+    """Negative weights: every panel hands over to the f64 kernel on the device; DenseMatrix takes the wide path
+    for an unrestricted 256-column float64 block and the masked-d form for a long row list."""
+    import tabmat_amd as tm
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext._types import DenseDev
+
+    rng = np.random.default_rng(9)
+    n, m = 30_000, 256
+    X = rng.standard_normal((n, m))
+    d = rng.random(n) - 0.3
+    cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
+    out = xd.dense_sandwich_i8_wide(DenseDev.from_host(X), torch.from_numpy(d).cuda(), cmax).cpu().numpy()
+    assert rel_err(out, _orc().dense_sandwich(X, d, None, None)) < 1e-10
+    calls = []
+    real = xd.dense_sandwich_i8_wide
+    monkeypatch.setattr(xd, "dense_sandwich_i8_wide", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    d = rng.random(n)
+    dm = tm.DenseMatrix(X)
+    assert rel_err(dm.sandwich(d), _orc().dense_sandwich(X, d, None, None)) < 1e-10 and len(calls) == 1
+    rows = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32)
+    ref = _orc().dense_sandwich(X, d, rows, None)
+    assert rel_err(dm.sandwich(d, rows=rows), ref) < 1e-10 and len(calls) == 2
+    few = rows[:100]
+    dm.sandwich(d, rows=few)
+    assert len(calls) == 2                      # a short row list keeps the row-list kernel
+    was = tm.set_strict_f64(True)
+    try:
+        assert rel_err(dm.sandwich(d), _orc().dense_sandwich(X, d, None, None)) < 1e-10 and len(calls) == 2
+    finally:
+        tm.set_strict_f64(was)
