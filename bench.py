@@ -510,7 +510,7 @@ def main():
             dense_term = ("int8x5 (40-bit fixed point per column on the int8 matrix cores, K1e; hand-over to "
                           "the f64 MFMA kernel outside its envelope)") if took_i8 else "f64 MFMA"
         if took_i8:
-            hist = took_i8[0]._i8_history().cpu().tolist()       # {consecutive envelope misses, calls}
+            hist = took_i8[0]._i8_history()[:2].cpu().tolist()   # {consecutive envelope misses, calls}
             handovers = {"consecutive_envelope_misses": int(hist[0]), "calls": int(hist[1])}
             was = tm.set_strict_f64(True)
             try:

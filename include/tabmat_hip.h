@@ -140,11 +140,13 @@ int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const do
  * MFMA (the j-panels of ext/dense_helpers-tmpl.cpp:289).  colmax: length m.  out (m, m) is overwritten. */
 int tm_dense_sandwich_i8_wide_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                   double *out, void *stream);
-/* The same with a per-matrix HISTORY (int32[2] in device memory, zeroed by the caller once; colsum may be
- * NULL): [0] counts consecutive calls whose weights left the envelope after the product, [1] the calls.
- * After three misses in a row the int8 kernel is skipped on the device (the f64 kernel alone runs
- * instead of both) and tried again every 32nd call -- a solver whose weights stay outside the envelope
- * pays for the int8 attempt three times, not in every iteration. */
+/* The same with a per-matrix HISTORY (int32[tm_dense_sandwich_i8_history_words()] in device memory, zeroed by
+ * the caller once; colsum may be NULL): [0] counts consecutive calls whose weights left the envelope after the
+ * product, [1] the calls, [4 ..] hold the diagonal of the previous call's result (128 doubles).  A call whose
+ * weights fail the envelope test against THAT diagonal skips the int8 kernel on the device before the product
+ * (round 4: a miss costs the f64 kernel alone -- the weights of an IRLS solver move slowly); after three
+ * misses in a row the int8 kernel is skipped anyway and tried again every 32nd call. */
+int tm_dense_sandwich_i8_history_words(void);
 int tm_dense_sandwich_i8_hist_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                   double *out, double *colsum, int32_t *history, void *stream);
 

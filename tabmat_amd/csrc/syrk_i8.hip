@@ -213,10 +213,11 @@ __global__ __launch_bounds__(256) void i8_screen_kernel(const double *__restrict
 }
 
 // sigma[i] = 2^k_i (the fixed-point scale of column i), rscale[i] = 2^-k_i
-// history (may be NULL; per matrix, device memory): [0] = consecutive calls that left the envelope after the
-// product, [1] = calls.  After three misses in a row the int8 kernel is skipped (flag bit 2: the f64
+// history (may be NULL; per matrix, device memory, int32[tm_dense_sandwich_i8_history_words()] zeroed once):
+// [0] = consecutive calls that left the envelope after the product, [1] = calls, [4 ..] = 128 doubles: the
+// diagonal of the previous call's result.  After three misses in a row the int8 kernel is skipped (flag bit 2: the f64
 // kernel alone runs, instead of both) and tried again every 32nd call.
-__global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, I8Info *info,
+__global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, int64_t n_rows, I8Info *info,
                                 double *__restrict__ sigma, double *__restrict__ rscale, int *history) {
     const int i = threadIdx.x;
     if (history != nullptr && i == 0) {
@@ -225,6 +226,16 @@ __global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, I8Info
     }
     if (i >= I8_W) return;
     const double dmax = __longlong_as_double(*reinterpret_cast<const long long *>(info));
+    // The envelope test of the column against the diagonal of the PREVIOUS call (history + 4: 128 doubles, 0 =
+    // none yet): the weights of an IRLS solver move slowly, so a call that is going to miss is recognised
+    // BEFORE the product and costs the f64 kernel alone, not the int8 attempt as well.
+    // A wrong guess costs one call: every call records its diagonal afterwards (i8_record_diag_kernel).
+    if (history != nullptr && i < m && n_rows > 0) {
+        const double prev = reinterpret_cast<const double *>(history + 4)[i];
+        const double bound = fmin(64.0, 134217728.0 / (double)n_rows);
+        if (prev > 0.0 && !(colmax[i] * colmax[i] * dmax <= bound * prev)) atomicOr(&info->flag, 4u);
+    }
+    __syncthreads();
     double s = 1.0, r = 1.0;
     if (i < m) {
         const double big = colmax[i] * sqrt(dmax);
@@ -745,6 +756,12 @@ __global__ void i8_envelope_kernel(const double *__restrict__ out, int64_t ldo, 
     if (history != nullptr && j == 0 && live) history[0] = miss ? history[0] + 1 : 0;
 }
 
+// the diagonal of this call's result (whichever kernel produced it) for the next call's prediction
+__global__ void i8_record_diag_kernel(const double *__restrict__ out, int64_t ldo, int m, int *history) {
+    const int j = threadIdx.x;
+    if (j < I8_W) reinterpret_cast<double *>(history + 4)[j] = j < m ? out[(int64_t)j * ldo + j] : 0.0;
+}
+
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
 int run_syrk_co_flagged(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
                         int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st);
@@ -783,7 +800,7 @@ int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const 
     TM_HIP(hipMemsetAsync(wb, 0, 4096 + part_bytes, st));
     const int sgrid = (int)std::min<int64_t>(4 * NUM_CU, ceil_div(n, 1024));
     hipLaunchKernelGGL(i8_screen_kernel, dim3((unsigned)sgrid), dim3(256), 0, st, d, n, info);
-    hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, info, sigma, rscale, history);
+    hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, n, info, sigma, rscale, history);
     TM_LAUNCH_CHECK();
     prof_begin(st);
     if (colsum)
@@ -802,6 +819,10 @@ int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const 
     prof_hold(true);               // (the event pair stays on the int8 kernel)
     rc = run_syrk_co_flagged(X, ldx, n, m, d, out, ldo, colsum, &info->flag, wb + own_bytes, st);
     prof_hold(false);
+    if (rc == TM_OK && history != nullptr) {
+        hipLaunchKernelGGL(i8_record_diag_kernel, dim3(1), dim3(I8_W), 0, st, out, ldo, (int)m, history);
+        TM_LAUNCH_CHECK();
+    }
     return rc;
 }
 
@@ -813,6 +834,8 @@ int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const do
 }  // namespace tmh
 
 extern "C" {
+
+int tm_dense_sandwich_i8_history_words(void) { return 4 + 2 * tmh::I8_W; }
 
 int tm_dense_sandwich_i8_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                              double *out, void *stream) {

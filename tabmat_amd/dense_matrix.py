@@ -212,10 +212,14 @@ class DenseMatrix(MatrixBase):
         return None if hit is False else hit
 
     def _i8_history(self):
-        """int32 [2] on the device: {consecutive envelope misses, calls} of this block's int8 syrk."""
+        """int32 words on the device: {consecutive envelope misses, calls, -, -, the previous call's diagonal
+        (128 doubles)} of this block's int8 syrk (tm_dense_sandwich_i8_hist_f64)."""
         h = getattr(self, "_i8_hist", None)
         if h is None:
-            h = self._i8_hist = torch.zeros(2, dtype=torch.int32, device=self._dev_c().buf.device)
+            from ._lib import lib
+
+            h = self._i8_hist = torch.zeros(int(lib().tm_dense_sandwich_i8_history_words()), dtype=torch.int32,
+                                            device=self._dev_c().buf.device)
         return h
 
     def _sandwich_dev(self, d, rows, cols):

@@ -111,10 +111,13 @@ def test_i8_column_sums_from_the_same_pass(n, m):
         assert np.abs(cs - want).max() <= 1e-12 * (np.abs(X).T @ np.abs(d)).max()
 
 
-def test_i8_history_skips_the_attempt_after_three_misses():
-    """tm_dense_sandwich_i8_hist_f64: weights that keep leaving the envelope pay for the int8 attempt three
-    times; from then on the device skips it (history[0] stays, the f64 kernel alone produces the result)
-    until the 32nd call tries again."""
+def test_i8_history_predicts_the_miss_from_the_previous_diagonal():
+    """tm_dense_sandwich_i8_hist_f64: the FIRST call with weights outside the envelope pays
+    for the int8 attempt (miss counted, diagonal recorded); from the second call on the envelope test against
+    the previous call's diagonal skips the attempt on the device BEFORE the product -- the miss counter stays
+    (the int8 kernel did not run), the f64 kernel alone produces the result.  Back inside the envelope, one
+    call later the int8 kernel runs again."""
+    from tabmat_amd._lib import lib
     from tabmat_amd.ext import dense as xd
     from tabmat_amd.ext._types import DenseDev
 
@@ -127,21 +130,25 @@ def test_i8_history_skips_the_attempt_after_three_misses():
     good = rng.random(n)
     Xd = DenseDev.from_host(X)
     cmax = torch.from_numpy(np.abs(X).max(axis=0)).cuda()
-    hist = torch.zeros(2, dtype=torch.int32, device="cuda")
+    words = int(lib().tm_dense_sandwich_i8_history_words())
+    hist = torch.zeros(words, dtype=torch.int32, device="cuda")
     ref_bad = _orc().dense_sandwich(X, bad, None, None)
     scale = np.sqrt(np.outer(np.diag(ref_bad), np.diag(ref_bad)))
     for call in range(1, 7):
         out = xd.dense_sandwich_i8(Xd, torch.from_numpy(bad).cuda(), cmax, history=hist).cpu().numpy()
         assert float((np.abs(out - ref_bad) / scale).max()) < 1e-12
         h = hist.cpu().numpy()
-        assert h[1] == call and h[0] == min(call, 3)      # misses counted while the int8 kernel still runs
-    # good weights while the attempt is skipped: still the f64 kernel, the history stays
+        assert h[1] == call and h[0] == 1                 # one attempt, then predicted
+        diag = hist[4:].view(torch.float64).cpu().numpy()
+        assert np.allclose(diag[:m], np.diag(ref_bad), rtol=1e-10)
+    # good weights: the prediction still sees the old diagonal (f64 kernel, counter untouched) ...
+    ref_good = _orc().dense_sandwich(X, good, None, None)
     out = xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist).cpu().numpy()
-    assert rel_err(out, _orc().dense_sandwich(X, good, None, None)) < 1e-10
-    assert hist.cpu().numpy()[0] == 3
-    # the 32nd call tries again and clears it
-    hist[1] = 32
-    xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist)
+    assert rel_err(out, ref_good) < 1e-10
+    assert hist.cpu().numpy()[0] == 1
+    # ... the next call runs the int8 kernel again and clears it
+    out = xd.dense_sandwich_i8(Xd, torch.from_numpy(good).cuda(), cmax, history=hist).cpu().numpy()
+    assert rel_err(out, ref_good) < 1e-10
     assert hist.cpu().numpy()[0] == 0
 
 
