@@ -299,6 +299,15 @@ class SparseMatrix(MatrixBase):
                 out = D.zeros((k, k), d.dtype)
             return out
         A = self._dev()
+        from . import categorical_matrix as _cm
+
+        if _cm.DETERMINISTIC and A.data.numel() > 0 and self.shape[0] > 0:
+            res = self._sandwich_deterministic(d, rows)
+            if res is not None:
+                if cols is not None:
+                    c64 = cols.to(torch.int64)
+                    res = res[c64][:, c64].contiguous()
+                return res
         if getattr(self, "_direct_pays", None) is None:
             self._direct_pays = xs.direct_sandwich_pays(A)
         w = D.nlen(cols) if cols is not None else 0
@@ -361,6 +370,42 @@ class SparseMatrix(MatrixBase):
                 res = res[c64][:, c64].contiguous()
             return res
         return xs.sparse_sandwich(A, d, rows, cols)
+
+    def _sandwich_deterministic(self, d, rows):
+        """TABMAT_AMD_DETERMINISTIC=1: the sparse self sandwich with a FIXED summation order, bit-identical
+        from run to run -- the property the reference's kernel has by construction (thread-owned output rows,
+        ext/sparse.pyx:55-74) and the LDS-atomic pair kernels (K2 / K2b) do not.  The block's columns are
+        written out densely 128 at a time and every chunk goes through the entry-list kernel (K3,
+        csrc/sparse_ent.hip): an accumulator there receives its entries in stream order, the workgroups'
+        partial sums are added in a fixed order.  out[i, j] and out[j, i] see the same terms in the same
+        order but multiply them in a different one, so the lower triangle is mirrored.  About 4x the time of
+        the atomic kernel at BASELINE configs[3]; opt-in."""
+        from .ext._types import DenseDev
+
+        ent = self._ent()
+        if ent is None:
+            return None
+        n, m = self.shape
+        A = self._dev()
+        if rows is not None:
+            dm = torch.zeros_like(d)
+            r64 = rows.to(torch.int64)
+            dm[r64] = d[r64]
+            d = dm
+        out = torch.empty((m, m), dtype=d.dtype, device=d.device)
+        W = 128
+        for c0 in range(0, m, W):
+            w = min(W, m - c0)
+            w_pad = (w + 3) // 4 * 4                     # 16-byte aligned rows for the kernel's slab copy
+            colmap = torch.full((m,), -1, dtype=torch.int32, device=d.device)
+            colmap[c0:c0 + w] = torch.arange(w, dtype=torch.int32, device=d.device)
+            T = torch.zeros((n, w_pad), dtype=A.data.dtype, device=d.device)
+            xs.csr_densify_cols(A, colmap, T)
+            res = xs.csr_dense_sandwich_ent(ent, DenseDev(T, n, w_pad, 0), d)
+            out[:, c0:c0 + w] = res[:, :w]
+            del T
+        low = torch.tril(out)
+        return low + torch.tril(out, -1).T
 
     def sandwich(self, d, rows=None, cols=None):
         """sparse_matrix.py:175-185."""

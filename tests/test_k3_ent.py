@@ -173,3 +173,39 @@ def test_sparse_matrix_takes_the_entry_kernel():
     assert any(s.startswith("tm_csr_dense_sandwich_ent_") for s in seen), seen
     ref = S.T @ (d[:, None] * X)
     assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_deterministic_sparse_self_sandwich(dtype, monkeypatch):
+    """TABMAT_AMD_DETERMINISTIC: the sparse self sandwich in a fixed summation order (column chunks through the
+    entry-list kernel) -- bit-identical from run to run, exactly symmetric, equal to the oracle within the
+    float tolerance; the reference's kernel is deterministic by construction (ext/sparse.pyx:55-74)."""
+    import tabmat_amd as tm
+    import tabmat_amd.categorical_matrix as cmod
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(12)
+    n, m = 30_011, 300
+    S = sps.random(n, m, density=0.05, format="csc", random_state=rng, dtype=np.float64).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    sm = tm.SparseMatrix(S)
+    monkeypatch.setattr(cmod, "DETERMINISTIC", True)
+    a = sm.sandwich(d)
+    b = sm.sandwich(d)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, a.T)
+    want = orc.sparse_sandwich(sps.csc_matrix(S).astype(np.float64), sps.csr_matrix(S).astype(np.float64),
+                               d.astype(np.float64), None, None)
+    tol = 1e-10 if dtype == np.float64 else 3e-4
+    assert np.abs(a - want).max() / np.abs(want).max() < tol
+    rows = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.int32)
+    cols = np.sort(rng.choice(m, 50, replace=False)).astype(np.int32)
+    Sr = S.tocsr()[rows][:, cols].astype(np.float64)
+    want_rc = (Sr.T.multiply(d[rows].astype(np.float64))).dot(Sr).toarray()
+    got_rc = sm.sandwich(d, rows, cols)
+    assert np.abs(got_rc - want_rc).max() / np.abs(want_rc).max() < tol
+    assert np.array_equal(got_rc, sm.sandwich(d, rows, cols))
+    monkeypatch.setattr(cmod, "DETERMINISTIC", False)
+    c = sm.sandwich(d)
+    assert np.abs(a - c).max() / np.abs(want).max() < tol
