@@ -32,9 +32,15 @@ __device__ __forceinline__ void sfor(Fn &&f) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int I>
+template <int I, bool HALF = false>
 __device__ __forceinline__ void issue_read(u32x32 &X, unsigned kq, unsigned lane_off) {
     unsigned tmp;
+    if constexpr (HALF)
+        asm volatile("v_add_u32_dpp %1, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                     "ds_read_b64 v[32+4*%5:32+4*%5+1], %1"
+                     : "+{v[32:63]}"(X), "=&v"(tmp)
+                     : "v"(kq), "v"(lane_off >> 1), "n"(I), "n"(I % 8));
+    else
     asm volatile("v_add_u32_dpp %1, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
                  "ds_read_b128 v[32+4*%5:32+4*%5+3], %1"
                  : "+{v[32:63]}"(X), "=&v"(tmp)
@@ -89,7 +95,12 @@ __device__ __forceinline__ void fma_entry(d16 &T0, d16 &T1, u32x32 &X, int sj, d
                      "v_fmac_f64 v[66:67], %4, v[32+4*%5+2:32+4*%5+3]"
                      : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
                      : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
-    } else if constexpr (MODE == 4) {      // LDS reads only
+    } else if constexpr (MODE == 7) {      // half rows: one fmac per entry (reads are b64, see issue_read)
+        asm volatile("s_waitcnt lgkmcnt(%6)\n\t"
+                     "v_fmac_f64_dpp v[64:65], %4, v[32+4*%5:32+4*%5+1] row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                     : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
+                     : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
+    } else if constexpr (MODE == 4 || MODE == 8) {      // LDS reads only
         asm volatile("s_waitcnt lgkmcnt(%6)"
                      : "+{v[64:95]}"(T0), "+{v[96:127]}"(T1), "+{v[32:63]}"(X)
                      : "s"(sj), "v"(a), "n"(I % 8), "n"(WAIT), "n"(I));
@@ -112,7 +123,7 @@ __device__ __forceinline__ void fma_entry(d16 &T0, d16 &T1, u32x32 &X, int sj, d
     }
 }
 #else
-template <int I> void issue_read(u32x32 &, unsigned, unsigned) {}
+template <int I, bool HALF = false> void issue_read(u32x32 &, unsigned, unsigned) {}
 template <int I> unsigned make_addr(unsigned, unsigned) { return 0; }
 template <int I> void read_at(u32x32 &, unsigned) {}
 template <int I, int WAIT> void fma_idx(d16 &, d16 &, u32x32 &, int, double) {}
@@ -176,12 +187,13 @@ __global__ __launch_bounds__(1024) void kidx(double *out, const double *vals_all
                 });
                 asm volatile("s_set_gpr_idx_off");
             } else {
-            if constexpr (MODE != 5) sfor<8>([&](auto ic) { issue_read<decltype(ic)::value>(X, kq, lane_off); });
+            constexpr bool HB = MODE == 7 || MODE == 8;
+            if constexpr (MODE != 5) sfor<8>([&](auto ic) { issue_read<decltype(ic)::value, HB>(X, kq, lane_off); });
             sfor<16>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 constexpr int wait = i <= 8 ? 7 : 15 - i;
                 fma_entry<MODE, i, wait>(T0, T1, X, sj[i], a, slo[i], shi[i]);
-                if constexpr (i + 8 < 16 && MODE != 5) issue_read<i + 8>(X, kq, lane_off);
+                if constexpr (i + 8 < 16 && MODE != 5) issue_read<i + 8, HB>(X, kq, lane_off);
             });
             }
         }
@@ -251,6 +263,8 @@ int main() {
         run(kidx<6>, "index mode on over the batch, idx_idx", nw, true);
         run(kidx<3>, "static accumulator, fmac without DPP", nw, false);
         run(kidx<4>, "LDS reads only (no FMA)", nw, false);
+        run(kidx<7>, "HALF rows: ds_read_b64 + 1 fmac (static)", nw, false);
+        run(kidx<8>, "HALF rows: ds_read_b64 only", nw, false);
         run(kidx<5>, "index mode + fmac_dpp only (no LDS)", nw, false);
     }
     return 0;
