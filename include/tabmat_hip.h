@@ -383,6 +383,12 @@ int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, cons
                                   int64_t m, const double *B, int64_t r, const double *d, double *out,
                                   double *colsum, void *stream);
 
+/* ---- Index widths of the sparse entry points.  csr_indices are int32, csr_indptr int64 everywhere below: the
+ * reference's fused integral type (ext/sparse.pyx:13-15, `win_integral` = int32 | int64) is NOT mirrored with
+ * separate _i64 symbols.  A binder narrows int64 column indices on upload (each is < m, and m fits int32 for
+ * every matrix this path can hold in HBM) and widens int32 row pointers; tabmat_amd/ext/_types.py does exactly
+ * that (CsrDev.from_scipy), tests/test_gpu_reference_cases.py loads the golden fixture with both widths. ---- */
+
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */
 int tm_csr_matvec_f32(const float *csr_data, const int32_t *csr_indices,
