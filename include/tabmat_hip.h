@@ -85,7 +85,11 @@ int tm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on 
  * "catdense_waves" / "catsparse_waves" (waves of the fused categorical cross terms), "co_grid"
  * (workgroups of the co-resident syrk), "wg_log" (device pointer to a placement log: uint64
  * {count, capacity, 0, 0} followed by records {XCC_ID << 32 | HW_ID, start, end, kernel tag} that
- * the instrumented kernels append per workgroup, s_memrealtime ticks; 0 = off). ---- */
+ * the instrumented kernels append per workgroup, s_memrealtime ticks; 0 = off); experiment knobs that used to be
+ * environment variables: "k2_slots" (8 / 4 / 2 slots per row and chunk of the chunked sparse sandwich, 0 = by
+ * density), "lg_lockstep" (soft lockstep of the lane-group K3's column-half workgroups, default 1), "k2b_waves",
+ * "ent_rounds" / "lg_rounds" (workgroup rounds of the K3 kernels), "ent_prof" (device pointer for the -DEN_PROF
+ * build's section counters).  A knob changes launch geometry, never results. ---- */
 /* (value INT64_MIN removes the setting: the built-in default applies again) */
 int tm_tune_set(const char *h_key, int64_t value);
 int tm_tune_get(const char *h_key, int64_t dflt, int64_t *value);

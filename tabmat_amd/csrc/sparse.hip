@@ -1069,7 +1069,7 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     // slots per row and list half by the mean number of nonzeros per row and 128-column chunk
     const double per_chunk = (double)nnz / ((double)n * nchunk);
-    static const int force_s = getenv("TABMAT_AMD_K2_SLOTS") ? atoi(getenv("TABMAT_AMD_K2_SLOTS")) : 0;
+    const int force_s = (int)tune("k2_slots", 0);      // (experiments: 8 / 4 / 2 slots per row and chunk; 0 = by density)
     // measured at 2M rows (profiles/r2_microbench.txt): 8 slots win above ~4.5 nonzeros per row and
     // chunk, 2 slots below ~0.9
     const int slots = force_s ? force_s : (per_chunk > 4.5 ? 8 : per_chunk > 0.9 ? 4 : 2);

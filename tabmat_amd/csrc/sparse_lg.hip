@@ -629,8 +629,8 @@ static int run_csr_dense_lg(const F *vals, const unsigned *koff, const int64_t *
     const size_t part_bytes = (sizeof(F) * (size_t)((int64_t)n_parts * nblk * stride) + 255) / 256 * 256;
     const size_t csum_bytes = ((want_csum ? sizeof(F) * (size_t)(nblk * m) : 0) + 255) / 256 * 256 + 256;
     // soft lockstep of the column-half workgroups (21.2 -> 18.1 GB of HBM traffic at cfg4, same
-    // time); TABMAT_AMD_LG_LOCKSTEP=0 switches it off
-    static const int lockstep = getenv("TABMAT_AMD_LG_LOCKSTEP") ? atoi(getenv("TABMAT_AMD_LG_LOCKSTEP")) : 1;
+    // time); tm_tune_set("lg_lockstep", 0) switches it off
+    const int lockstep = (int)tune("lg_lockstep", 1);
     const size_t prog_bytes = (sizeof(int) * (size_t)(n_parts * nblk * nz) + 255) / 256 * 256;
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + part_bytes + csum_bytes + prog_bytes + 256, &wsv, st);

@@ -2,7 +2,6 @@
 a sparse block is kept on the device; see include/tabmat_hip.h."""
 from __future__ import annotations
 
-import os
 
 from .. import _device as D
 from .._lib import call
@@ -235,7 +234,7 @@ def sparse_sandwich_chunked(A: CsrDev, d):
 
 
 # the block-list form of the unrestricted sparse self sandwich (csrc/sparse_blocks.hip)
-K2_BLOCKS = os.environ.get("TABMAT_AMD_K2_BLOCKS", "1") != "0"
+K2_BLOCKS = True
 
 
 def blocks_sandwich_pays(A: CsrDev) -> bool:

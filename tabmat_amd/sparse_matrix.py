@@ -27,9 +27,9 @@ from .util import (
 # The interleaved-ELL twin pads every non-empty (slab, column group) to whole 64-slot iterations
 # (x1.9 .. x2.5 at 5 % density); beyond this factor the compact slab stream is used instead.
 ELL_MAX_PAD = 8.0
-# K3's lane-group stream in its compact form (values of the real slots + a byte map: 2.7 instead of 7.7 GB at
-# BASELINE configs[3]); TABMAT_AMD_LG_COMPACT=0 keeps the padded stream of round 2
-LG_COMPACT = os.environ.get("TABMAT_AMD_LG_COMPACT", "1") != "0"
+# K3's lane-group stream (the fallback of the entry twin since round 4) in its compact form: values of the real
+# slots + a byte map, 2.7 instead of 7.7 GB at BASELINE configs[3] (False keeps the padded stream: tests only)
+LG_COMPACT = True
 # A row restriction with at most this fraction of the rows runs the row-list kernels (cost
 # proportional to len(rows)); above it the full-pass kernels with a masked d are cheaper
 # (scripts/dev/time_rows.py: break-even near one half for the self sandwich, one quarter for the

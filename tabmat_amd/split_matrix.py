@@ -38,7 +38,7 @@ from .util import (
 # (profiles/r2_microbench.txt, profiles/r3_coresidency.txt).  The harnesses live in scripts/dev/overlap_step.py;
 # the product path launches its kernels in line on the current stream.)
 # row lists shorter than this share of n take the row-list form of the fused categorical x sparse term
-ROW_LIST_FRACTION_CATSPARSE = float(os.environ.get("TABMAT_AMD_ROW_LIST_CATSPARSE", "0.04"))
+ROW_LIST_FRACTION_CATSPARSE = 0.04      # (measured break-even, profiles/r3_cols_rows.txt)
 # a categorical block's diagonal as the row sum of its table with a complete partner categorical
 DIAG_FROM_PAIRS = True
 # all small categorical x categorical tables + diagonals in one launch (tm_multi_cat_pairs_*)
@@ -55,7 +55,7 @@ FULL_UNSELECTED_SHARE = 0.2
 # matvec / transpose_matvec stream all of X whatever the selection (row-major dense rows, CSR): the
 # unrestricted kernels are never slower (cfg4 shape, 2M rows, 5 % of the columns: 0.88 / 0.99 ms
 # restricted, 0.55 / 0.60 ms unrestricted + selection), so they always take this form
-FULL_THEN_SELECT_MV = float(os.environ.get("TABMAT_AMD_FULL_THEN_SELECT_MV", "0.0"))
+FULL_THEN_SELECT_MV = 0.0
 # a NARROW selection (below FULL_THEN_SELECT, at most NARROW_COLS selected dense + sparse columns -- one
 # syrk panel):
 # those columns are gathered / written out densely into one row-major block and the unrestricted
@@ -371,7 +371,7 @@ class SplitMatrix(MatrixBase):
 
     # levels that fit one LDS tile of doubles next to 32 dense / 33 sparse columns
     FUSED_LEVELS = 496
-    FUSED_CATS = int(os.environ.get("TABMAT_AMD_FUSED_CATS", "8"))
+    FUSED_CATS = 8
 
     def _cat_groups(self, cat_ids):
         """Categorical blocks whose cross terms are fused into one pass (tm_multi_cat_*): groups of
