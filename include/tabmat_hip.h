@@ -555,6 +555,20 @@ int tm_multi_cat_sparse_sandwich_rows_f64(const void *const *h_codes, const int6
                                           const int32_t *row_ranges, const int32_t *rows,
                                           int64_t n_sel, int64_t m, const double *d_sel, double *out,
                                           void *stream);
+/* The same fused categorical x sparse cross terms on the ENTRY twin of the sparse block (round 4; layout at
+ * tm_csr_dense_sandwich_ent_*): no slab-form twin is needed for a block whose sparse x dense term runs on the entry
+ * kernel.  mk = 16 * groups kernel columns; out [sum(n_cols)][mk] in kernel column order (the caller applies the
+ * twin's column permutation), overwritten.  Replaces CategoricalMatrix._cross_sparse
+ * (categorical_matrix.py:825-838, a scipy.sparse product) for all categoricals of a SplitMatrix at once. */
+int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
+                                         const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         int64_t mk, float *out, void *stream);
+int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
+                                         const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         int64_t mk, double *out, void *stream);
+
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

@@ -935,6 +935,95 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
         dst[b] = (F)tile[(b / group_cols) * tstr + (b % group_cols)];
 }
 
+// The same fused categorical x sparse cross terms on the ENTRY twin of the sparse block (round 4: the stream K3
+// walks, csrc/sparse_ent.hip / tabmat_amd/ext/_types.py::SlabEnt -- {value, row << 4 | column in group} in batches
+// of 16 slots, blocks of a 16-column group slab after slab), so that a design whose sparse x dense term runs on the
+// entry kernel needs no slab-form twin (3.4 GB at BASELINE configs[3]) for this term.  A workgroup owns TWO column
+// groups (32 kernel columns: tile [total levels][33] of doubles, as the slab kernel) over a range of slabs; its
+// waves alternate between the two groups and cut the range among themselves; lane <-> slot, 64 slots per step.
+// The d and the codes of a slot's row are gathered from global memory (rows of a (group, slab) block lie within
+// 64 rows: the lines stay in the L1 / L2); the stream of the step after next and the gathers of the next step are
+// in flight while the current one is scattered (the slab kernel's lesson: it was latency-bound, not atomic-bound).
+#ifndef EN_CS_U
+#define EN_CS_U 4
+#endif
+template <typename F, int NC>
+__global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
+    const unsigned *__restrict__ bstart, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
+    F *__restrict__ ws, int64_t stride) {
+    constexpr int GC = 32, TSTR = GC + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][33]
+    const int nel = cs.total * TSTR;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int h = wave & 1;                               // which of the pair's two groups
+    const int g = 2 * blockIdx.y + h;
+    const int nwh = (nwave + 1 - h) / 2;                  // waves on this group
+    const int wi = wave >> 1;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    if (g < n_groups && s1 > s0) {
+        const int64_t spw = (s1 - s0 + nwh - 1) / nwh;
+        const int64_t sa = min(s0 + (int64_t)wi * spw, s1), sb = min(sa + spw, s1);
+        const unsigned *brow = bstart + (int64_t)g * (n_slabs + 1);
+        const int64_t e0 = (int64_t)brow[sa] * 16, e1 = (int64_t)brow[sb] * 16;     // slots of the wave
+        // U x 64 slots per step and lane: the kernel is bound by the memory round trips of its two dependent
+        // loads (stream -> d / codes of the row), not by the atomics -- more of them in flight per wave
+        constexpr int U = EN_CS_U;
+        struct Step { F v[U]; unsigned m[U]; F dk[U]; int c[U][NC]; };
+        auto load_stream = [&](int64_t e, Step &t) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = e + 64 * u + lane < e1;
+                const int64_t i = ok ? e + 64 * u + lane : (e1 > e0 ? e1 - 1 : 0);
+                t.v[u] = ok ? vals[i] : F(0);
+                t.m[u] = meta[i];
+            }
+        };
+        auto load_rows = [&](Step &t) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned row = t.m[u] >> 4;
+                t.dk[u] = d[row];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) t.c[u][c] = cs.codes[c][row] - cs.drop[c];
+            }
+        };
+        if (e1 > e0) {
+            Step cur, nxt, nx2;
+            load_stream(e0, cur);
+            load_stream(e0 + 64 * U, nxt);
+            load_rows(cur);
+            for (int64_t e = e0; e < e1; e += 64 * U) {
+                load_stream(e + 128 * U, nx2);
+                load_rows(nxt);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // rows masked out by d == 0 (and padding slots: value 0) contribute exactly nothing
+                    const F x = (cur.dk[u] != F(0) && cur.v[u] != F(0)) ? cur.dk[u] * cur.v[u] : F(0);
+                    const int col = 16 * h + (int)(cur.m[u] & 15u);
+                    if (x != F(0)) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            if (cur.c[u][c] >= 0)
+                                atomic_add(&tile[(cs.off[c] + cur.c[u][c]) * TSTR + col], (lds_acc_t)x);
+                    }
+                }
+                cur = nxt;
+                nxt = nx2;
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < cs.total * GC; b += blockDim.x)
+        dst[b] = (F)tile[(b / GC) * TSTR + (b % GC)];
+}
+
 // Row-list form of the fused categorical x sparse cross terms (the reference's cost for `rows=` is
 // proportional to len(rows): categorical_matrix.py:825-838 works on self[rows]): the selected rows'
 // entry lists come from the chunk-major twin through a {start, end} table [chunk][selected row]
@@ -1233,6 +1322,68 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     return TM_OK;
 }
 
+// entry-twin form (see multi_cat_sparse_ent_kernel): out [total levels][mk], mk = 16 * groups kernel columns
+template <typename F>
+static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
+                                    int n_cats, int64_t n, const F *d, const F *vals, const unsigned *meta,
+                                    const unsigned *bstart, int64_t mk, F *out, hipStream_t st) {
+    CatSet cs;
+    int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
+    if (rc) return rc;
+    const int64_t total = (int64_t)cs.total * mk;
+    if (total == 0) return TM_OK;
+    if (n == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    TM_REQUIRE(mk % 16 == 0 && n_cats >= 1 && n_cats <= 8, "kernel columns in groups of 16, 1 .. 8 categoricals");
+    TM_REQUIRE(n < (1ll << 28), "at most 2^28 - 1 rows per block");
+    constexpr int GC = 32;
+    const int64_t stride = (int64_t)cs.total * GC;
+    const size_t lds = ((sizeof(lds_acc_t) * (size_t)cs.total * (GC + 1) + 15) / 16) * 16;
+    if (lds > HIST_LDS_MAX) {
+        set_error("multi_cat_sparse_ent: %d stacked categories exceed the LDS tile", cs.total);
+        return TM_EUNSUPPORTED;
+    }
+    const int nw = (int)std::min<int64_t>(16, std::max<int64_t>(4, tune("catsparse_waves", 16)));
+    const int n_groups = (int)(mk / 16);
+    const int n_pairs = (n_groups + 1) / 2;
+    const int64_t n_slabs = ceil_div(n, 64);
+    int64_t nblk = std::max<int64_t>(1, tune("catsparse_rounds", 1) * NUM_CU / n_pairs);
+    nblk = std::min<int64_t>(nblk, n_slabs);
+    const int64_t spb = ceil_div(n_slabs, nblk);
+    nblk = ceil_div(n_slabs, spb);
+    const size_t tmp_bytes = ((sizeof(F) * (size_t)(n_pairs * stride) + 255) / 256) * 256;
+    void *wsv = nullptr;
+    rc = get_workspace(tmp_bytes + sizeof(F) * (size_t)((int64_t)n_pairs * nblk * stride) + 256, &wsv, st);
+    if (rc) return rc;
+    F *tmp = reinterpret_cast<F *>(wsv);
+    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    auto kern = n_cats == 1   ? &multi_cat_sparse_ent_kernel<F, 1>
+                : n_cats == 2 ? &multi_cat_sparse_ent_kernel<F, 2>
+                : n_cats == 3 ? &multi_cat_sparse_ent_kernel<F, 3>
+                : n_cats == 4 ? &multi_cat_sparse_ent_kernel<F, 4>
+                : n_cats == 5 ? &multi_cat_sparse_ent_kernel<F, 5>
+                : n_cats == 6 ? &multi_cat_sparse_ent_kernel<F, 6>
+                : n_cats == 7 ? &multi_cat_sparse_ent_kernel<F, 7>
+                              : &multi_cat_sparse_ent_kernel<F, 8>;
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds, st, cs, d, vals, meta,
+                       bstart, n_groups, n_slabs, spb, ws, stride);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_pairs, tmp, (int64_t)n_pairs * stride, false, st);
+    if (rc) return rc;
+    // tmp [pair][total][32] -> out[total][mk]
+    hipLaunchKernelGGL((multi_cat_untile_kernel<F>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, tmp,
+                       (int64_t)cs.total, mk, GC, out);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
 }  // namespace tmh
 
 using namespace tmh;
@@ -1378,6 +1529,20 @@ int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64
                                          void *stream) {
     return run_multi_cat_dense<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, M, M_ncol, 0, out,
                                        as_stream(stream), rows, n_rows);
+}
+int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
+                                         const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         int64_t mk, float *out, void *stream) {
+    return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
+                                           out, as_stream(stream));
+}
+int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                         const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
+                                         const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         int64_t mk, double *out, void *stream) {
+    return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
+                                            out, as_stream(stream));
 }
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

@@ -420,6 +420,20 @@ def multi_cat_sparse_sandwich(cats, d, S: SlabCsc):
     return res
 
 
+def multi_cat_sparse_sandwich_ent(cats, d, E):
+    """The same on the ENTRY twin of the sparse block (E: SlabEnt, the stream of the sparse x dense kernel of
+    round 4): stacked [sum(n_cols) x E.m]; no slab-form twin needed."""
+    total = sum(int(c[1]) for c in cats)
+    if total == 0 or E.m == 0 or E.n == 0:
+        return D.zeros((total, E.m), E.vals.dtype)
+    res = D.out_buf((total, E.mk), E.vals.dtype)
+    codes, ncols, drop, n = _cat_args(cats)
+    D.same_float("multi_cat_sparse_sandwich_ent", E.vals, d)
+    call(f"tm_multi_cat_sparse_sandwich_ent_{D.fsuf(E.vals)}", codes, ncols, drop, n, E.n, D.p(d),
+         D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.mk, D.p(res), D.stream_ptr())
+    return res[:, E.inv]      # kernel columns -> the block's columns
+
+
 def multi_cat_sparse_sandwich_rows(cats, d, A, rows):
     """The fused categorical x sparse cross terms over a short row list: cost proportional to
     len(rows) (the reference works on self[rows], categorical_matrix.py:825-838).  A: CsrDev (its

@@ -172,10 +172,13 @@ class SparseMatrix(MatrixBase):
         columns of the dense block this one will be crossed with (SplitMatrix.to_device passes it)
         -- selects the interleaved-ELL geometry to pre-build; None builds none."""
         self._dev().chunk_major()
-        self._slab()
+        ent = None
         if dense_width is not None and dense_width > 0:
-            if dense_width <= 64 or (self._ent() is None and self._lg() is None):
+            ent = self._ent() if dense_width > 64 else None
+            if dense_width <= 64 or (ent is None and self._lg() is None):
                 self._ell(wide=dense_width > 64)
+        if ent is None:
+            self._slab()       # (categorical x sparse runs on the entry twin when there is one)
         return self
 
     @property

@@ -454,6 +454,15 @@ class SplitMatrix(MatrixBase):
             return xsplit.multi_cat_sparse_sandwich_rows(cats, d_rows, mw._dev(), rows)
         if (isinstance(mw, SparseMatrix) and total * 33 <= budget
                 and mw._dev().data.numel() > 0 and (rows is None or mw._values_finite())):
+            # on the entry twin when the sparse x dense term of this matrix runs on it anyway (a C-ordered dense
+            # block of more than 64 columns): no slab-form twin is built for the block at all
+            ent = None
+            if len(cats) <= 8 and (getattr(mw, "_entblk", None) or any(
+                    isinstance(mo, DenseMatrix) and mo.shape[1] > 64 and mo.dtype == mw.dtype
+                    for mo in self.matrices)):
+                ent = mw._ent()
+            if ent is not None:
+                return xsplit.multi_cat_sparse_sandwich_ent(cats, d_eff, ent)
             return xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
         return None
 

@@ -209,3 +209,63 @@ def test_deterministic_sparse_self_sandwich(dtype, monkeypatch):
     monkeypatch.setattr(cmod, "DETERMINISTIC", False)
     c = sm.sandwich(d)
     assert np.abs(a - c).max() / np.abs(want).max() < tol
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,levels", [(9000, 100, (7, 5)), (20_011, 512, (256, 96, 32)), (70, 16, (3,)),
+                                        (30_000, 40, (40, 30, 20, 10, 5, 4, 3, 2))])
+def test_cat_sparse_cross_terms_on_the_entry_twin(n, m, levels, dtype):
+    """tm_multi_cat_sparse_sandwich_ent_*: all categorical x sparse blocks of a SplitMatrix from one pass over the
+    entry twin, against the oracle's sandwich_cat_sparse (the reference: scipy.sparse product,
+    categorical_matrix.py:825-838); drop_first, missing codes, zero weights."""
+    from oracle import oracle as orc
+    from tabmat_amd.ext import split as xsplit
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=0.06, format="csr", random_state=rng, dtype=np.float64)
+    S.data = rng.standard_normal(S.data.shape[0])
+    S = S.astype(dtype)
+    S.sort_indices()
+    d = rng.random(n).astype(dtype)
+    d[::6] = 0
+    csr = CsrDev(torch.from_numpy(S.data.copy()).cuda(), torch.from_numpy(S.indices.astype(np.int32)).cuda(),
+                 torch.from_numpy(S.indptr.astype(np.int64)).cuda(), n, m)
+    tw = SlabEnt.from_csr(csr)
+    cats, refs = [], []
+    for k, lv in enumerate(levels):
+        codes = rng.integers(0, lv, n).astype(np.int32)
+        if k % 2:
+            codes[rng.random(n) < 0.05] = -1
+        drop = bool(k % 3 == 1)
+        cats.append((torch.from_numpy(codes).cuda(), lv - int(drop), drop))
+        refs.append(orc.sandwich_cat_sparse(codes, lv, d.astype(np.float64), S.astype(np.float64).tocsr(), None, None,
+                                            None)[int(drop):])
+    got = xsplit.multi_cat_sparse_sandwich_ent(cats, torch.from_numpy(d).cuda(), tw).cpu().numpy()
+    want = np.vstack(refs)
+    assert got.shape == want.shape
+    tol = 1e-10 if dtype == np.float64 else 3e-5
+    assert np.abs(got - want).max() / max(np.abs(want).max(), 1e-300) < tol
+
+
+@gpu
+def test_split_matrix_needs_no_slab_twin_beside_the_entry_twin():
+    """A SplitMatrix with a wide C-ordered dense block: sparse x dense AND categorical x sparse run on the entry
+    twin; the slab-form twin of the sparse block is never built (3.4 GB at BASELINE configs[3])."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(3)
+    n = 20_000
+    X = rng.standard_normal((n, 128))
+    S = sps.random(n, 200, density=0.05, format="csc", random_state=rng)
+    c1, c2 = rng.integers(0, 20, n), rng.integers(0, 7, n)
+    mat = tm.SplitMatrix([tm.DenseMatrix(X), tm.SparseMatrix(S), tm.CategoricalMatrix(c1), tm.CategoricalMatrix(c2)])
+    d = rng.random(n)
+    E = np.hstack([X, S.toarray(), np.eye(20)[c1], np.eye(7)[c2]])
+    for m2 in (mat, tm.SplitMatrix([tm.DenseMatrix(X), tm.SparseMatrix(S), tm.CategoricalMatrix(c1),
+                                    tm.CategoricalMatrix(c2)]).to_device()):
+        got = m2.sandwich(d)
+        want = E.T @ (d[:, None] * E)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-10
+        sp = m2.matrices[1]
+        assert getattr(sp, "_entblk", None) and getattr(sp, "_slabblk", None) is None
