@@ -128,8 +128,12 @@ def kernel_ops(mat, d):
                         fused.append((f"allcats_x_dense{i}", lambda mw=mw, oh=oh: xs.csr_dense_sandwich_slab(
                             oh, mw._dev(), d)))
                 elif isinstance(mw, tm.SparseMatrix):
-                    fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
-                        cats, d, mw._slab())))
+                    if getattr(mw, "_entblk", None) is not None:              # same choice as the product
+                        fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich_ent(
+                            cats, d, mw._ent())))
+                    else:
+                        fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
+                            cats, d, mw._slab())))
             # the fused kernels replace the per-pair categorical cross terms
             ops = [o for o in ops if not (("categorical" in o[0]) and ("dense" in o[0] or "sparse" in o[0])
                                           and "x" in o[0])] + fused
@@ -529,6 +533,26 @@ def main():
             finally:
                 tm.set_strict_f64(was)
 
+    # the same launch sequence replayed from a HIP graph (the form a solver's per-iteration product takes,
+    # SplitMatrix.sandwich_graph), reported beside the eager step -- never `value`
+    ms_graph = None
+    if world == 1 and not use_graph and hasattr(mat, "_sandwich_dev") and not isinstance(mat, tm.CategoricalMatrix):
+        from tabmat_amd.graph import CapturedProduct
+
+        try:
+            cap = CapturedProduct(lambda dd: mat._sandwich_dev(dd, None, None), d)
+            for _ in range(max(1, args.warmup)):
+                cap(cap._static_in)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                cap(cap._static_in)
+            torch.cuda.synchronize()
+            ms_graph = (time.perf_counter() - t1) / args.steps * 1e3
+            del cap
+        except RuntimeError as e:      # a side measurement: the eager line stands without it
+            print(f"[bench] hipgraph replay not measured: {e}", file=sys.stderr)
+
     alg_bytes = synth.algorithmic_bytes(mat)
     flops = synth.algorithmic_flops(mat) if isinstance(mat, tm.SplitMatrix) else (
         float(n_local) * p * (p + 1) if isinstance(mat, tm.DenseMatrix) else float(n_local))
@@ -627,6 +651,7 @@ def main():
             "dense_term": dense_term,
             "dense_term_handover": handovers,
             "ms_per_step_f64_only": None if ms_f64_only is None else round(ms_f64_only, 4),
+            "ms_per_step_hipgraph": None if ms_graph is None else round(ms_graph, 4),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,

@@ -12,5 +12,5 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INST
   rm -rf /tmp/pk$i
   rocprofv3 --pmc $grp -d /tmp/pk$i -o k --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic > /tmp/pk$i.log 2>&1
   echo "## group $i: $grp"
-  python $R/scripts/pmc_summary.py /tmp/pk$i 2>&1 | grep -A7 "csr_dense_ent_kernel\|csr_dense_lg_kernel\|sparse_sandwich_blocks_kernel\|syrk_i8_kernel<\|multi_cat_dense_wide_kernel"
+  python $R/scripts/pmc_summary.py /tmp/pk$i 2>&1 | grep -A7 "csr_dense_ent_kernel\|csr_dense_lg_kernel\|sparse_sandwich_blocks_kernel\|syrk_i8_kernel<\|multi_cat_dense_wide_kernel\|multi_cat_sparse_ent_kernel"
 done

@@ -1,12 +1,14 @@
-"""Average (and min / max over dispatches) of the rocprofv3 --pmc counters per tabmat kernel."""
+"""Average (and min / max over dispatches) of the rocprofv3 --pmc counters per tabmat kernel (kernels whose name
+holds `tmh::`, or the substring given as the second argument)."""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     name = r["Kernel_Name"]
-    if "tmh::" not in name:
+    tag = sys.argv[2] if len(sys.argv) > 2 else "tmh::"
+    if tag not in name:
         continue
-    key = name.split("tmh::")[1][:44]
+    key = name.split("tmh::")[1][:44] if "tmh::" in name else name[:44]
     vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in vals.items():
     print(k)

@@ -148,6 +148,14 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                 e.tb = (!FULL && (sd.q.w & KB_FLAG_REP_B)) ? (lt & 3) : lt;
                 const unsigned iA = min((unsigned)(sd.q.x - baseA) + min((unsigned)e.ta, (unsigned)max(e.nA - 1, 0)), spanA1);
                 const unsigned iB = min((unsigned)(sd.q.y - baseB) + min((unsigned)e.tb, (unsigned)max(e.nB - 1, 0)), spanB1);
+#ifdef KB_ABL_WRAP   // ablation (timing only, wrong results): every entry gather lands in a window the L2 holds
+                const unsigned iAw = iA & (unsigned)(KB_ABL_WRAP), iBw = iB & (unsigned)(KB_ABL_WRAP);
+                e.ca = ldi(indA, min(iAw, spanA1));
+                e.va = ldf(dataA, min(iAw, spanA1));
+                e.cb = ldi(indB, min(iBw, spanB1));
+                e.vb = ldf(dataB, min(iBw, spanB1));
+                return e;
+#endif
                 e.ca = ldi(indA, iA);
                 e.va = ldf(dataA, iA);
                 e.cb = ldi(indB, iB);

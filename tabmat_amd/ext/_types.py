@@ -99,12 +99,13 @@ class CsrDev:
             self._cm = cm
         return cm
 
-    def pair_blocks(self, n_wg: int = 512, nw: int = 16):
+    def pair_blocks(self, n_wg: int = 1024, nw: int = 16, cyclic: int = 4096):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
         at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
-        tile (part = I (I + 1) / 2 + J); the blocks of a tile are dealt to its workgroups in row order
-        (workgroups in proportion to the block counts, ~n_wg in all); inside a workgroup the FULL
+        tile (part = I (I + 1) / 2 + J); the blocks of a tile are dealt to its workgroups by row range (`cyclic`
+        rows per range, round-robin; 0 = one contiguous piece each; workgroups in proportion to the block counts,
+        ~n_wg in all); inside a workgroup the FULL
         blocks (both sides > 4 entries: 8 DPP steps) come first, then the HALF ones (4 steps; flag
         bits 16 / 17: the A / B side is the short one next to a long side, see csrc/sparse_blocks.hip).
         wg_tab row: {part, slot, first block, end, end of the FULL blocks, waves on the FULL list,
@@ -134,9 +135,12 @@ class CsrDev:
             # than a FULL one (55 vs 88) but takes as long -- the kernel waits for its loads -- measured
             # at 4M rows: 1.64 ms with equal weights, 1.89 ms with 49 : 88 (profiles/r3_k2_blocks.txt)
             COST_FULL, COST_HALF, NW = 1.0, 1.0, int(nw)
+            if cyclic and int((cptr[:, -1] - cptr[:, 0]).max().item()) * 8 >= 2**31 - 2**20:
+                cyclic = 0          # a workgroup's range (a whole chunk) would no longer fit 32-bit byte offsets
             # workgroups per tile in proportion to its blocks, EXACTLY n_wg in all (largest remainders): the
             # grid then runs in whole rounds of 256 -- 386 workgroups (one and a half rounds) took 5.0 ms
-            # where 256 take 4.25 and 512 take 4.04 (two rounds of half-sized workgroups balance the tail)
+            # where 256 take 4.25, 512 4.16 and 1024 4.04; with the round-robin deal of 4096-row ranges 3.99
+            # (profiles/r4_k2b.txt)
             share = [n_wg * c / max(total_blocks, 1) for c in counts]
             cap = [max(1, -(-c // 256)) if c else 0 for c in counts]         # at least 256 blocks per workgroup
             nbp = [0 if c == 0 else max(min_nb, min(int(sh), cp)) for c, sh, cp in zip(counts, share, cap)]
@@ -174,25 +178,42 @@ class CsrDev:
                     desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
                                         row, na | (nb << 8) | flags], dim=1).to(torch.int32)
                     nb_p = max(1, nbp[part])
-                    per = -(-c // nb_p)
-                    wg = torch.div(torch.arange(c, device=dev, dtype=torch.int64), per, rounding_mode="floor")
+                    if cyclic:
+                        # row ranges of `cyclic` rows dealt round-robin: every workgroup of every tile sweeps the
+                        # rows 0 -> n over the run of the kernel, so the ~5 tiles that read a chunk's entries
+                        # of the same rows do so within a few ms of each other (Infinity Cache hits)
+                        wg = torch.div(row, cyclic, rounding_mode="floor") % nb_p
+                    else:
+                        per = -(-c // nb_p)
+                        wg = torch.div(torch.arange(c, device=dev, dtype=torch.int64), per, rounding_mode="floor")
                     key = wg * 2 + (~full).to(torch.int64)
                     order = torch.sort(key, stable=True).indices          # row order kept inside a class
-                    cnts = torch.bincount(key, minlength=nb_p * 2).view(nb_p, 2).cpu().numpy()
-                    rows_h = row[torch.arange(0, c, per, device=dev)].cpu().numpy()
-                    rows_l = row[torch.clamp(torch.arange(per, c + per, per, device=dev) - 1, max=c - 1)].cpu().numpy()
+                    cnts = torch.bincount(key, minlength=nb_p * 2).view(nb_p, 2)
+                    big = torch.iinfo(torch.int64).max
+                    rows_h = torch.full((nb_p,), big, dtype=torch.int64, device=dev).scatter_reduce_(
+                        0, wg, row, "amin").cpu().numpy()
+                    rows_l = torch.zeros(nb_p, dtype=torch.int64, device=dev).scatter_reduce_(
+                        0, wg, row, "amax").cpu().numpy()
+                    cnts = cnts.cpu().numpy()
                     descs.append(desc[order])
+                    lo = off
                     for sgl in range(nb_p):
-                        lo, hi = off + sgl * per, min(off + (sgl + 1) * per, off + c)
+                        nf, nh = int(cnts[sgl][0]), int(cnts[sgl][1])
+                        hi = lo + nf + nh
                         if lo >= hi:
                             continue
-                        nf, nh = int(cnts[sgl][0]), int(cnts[sgl][1])
                         wf = NW if nh == 0 else 0 if nf == 0 else \
                             min(NW - 1, max(1, int(round(NW * nf * COST_FULL / (nf * COST_FULL + nh * COST_HALF)))))
                         tab.append((part, sgl, lo, hi, lo + nf, wf, int(rows_h[sgl]), int(rows_l[sgl])))
+                        lo = hi
                     max_nb = max(max_nb, nb_p)
                     off += c
                     del row, start, idx, a, b, na, nb, full, flags, desc, wg, key, order
+            if cyclic:
+                # rounds of 256 workgroups: every round holds a share of EVERY tile (slot-major order), so each
+                # round is one sweep over the rows by all tiles at once
+                rounds = max(1, -(-n_wg // 256))
+                tab.sort(key=lambda t: (t[1] % rounds, t[0], t[1]))
             blocks = torch.cat(descs).contiguous() if descs else torch.zeros((0, 4), dtype=torch.int32, device=dev)
             del descs
             wg_tab = torch.tensor(tab, dtype=torch.int32, device=dev).reshape(-1, 8).contiguous()
