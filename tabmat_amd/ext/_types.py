@@ -99,12 +99,12 @@ class CsrDev:
             self._cm = cm
         return cm
 
-    def pair_blocks(self, n_wg: int = 1024, nw: int = 16, cyclic: int = 4096):
+    def pair_blocks(self, n_wg: int = 0, nw: int = 16, cyclic=None):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
         at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
         tile (part = I (I + 1) / 2 + J); the blocks of a tile are dealt to its workgroups by row range (`cyclic`
-        rows per range, round-robin; 0 = one contiguous piece each; workgroups in proportion to the block counts,
+        rows per range, round-robin; 0 = one contiguous piece each; None / n_wg 0 = chosen by the list's length; workgroups in proportion to the block counts,
         ~n_wg in all); inside a workgroup the FULL
         blocks (both sides > 4 entries: 8 DPP steps) come first, then the HALF ones (4 steps; flag
         bits 16 / 17: the A / B side is the short one next to a long side, see csrc/sparse_blocks.hip).
@@ -135,6 +135,13 @@ class CsrDev:
             # than a FULL one (55 vs 88) but takes as long -- the kernel waits for its loads -- measured
             # at 4M rows: 1.64 ms with equal weights, 1.89 ms with 49 : 88 (profiles/r3_k2_blocks.txt)
             COST_FULL, COST_HALF, NW = 1.0, 1.0, int(nw)
+            # four rounds of 256 workgroups and the round-robin deal pay for long lists only (10M rows: 4.09 ->
+            # 3.96 ms; 1M rows: 0.39 -> 0.42 ms, profiles/r4_k2b.txt): below 50M blocks two rounds, contiguous pieces
+            big = total_blocks >= 50_000_000
+            if not n_wg:
+                n_wg = 1024 if big else 512
+            if cyclic is None:
+                cyclic = 4096 if big else 0
             if cyclic and int((cptr[:, -1] - cptr[:, 0]).max().item()) * 8 >= 2**31 - 2**20:
                 cyclic = 0          # a workgroup's range (a whole chunk) would no longer fit 32-bit byte offsets
             # workgroups per tile in proportion to its blocks, EXACTLY n_wg in all (largest remainders): the
@@ -182,7 +189,9 @@ class CsrDev:
                         # row ranges of `cyclic` rows dealt round-robin: every workgroup of every tile sweeps the
                         # rows 0 -> n over the run of the kernel, so the ~5 tiles that read a chunk's entries
                         # of the same rows do so within a few ms of each other (Infinity Cache hits)
-                        wg = torch.div(row, cyclic, rounding_mode="floor") % nb_p
+                        # (short matrices: at least four ranges per workgroup, or most of them would stay empty)
+                        rng_rows = max(32, min(cyclic, n // (4 * nb_p)))
+                        wg = torch.div(row, rng_rows, rounding_mode="floor") % nb_p
                     else:
                         per = -(-c // nb_p)
                         wg = torch.div(torch.arange(c, device=dev, dtype=torch.int64), per, rounding_mode="floor")

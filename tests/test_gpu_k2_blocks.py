@@ -76,3 +76,41 @@ def test_wave_knob_does_not_change_the_result(waves):
     finally:
         _lib.call("tm_tune_set", b"k2b_waves", -2**63)
     assert rel_err(got, want) < 1e-10
+
+
+@pytest.mark.parametrize("n,m,dens,n_wg,cyclic", [(20_011, 300, 0.06, 64, 128), (9_000, 512, 0.05, 1024, 4096),
+                                                  (777, 100, 0.1, 16, 32), (50_000, 256, 0.03, 256, 1000)])
+def test_round_robin_deal_of_row_ranges(n, m, dens, n_wg, cyclic):
+    """Round 4: the blocks of a tile are dealt to its workgroups in round-robin row ranges (the default above 50M
+    blocks, profiles/r4_k2b.txt); here forced on small matrices.  The table must cover every block exactly once,
+    FULL blocks first inside a workgroup, rows inside [first row, last row], and the product must not change."""
+    import tabmat_amd as tm
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(n)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng, dtype=np.float64)
+    d = rng.random(n)
+    A = tm.SparseMatrix(S)._dev()
+    ref_blocks, _, _ = A.pair_blocks()
+    n_blocks = int(ref_blocks.shape[0])
+    ref_sorted = torch.unique(ref_blocks, dim=0)
+    A._pb = None
+    blocks, tab, max_nb = A.pair_blocks(n_wg=n_wg, cyclic=cyclic)
+    assert int(blocks.shape[0]) == n_blocks and torch.equal(torch.unique(blocks, dim=0), ref_sorted)
+    t = tab.cpu().numpy()
+    b = blocks.cpu().numpy()
+    covered = np.zeros(n_blocks, dtype=np.int64)
+    for part, slot, lo, hi, fend, wf, r0, r1 in t:
+        assert 0 <= slot < max_nb and lo < hi and lo <= fend <= hi and 0 <= wf <= 16
+        covered[lo:hi] += 1
+        rows = b[lo:hi, 2]
+        assert rows.min() >= r0 and rows.max() <= r1
+        na, nb = b[lo:hi, 3] & 0xff, (b[lo:hi, 3] >> 8) & 0xff
+        full = (na > 4) & (nb > 4)
+        assert full[:fend - lo].all() and not full[fend - lo:].any()
+        assert (np.diff(rows[:fend - lo]) >= 0).all() and (np.diff(rows[fend - lo:]) >= 0).all()
+    assert (covered == 1).all()
+    got = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
+    assert rel_err(got, (S.T.multiply(d)).dot(S).toarray()) < 1e-10
+    assert np.array_equal(got, got.T)
