@@ -389,9 +389,16 @@ int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, cons
 
 /* ---- Index widths of the sparse entry points.  csr_indices are int32, csr_indptr int64 everywhere below: the
  * reference's fused integral type (ext/sparse.pyx:13-15, `win_integral` = int32 | int64) is NOT mirrored with
- * separate _i64 symbols.  A binder narrows int64 column indices on upload (each is < m, and m fits int32 for
- * every matrix this path can hold in HBM) and widens int32 row pointers; tabmat_amd/ext/_types.py does exactly
- * that (CsrDev.from_scipy), tests/test_gpu_reference_cases.py loads the golden fixture with both widths. ---- */
+ * separate _i64 symbols.  A binder narrows int64 column indices (each is < m, and m fits int32 for every matrix
+ * this path can hold in HBM) and widens int32 row pointers -- on upload (CsrDev.from_scipy) or, for arrays that
+ * already sit in HBM, with the two device-side conversions below; tests/test_gpu_reference_cases.py loads the golden fixture with both widths. ---- */
+
+/* The two conversions, on the device, for a binder that holds the other width (CsrDev.from_device_arrays):
+ *   tm_index_narrow_i64: dst[i] = (int32) src[i]; bad[0] |= 1 when some src[i] lies outside [0, limit)
+ *                        (limit <= 2^31; bad is a device int32 the caller zeroed);
+ *   tm_index_widen_i32:  dst[i] = (int64) src[i]. */
+int tm_index_narrow_i64(const int64_t *src, int64_t count, int64_t limit, int32_t *dst, int32_t *bad, void *stream);
+int tm_index_widen_i32(const int32_t *src, int64_t count, int64_t *dst, void *stream);
 
 /* out[Ci] += sum_{j in cols} X[rows[Ci], j] * v[j]      (CSR twin; v length m).
  * Replaces csr_matvec_unrestricted / csr_matvec (ext/sparse.pyx:79-140). */

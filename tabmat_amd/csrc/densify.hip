@@ -77,6 +77,42 @@ __global__ __launch_bounds__(256) void dense_gather_cols_f_kernel(
 
 using namespace tmh;
 
+// int64 -> int32 indices on the device (bad[0] |= 1 when a value lies outside [0, limit)); int32 -> int64
+__global__ void index_narrow_kernel(const int64_t *__restrict__ src, int64_t count, int64_t limit,
+                                    int32_t *__restrict__ dst, int32_t *__restrict__ bad) {
+    bool off = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = src[i];
+        off |= v < 0 || v >= limit;
+        dst[i] = (int32_t)v;
+    }
+    if (__any(off) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+__global__ void index_widen_kernel(const int32_t *__restrict__ src, int64_t count, int64_t *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (int64_t)src[i];
+}
+
+extern "C" {
+int tm_index_narrow_i64(const int64_t *src, int64_t count, int64_t limit, int32_t *dst, int32_t *bad, void *stream) {
+    using namespace tmh;
+    if (count <= 0) return TM_OK;
+    TM_REQUIRE(limit >= 0 && limit <= (1ll << 31), "index limit beyond int32");
+    hipLaunchKernelGGL(index_narrow_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(count, 256), 4096)), dim3(256), 0,
+                       as_stream(stream), src, count, limit, dst, bad);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+int tm_index_widen_i32(const int32_t *src, int64_t count, int64_t *dst, void *stream) {
+    using namespace tmh;
+    if (count <= 0) return TM_OK;
+    hipLaunchKernelGGL(index_widen_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(count, 256), 4096)), dim3(256), 0,
+                       as_stream(stream), src, count, dst);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+}  // extern "C"
+
 extern "C" {
 #define TM_DENSIFY(SUF, F)                                                                              \
     int tm_csr_densify_cols_##SUF(const F *data, const int32_t *indices, const int64_t *indptr,         \

@@ -279,6 +279,37 @@ class CsrDev:
         return CsrDev(self.data[pos], self.indices[pos], indptr, int(r.numel()), self.m)
 
     @staticmethod
+    def from_device_arrays(data, indices, indptr, shape) -> "CsrDev":
+        """CSR arrays that already live in HBM, column indices / row pointers of EITHER width (the reference's
+        `win_integral` = int32 | int64, ext/sparse.pyx:13-15): int64 column indices are narrowed and int32 row
+        pointers widened ON the device (tm_index_narrow_i64 / tm_index_widen_i32); an index outside [0, m) raises."""
+        from .. import _lib
+
+        n, m = int(shape[0]), int(shape[1])
+        if m >= 2**31 or n >= 2**31:
+            raise ValueError("sparse block dimensions must fit int32 on the device")
+        dev = data.device
+        st = D.stream_ptr()
+        if indices.dtype == torch.int64:
+            src = indices.contiguous()
+            narrow = torch.empty(src.numel(), dtype=torch.int32, device=dev)
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.call("tm_index_narrow_i64", D.p(src), src.numel(), m, D.p(narrow), D.p(bad), st)
+            if int(bad.item()):
+                raise ValueError("column index outside [0, m)")
+            indices = narrow
+        elif indices.dtype != torch.int32:
+            raise TypeError("column indices must be int32 or int64")
+        if indptr.dtype == torch.int32:
+            src = indptr.contiguous()
+            wide = torch.empty(src.numel(), dtype=torch.int64, device=dev)
+            _lib.call("tm_index_widen_i32", D.p(src), src.numel(), D.p(wide), st)
+            indptr = wide
+        elif indptr.dtype != torch.int64:
+            raise TypeError("row pointers must be int32 or int64")
+        return CsrDev(data.contiguous(), indices.contiguous(), indptr.contiguous(), n, m)
+
+    @staticmethod
     def from_scipy(csr) -> "CsrDev":
         n, m = csr.shape
         if m >= 2**31 or n >= 2**31:

@@ -60,3 +60,35 @@ def test_device_split_keeps_names():
     csr = csc_arrays_to_csr_dev(S.data, S.indices, S.indptr, S.shape)
     dev = from_csc(tm.SparseMatrix.from_device(csr), 0.1, column_names=names)
     assert dev.get_names("column") == host.get_names("column")
+
+
+@pytest.mark.parametrize("idx_dtype,ptr_dtype", [("int64", "int64"), ("int64", "int32"), ("int32", "int32")])
+def test_device_csr_arrays_of_either_index_width(idx_dtype, ptr_dtype):
+    """The reference's sparse kernels take int32 or int64 indices (`win_integral`, ext/sparse.pyx:13-15).  Device CSR
+    arrays of either width are taken without a host round trip: tm_index_narrow_i64 / tm_index_widen_i32."""
+    import torch
+    from scipy import sparse as sps
+
+    import tabmat_amd as tm
+    from tabmat_amd.ext._types import CsrDev
+
+    rng = np.random.default_rng(11)
+    S = sps.random(4_000, 300, density=0.05, format="csr", random_state=rng, dtype=np.float64)
+    S.sort_indices()
+    data = torch.from_numpy(S.data).cuda()
+    ind = torch.from_numpy(S.indices.astype(idx_dtype)).cuda()
+    ptr = torch.from_numpy(S.indptr.astype(ptr_dtype)).cuda()
+    sm = tm.SparseMatrix.from_device(CsrDev.from_device_arrays(data, ind, ptr, S.shape))
+    d = rng.random(4_000)
+    v = rng.random(300)
+    assert np.allclose(sm.matvec(v), S @ v, rtol=1e-12, atol=1e-12)
+    assert np.allclose(sm.transpose_matvec(d), S.T @ d, rtol=1e-12, atol=1e-12)
+    assert np.allclose(sm.sandwich(d), (S.T.multiply(d) @ S).toarray(), rtol=1e-10, atol=1e-12)
+    if idx_dtype == "int64":
+        bad = ind.clone()
+        bad[17] = 300                      # == m: outside [0, m)
+        with pytest.raises(ValueError):
+            CsrDev.from_device_arrays(data, bad, ptr, S.shape)
+        bad[17] = -1
+        with pytest.raises(ValueError):
+            CsrDev.from_device_arrays(data, bad, ptr, S.shape)
