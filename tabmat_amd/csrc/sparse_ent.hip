@@ -51,9 +51,6 @@ constexpr int EN_THREADS = EN_NW * 64;
 constexpr int EN_W = 128;           // dense columns per part
 constexpr int EN_B = 16;            // slots per batch
 constexpr int EN_SB = 64;           // slots per superbatch (lane <-> slot)
-#ifndef EN_PIECE_AT
-#define EN_PIECE_AT 0               // a wave issues its copy pieces in front of this batch of a slab
-#endif
 // (four LDS reads in flight per wave: landing slots v[48 : 63]; eight measured no faster)
 
 template <typename F>
@@ -323,7 +320,6 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #endif
     int w = 0;                         // slab being worked on (relative)
     int ncopied = 0;                   // pieces of slab w + 1 issued so far
-    int bis = 0;                       // batches of slab w worked on so far
     auto end_slab = [&]() {
         const bool more = w + 1 < ns;
         if (more) {
@@ -351,7 +347,6 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
 #endif
         EN_TICK(pt_bar)
         ncopied = 0;
-        bis = 0;
         ++w;
     };
     u4 enext = u4{0u, 0u, 0u, 0u};
@@ -368,32 +363,16 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         // superbatch has to wait for the fold)
         if (q != 3) enext = scratch[(q + 1) * EN_B + l16];
         EN_TICK(pt_a)
-#if defined(EN_DEBUG)
-        if (prof != nullptr && b == 0 && wave == 0 && blockIdx.x == 0) {
-            unsigned *o = reinterpret_cast<unsigned *>(prof) + lane * 8;
-            o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3];
-            o[4] = (unsigned)__builtin_amdgcn_readlane((int)(e[3] & 0xffu), 0);
-            o[5] = (unsigned)__builtin_amdgcn_readlane((int)(e[3] & 0xffu), 1);
-            o[6] = my; o[7] = lds_base;
-        }
-#endif
         const int slab = __builtin_amdgcn_readlane((int)e[3], 1);
         while (w < slab) end_slab();
-#if defined(EN_PIECE_SPLIT)           // half of the pieces with the first batch of a slab, half with the second
-        if (ncopied < NV && w + 1 < ns) {
-            issue_pieces((w & 1) ^ 1, ncopied, ncopied + NV / 2);
-            ncopied += NV / 2;
-            psince += NV / 2;
-            lsince = 0;
-        }
-#else
-        if (ncopied == 0 && w + 1 < ns && bis >= EN_PIECE_AT) {   // the copy of the next slab starts here
+        // the copy of the next slab starts in front of the slab's first batch (with the second / third batch, or
+        // half and half, measured no different: profiles/r4_k3_ent.txt)
+        if (ncopied == 0 && w + 1 < ns) {
             issue_pieces((w & 1) ^ 1, 0, NV);
             ncopied = NV;
             psince += NV;
             lsince = 0;
         }
-#endif
         EN_TICK(pt_p)
         F a;
         if constexpr (sizeof(F) == 8) a = __hiloint2double((int)e[1], (int)e[0]);
@@ -415,7 +394,6 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         else if (nq == 1) en_batch_asm<4, F>(p0, p1, p2, p3, a, e[2], lane_off);
 #endif
         EN_TICK(pt_x)
-        ++bis;
 #if defined(EN_PROF)
         ++pt_n;
 #endif
