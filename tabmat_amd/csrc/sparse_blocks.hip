@@ -173,6 +173,7 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                 add_pair(dpp_xor_i32<1>(kb), la, ba, av * dpp_xor<1>(vb));
                 add_pair(dpp_xor_i32<2>(kb), la, ba, av * dpp_xor<2>(vb));
                 add_pair(dpp_xor_i32<3>(kb), la, ba, av * dpp_xor<3>(vb));
+#ifndef KB_ABL_HALFSTEPS   // ablation (timing only, wrong results): FULL blocks stop after 4 of their 8 steps
                 if constexpr (FULL) {
                     const int kb4 = dpp_xor_i32<4>(kb);
                     const F vb4 = dpp_xor<4>(vb);
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                     add_pair(dpp_xor_i32<2>(kb4), la, ba, av * dpp_xor<2>(vb4));
                     add_pair(dpp_xor_i32<3>(kb4), la, ba, av * dpp_xor<3>(vb4));
                 }
+#endif
             };
             // software pipeline as in the chunked kernel: descriptors two turns ahead, entries one turn
             // ahead, two wave steps per turn, two turns per iteration with alternating registers (a ring
