@@ -1,5 +1,6 @@
 """-m gpu parity of K2b, the block-list sparse self sandwich (csrc/sparse_blocks.hip; reference:
 ext/sparse.pyx:17-77) against the oracle and the chunked kernel."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -36,6 +37,7 @@ def test_blocks_sandwich_vs_oracle(n, m, dens, dtype):
     assert rel_err(got, other) < (1e-12 if dtype == np.float64 else 1e-4)
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"), reason="the fixed-order sparse self sandwich is selected instead")
 def test_blocks_path_is_taken_by_sparse_matrix_sandwich(monkeypatch):
     import tabmat_amd as tm
     from tabmat_amd.ext import sparse as xs

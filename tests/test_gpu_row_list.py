@@ -2,6 +2,7 @@
 masked full pass): the row-list kernels of the sparse self sandwich (K2 on a row table), the sparse
 x dense term (LDS-tile row kernel) and the fused categorical x dense term against the oracle, and a
 timing assertion at 2M rows."""
+import os
 import time
 
 import numpy as np
@@ -76,6 +77,7 @@ def test_split_sandwich_with_short_row_lists(frac, dtype):
                    orc.split_sandwich(blocks, idx, d.astype(np.float64), rows, cols)) < tol
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"), reason="the fixed-order kernels are selected instead")
 def test_row_restriction_costs_what_its_rows_cost():
     """sandwich(d, rows = 10 % of n) at 2M rows must be several times faster than the full one
     (measured 3.1x at 2M rows, 3.7x at 10M; the reference's cost is O(len(rows)) too)."""

@@ -2,6 +2,7 @@
 ext/dense_helpers-tmpl.cpp:266-311): against the oracle at 1e-10 of max|out| AND entry by entry
 relative to each entry's natural scale, the device-side hand-over to the f64 kernel for weights
 outside the envelope, chunk (64 rows) / item (2048 rows) edges, columns of mixed magnitude."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -56,6 +57,7 @@ def test_i8_hand_over_for_negative_or_nonfinite_weights():
     assert not np.isfinite(out).all()               # inf propagates as in the reference
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_SYRK_I8", "1") == "0", reason="strict float64: the int8 path is switched off")
 def test_dense_matrix_takes_the_i8_path_only_inside_the_envelope(monkeypatch):
     import tabmat_amd as tm
     from tabmat_amd.ext import dense as xd
@@ -173,6 +175,7 @@ def test_i8_wide_panels_vs_oracle(n, m):
     assert np.allclose(out, out.T, rtol=0, atol=0) or float((np.abs(out - out.T) / scale).max()) < 1e-12
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_SYRK_I8", "1") == "0", reason="strict float64: the int8 path is switched off")
 def test_i8_wide_hand_over_and_dense_matrix_dispatch(monkeypatch):
     """Negative weights: every panel hands over to the f64 kernel on the device; DenseMatrix takes the wide path
     for an unrestricted 256-column float64 block and the masked-d form for a long row list."""
