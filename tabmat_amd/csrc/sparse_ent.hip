@@ -369,6 +369,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
         // half and half, measured no different: profiles/r4_k3_ent.txt)
         if (ncopied == 0 && w + 1 < ns) {
             issue_pieces((w & 1) ^ 1, 0, NV);
+
             ncopied = NV;
             psince += NV;
             lsince = 0;
