@@ -172,6 +172,10 @@ class SparseMatrix(MatrixBase):
         columns of the dense block this one will be crossed with (SplitMatrix.to_device passes it)
         -- selects the interleaved-ELL geometry to pre-build; None builds none."""
         self._dev().chunk_major()
+        if xs.blocks_sandwich_pays(self._dev()):
+            # the self sandwich's static block list: built here, not inside the first product (its builder reads
+            # per-tile counts back to the host)
+            self._dev().pair_blocks()
         ent = None
         if dense_width is not None and dense_width > 0:
             ent = self._ent() if dense_width > 64 else None

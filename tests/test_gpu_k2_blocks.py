@@ -116,3 +116,16 @@ def test_round_robin_deal_of_row_ranges(n, m, dens, n_wg, cyclic):
     got = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
     assert rel_err(got, (S.T.multiply(d)).dot(S).toarray()) < 1e-10
     assert np.array_equal(got, got.T)
+
+
+def test_to_device_builds_the_block_list_up_front():
+    """the block list's builder synchronises with the host (per-tile counts): to_device() builds it, so
+    that the first sandwich -- possibly inside a HIP-graph capture -- finds it."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(8)
+    S = sps.random(30_000, 512, density=0.05, format="csc", random_state=rng)
+    sm = tm.SparseMatrix(S)
+    assert getattr(sm._dev(), "_pb", None) is None
+    sm.to_device()
+    assert getattr(sm._dev(), "_pb", None) is not None
