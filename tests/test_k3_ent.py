@@ -124,6 +124,64 @@ def test_ent_kernel_zero_weights_and_colsum(dtype):
     _ent_vs_oracle(9000, 200, 128, 0.05, dtype, seed=6, d_zero_every=5, want_colsum=False, poison=True)
 
 
+def _structured(kind, n, m, rng):
+    """Sparsity patterns a uniform random matrix never shows."""
+    if kind == "one_full_column":              # every row has an entry in one column: blocks of 64 slots, every slab
+        S = sps.lil_matrix((n, m))
+        S[:, m // 2] = rng.standard_normal((n, 1))
+        S[rng.integers(0, n, 50), rng.integers(0, m, 50)] = 1.5
+    elif kind == "last_group_last_slab":       # entries only in the last 16-column group of the last (partial) slab
+        S = sps.lil_matrix((n, m))
+        r0 = (n - 1) // 64 * 64
+        for r in range(r0, n):
+            S[r, m - 1 - (r % min(16, m))] = float(r + 1)
+    elif kind == "banded":                     # column ~ row: consecutive slabs hit consecutive groups
+        rows = np.arange(n)
+        S = sps.csr_matrix((rng.standard_normal(3 * n), (np.repeat(rows, 3),
+                            (np.repeat(rows * m // n, 3) + np.tile([0, 1, 2], n)) % m)), shape=(n, m)).tolil()
+    elif kind == "dense_rows":                 # a few completely filled rows, the rest empty
+        S = sps.lil_matrix((n, m))
+        for r in rng.choice(n, 5, replace=False):
+            S[r, :] = rng.standard_normal((1, m))
+    else:                                      # "first_slab_only"
+        S = sps.lil_matrix((n, m))
+        S[:min(64, n), :] = rng.standard_normal((min(64, n), m))
+    S = S.tocsr()
+    S.sum_duplicates()
+    S.sort_indices()
+    return S
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["one_full_column", "last_group_last_slab", "banded", "dense_rows", "first_slab_only"])
+@pytest.mark.parametrize("n,m", [(5003, 100), (64 * 40, 512), (130, 17)])
+def test_ent_kernel_structured_patterns(kind, n, m, dtype):
+    """Blocks of exactly / more than 64 slots in every slab, groups and slabs without any entry, entries only in the
+    ragged tail: the cases the superbatch fold, the quad cut and the slab walk have branches for."""
+    from oracle import oracle as orc
+    from tabmat_amd.ext import sparse as xs
+    from tabmat_amd.ext._types import DenseDev
+
+    rng = np.random.default_rng(n + m + len(kind))
+    S = _structured(kind, n, m, rng).astype(dtype)
+    k = 128
+    B = rng.standard_normal((n, k)).astype(dtype)
+    d = rng.random(n).astype(dtype)
+    csr = CsrDev(torch.from_numpy(S.data.copy()).cuda(), torch.from_numpy(S.indices.astype(np.int32)).cuda(),
+                 torch.from_numpy(S.indptr.astype(np.int64)).cuda(), n, m)
+    tw = SlabEnt.from_csr(csr, max_pad=1e9)
+    assert tw is not None
+    out, cs = xs.csr_dense_sandwich_ent(tw, DenseDev(torch.from_numpy(B).cuda(), n, k, 0), torch.from_numpy(d).cuda(),
+                                        want_colsum=True)
+    ref = orc.csr_dense_sandwich(S.astype(np.float64).tocsr(), B.astype(np.float64), d.astype(np.float64),
+                                 None, None, None)
+    tol = 1e-10 if dtype == np.float64 else 2e-5
+    assert np.abs(out.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300) < tol
+    cref = S.astype(np.float64).T @ d.astype(np.float64)
+    assert np.abs(cs.cpu().numpy() - cref).max() / max(np.abs(cref).max(), 1e-300) < tol
+
+
 @gpu
 def test_ent_kernel_explicit_zero_values_and_empty_matrix():
     from tabmat_amd.ext import sparse as xs
