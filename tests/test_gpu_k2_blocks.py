@@ -129,3 +129,42 @@ def test_to_device_builds_the_block_list_up_front():
     assert getattr(sm._dev(), "_pb", None) is None
     sm.to_device()
     assert getattr(sm._dev(), "_pb", None) is not None
+
+
+@pytest.mark.parametrize("deal", [dict(), dict(n_wg=96, cyclic=64)])
+@pytest.mark.parametrize("kind", ["one_full_column", "dense_rows", "banded", "two_chunks_only"])
+def test_blocks_sandwich_structured_patterns(kind, deal):
+    """Patterns a uniform random matrix never shows: a column every row holds (its diagonal cell collects n pairs), a few
+    completely filled rows (4 x 4 pieces of 8 per tile and row), a band (only tiles next to the diagonal hold blocks),
+    entries in the first and last chunk only (empty tiles in between) -- with both deals of the blocks."""
+    import tabmat_amd as tm
+    from tabmat_amd import _device as D
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(len(kind))
+    n, m = 6_000, 400
+    S = sps.lil_matrix((n, m))
+    if kind == "one_full_column":
+        S[:, 130] = rng.standard_normal((n, 1))
+        S[rng.integers(0, n, 300), rng.integers(0, m, 300)] = 0.5
+    elif kind == "dense_rows":
+        for r in rng.choice(n, 7, replace=False):
+            S[r, :] = rng.standard_normal((1, m))
+    elif kind == "banded":
+        rows = np.repeat(np.arange(n), 5)
+        cols = (np.repeat(np.arange(n) * m // n, 5) + np.tile(np.arange(5) * 9, n)) % m
+        S = sps.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, m)).tolil()
+    else:
+        S[:, :20] = sps.random(n, 20, density=0.3, random_state=rng).tolil()
+        S[:, m - 20:] = sps.random(n, 20, density=0.3, random_state=rng).tolil()
+    S = sps.csc_matrix(S)
+    S.sum_duplicates()
+    d = rng.random(n)
+    d[::11] = 0
+    A = tm.SparseMatrix(S)._dev()
+    if deal:
+        A.pair_blocks(**deal)
+    got = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
+    want = (S.T.multiply(d)).dot(S).toarray()
+    assert rel_err(got, want) < 1e-10
+    assert np.array_equal(got, got.T)
