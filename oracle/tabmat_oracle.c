@@ -5,7 +5,7 @@
  * library, and only as the checker / the timed CPU baseline ("port").
  *
  * It is a plain-C (C11 + OpenMP) restatement of the reference's native loops
- * (Quantco/tabmat, src/tabmat/ext/*).  Each function cites the reference
+ * (Quantco/tabmat, src/tabmat/ext/ directory).  Each function cites the reference
  * file:line it follows; see oracle_kernels.inc.h.
  *
  * Parity status: PINNED against the reference's own known-answer tests and its
