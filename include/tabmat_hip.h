@@ -144,6 +144,26 @@ int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const do
  * MFMA (the j-panels of ext/dense_helpers-tmpl.cpp:289).  colmax: length m.  out (m, m) is overwritten. */
 int tm_dense_sandwich_i8_wide_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                   double *out, void *stream);
+/* CENTRED forms (round 5): the product of X - 1 center' -- (X - 1 c')' diag(d) (X - 1 c') and, in colsum,
+ * (X - 1 c')' d -- with the centre subtracted on the way in (K1e: before the fixed-point conversion, so the 40
+ * bits are spent on x - c; colmax[i] is then max_r |X[r][i] - center[i]|).  What StandardizedMatrix.sandwich
+ * (standardized_mat.py:123-172) needs: the reference subtracts mean-sized rank-one terms from the raw product,
+ * which amplifies any error of the product by (mean / std)^2; here those terms never form.  center: length m,
+ * indexed by the column of X (also under cols).  colsum / history may be NULL.  The generic form takes any
+ * order / rows / cols like tm_dense_sandwich_*. */
+int tm_dense_sandwich_centered_f32(const float *X, int64_t n, int64_t m, int order_f, const float *d,
+                                   const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                                   const float *center, float *out, void *stream);
+int tm_dense_sandwich_centered_f64(const double *X, int64_t n, int64_t m, int order_f, const double *d,
+                                   const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                                   const double *center, double *out, void *stream);
+int tm_dense_sandwich_co_centered_f64(const double *X, int64_t n, int64_t m, const double *d, const double *center,
+                                      double *out, double *colsum, void *stream);
+int tm_dense_sandwich_i8_centered_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                      const double *center, double *out, double *colsum, int32_t *history,
+                                      void *stream);
+int tm_dense_sandwich_i8_wide_centered_f64(const double *X, int64_t n, int64_t m, const double *d,
+                                           const double *colmax, const double *center, double *out, void *stream);
 /* The same with a per-matrix HISTORY (int32[tm_dense_sandwich_i8_history_words()] in device memory, zeroed by
  * the caller once; colsum may be NULL): [0] counts consecutive calls whose weights left the envelope after the
  * product, [1] the calls, [4 ..] hold the diagonal of the previous call's result (128 doubles).  A call whose
@@ -817,6 +837,15 @@ int tm_vec_sum_f64(const double *v, const int32_t *rows, int64_t n, double *out,
 int tm_standardize_sandwich_f64(double *inout, const double *inner_diag, const double *xtd,
                                 const double *shift, const double *mult, const double *sum_d,
                                 int64_t k, void *stream);
+/* The same result from a PARTLY CENTRED inner product (the _centered_ dense sandwiches above): column i of
+ * the inner matrix was taken as x_i - center[i] (0: as it is), xtd[i] = sum_r d_r (x_ri - center[i]);
+ * group[i] >= 0 names the block whose self term was computed centred: inout[i][j] holds the centred product
+ * where group[i] == group[j] >= 0 and the raw product elsewhere (those entries are centred here with
+ * rank-one terms).  inout[i][j] <- S'_ij mult_i mult_j + mult_i xtd_i delta_j + delta_i mult_j xtd_j
+ * + delta_i delta_j S,  delta = shift + center * mult (rounding-sized for center = -shift / mult). */
+int tm_standardize_sandwich_centered_f64(double *inout, const double *xtd, const double *center,
+                                         const int32_t *group, const double *shift, const double *mult,
+                                         const double *sum_d, int64_t k, void *stream);
 
 #ifdef __cplusplus
 }

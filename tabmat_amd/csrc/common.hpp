@@ -55,8 +55,9 @@ int64_t tune(const char *key, int64_t dflt);
 
 // K1c (syrk_co.hip): X' diag(d) X of an unrestricted C-ordered f64 block of an even number of
 // columns <= 128; colsum (may be NULL) receives X' d.  syrk_co_ok() says whether a block qualifies.
+// center (may be NULL): per-column centres c -- the product (and column sums) of X - 1 c'.
 int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out,
-                double *colsum, hipStream_t st);
+                double *colsum, hipStream_t st, const double *center = nullptr);
 inline bool syrk_co_ok(const void *X, int64_t m) {
     return m > 0 && m <= 128 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
@@ -67,7 +68,8 @@ inline bool syrk_co_pays(int64_t m) { return m > 64; }
 // K1e (syrk_i8.hip): the float64 syrk on the int8 matrix cores, for a block of <= 128 even columns or -- through
 // the row strides ldx / ldo of X / out -- for a 128-column panel of a wider block in place.
 int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, const double *colmax,
-                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st);
+                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st,
+                      const double *center = nullptr);
 
 // K1d (syrk_bf16.hip): X' diag(d) X of an unrestricted C-ordered f32 block of 4 k <= 256 columns on the
 // bf16 matrix cores (three-piece split, f32 accumulation); it pays above 128 columns.

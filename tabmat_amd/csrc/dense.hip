@@ -158,7 +158,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                                                    const int32_t *__restrict__ rows,
                                                    int64_t n_iter, int64_t rows_per_block,
                                                    const int32_t *__restrict__ cols, int n_cols,
-                                                   F *__restrict__ ws, int64_t coff0, int64_t coff1) {
+                                                   F *__restrict__ ws, int64_t coff0, int64_t coff1,
+                                                   const F *__restrict__ center) {
+    // center (may be NULL; indexed by the column of X): the columns are centred on the way into LDS, x - c: the
+    // product of X - 1 c' (what StandardizedMatrix.sandwich is after, standardized_mat.py:123-172, without
+    // subtracting mean-sized rank-one terms from the raw product).  Uniform branches: the uncentred path is
+    // the code it was.
     // coff0 / coff1 (LOAD_C_VEC only): first column of X behind the virtual columns 0..127 and
     // 128..255 -- a 128-column panel of a wider block, or the two panels of a rectangular pass,
     // read with the same 16-byte loads as a whole block (0 / 128 = the block itself)
@@ -206,8 +211,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                 if (q < C::NVEC && t < t1 && c < n_cols) {
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     // (streamed once: nontemporal, 3.68 -> 3.60 ms at cfg4)
-                    v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(
-                        X + row * m + (c < 128 ? coff0 + c : coff1 + c - 128)));
+                    const int64_t xc = c < 128 ? coff0 + c : coff1 + c - 128;
+                    v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(X + row * m + xc));
+                    if (center != nullptr) v -= *reinterpret_cast<const vec_t *>(center + xc);
                 }
 #pragma unroll
                 for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
@@ -233,6 +239,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                         for (int e = 0; e < C::VEC; ++e)
                             if (t + e < t1) v[e] = src[e];
                     }
+                    if (center != nullptr) {
+                        const F cc = center[c];
+#pragma unroll
+                        for (int e = 0; e < C::VEC; ++e)
+                            if (t + e < t1) v[e] -= cc;
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     const int64_t col = cols ? (int64_t)cols[c] : c;
                     v = X[row * m + col];
+                    if (center != nullptr) v -= center[col];
                 }
                 stage[i] = v;
             }
@@ -264,6 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     const int64_t col = cols ? (int64_t)cols[c] : c;
                     v = X[col * n + row];
+                    if (center != nullptr) v -= center[col];
                 }
                 stage[i] = v;
             }
@@ -405,7 +419,7 @@ template <typename F, int NBLK, bool RECT = false>
 static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d,
                        const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
                        const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
-                       hipStream_t st, int64_t coff0 = 0, int64_t coff1 = 128) {
+                       hipStream_t st, int64_t coff0 = 0, int64_t coff1 = 128, const F *center = nullptr) {
     using C = SyrkCfg<F, NBLK, RECT>;
     const int blocks_per_cu = (2 * C::LDS <= LDS_BYTES) ? 2 : 1;
     int64_t nblk = std::min<int64_t>((int64_t)NUM_CU * blocks_per_cu,
@@ -427,7 +441,7 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(C::THREADS), C::LDS, st, X, n, m, d,
-                           rows, n_iter, rpb, cols, n_cols, part, coff0, coff1);
+                           rows, n_iter, rpb, cols, n_cols, part, coff0, coff1, center);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
@@ -464,22 +478,22 @@ template <typename F>
 static int syrk_dispatch(const F *X, int64_t n, int64_t m, int order_f, const F *d,
                          const int32_t *rows, int64_t n_iter, const int32_t *cols, int n_cols,
                          const int32_t *pos, F *out, int64_t ldo, char *wsbase, size_t ws_off,
-                         hipStream_t st, int64_t coff0 = 0) {
+                         hipStream_t st, int64_t coff0 = 0, const F *center = nullptr) {
     if (n_cols <= 16)
         return launch_syrk<F, 1>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st, coff0, coff0 + 128);
+                                 wsbase, ws_off, st, coff0, coff0 + 128, center);
     if (n_cols <= 32)
         return launch_syrk<F, 2>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st, coff0, coff0 + 128);
+                                 wsbase, ws_off, st, coff0, coff0 + 128, center);
     if (n_cols <= 64)
         return launch_syrk<F, 4>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st, coff0, coff0 + 128);
+                                 wsbase, ws_off, st, coff0, coff0 + 128, center);
     if (n_cols <= 128)
         return launch_syrk<F, 8>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                 wsbase, ws_off, st, coff0, coff0 + 128);
+                                 wsbase, ws_off, st, coff0, coff0 + 128, center);
     if constexpr (sizeof(F) == 4) {
         return launch_syrk<F, 16>(X, n, m, order_f, d, rows, n_iter, cols, n_cols, pos, out, ldo,
-                                  wsbase, ws_off, st, coff0, coff0 + 128);
+                                  wsbase, ws_off, st, coff0, coff0 + 128, center);
     } else {
         set_error("internal: f64 syrk panel wider than 128 columns");
         return TM_EINVAL;
@@ -494,7 +508,8 @@ __global__ void iota_or_copy_i32_kernel(int32_t *dst, const int32_t *src, int32_
 template <typename F>
 static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, const F *d,
                               const int32_t *rows, int64_t n_rows, const int32_t *cols,
-                              int64_t n_cols_in, F *out, hipStream_t st) {
+                              int64_t n_cols_in, F *out, hipStream_t st, const F *center = nullptr) {
+    // center (may be NULL, length m, indexed by the column of X): the product of X - 1 center'
     const int64_t n_cols = cols ? n_cols_in : m;
     const int64_t n_iter = rows ? n_rows : n;
     if (n_cols == 0) return TM_OK;
@@ -504,20 +519,20 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     }
     TM_REQUIRE(n_cols < (1 << 20), "too many columns");
     // a handful of columns: one lane per pair of columns, no tiles (syrk_narrow.hip)
-    if (rows == nullptr && cols == nullptr && syrk_narrow_ok(m) && tune("syrk_narrow", 1))
+    if (rows == nullptr && cols == nullptr && center == nullptr && syrk_narrow_ok(m) && tune("syrk_narrow", 1))
         return run_syrk_narrow<F>(X, n, m, order_f, d, out, st);
     if constexpr (sizeof(F) == 8) {
         // unrestricted C-ordered f64 block of <= 128 columns: the LDS-light kernel with fragment
         // prefetch and dynamic work items (syrk_co.hip; 3.2-3.4 ms against 3.6-3.7 ms at cfg4)
         if (!order_f && rows == nullptr && cols == nullptr && syrk_co_ok(X, m) && syrk_co_pays(m) &&
             tune("syrk_co", 1))
-            return run_syrk_co(X, n, m, d, out, nullptr, st);
+            return run_syrk_co(X, n, m, d, out, nullptr, st, center);
     }
     if constexpr (sizeof(F) == 4) {
         // unrestricted C-ordered f32 block of 129 .. 256 columns: three-piece bf16 split on the bf16
         // matrix cores (syrk_bf16.hip; 16x the rate of the f32-input MFMA, f32 accuracy)
-        if (!order_f && rows == nullptr && cols == nullptr && m > 128 && syrk_bf16x3_ok(X, m) &&
-            tune("syrk_bf16", 1))
+        if (!order_f && rows == nullptr && cols == nullptr && center == nullptr && m > 128 &&
+            syrk_bf16x3_ok(X, m) && tune("syrk_bf16", 1))
             return run_syrk_bf16x3(X, n, m, d, out, st);
     }
     void *wsv = nullptr;
@@ -527,7 +542,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
         int rc = get_workspace(syrk_ws_bytes<F>(W), &wsv, st);
         if (rc) return rc;
         return syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, cols, (int)n_cols, nullptr, out,
-                                n_cols, reinterpret_cast<char *>(wsv), 0, st);
+                                n_cols, reinterpret_cast<char *>(wsv), 0, st, 0, center);
     }
     // wide blocks: 128-column panels.  Diagonal panels are lower-triangular syrks; every panel
     // pair (a < b) is one rectangular pass over the 256 virtual columns [panel a | panel b].
@@ -553,7 +568,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
                            (const int32_t *)nullptr, a * PW, wa);
         TM_LAUNCH_CHECK();
         rc = syrk_dispatch<F>(X, n, m, order_f, d, rows, n_iter, contiguous ? nullptr : vcols, wa, vpos,
-                              out, n_cols, base, idx_bytes, st, contiguous ? (int64_t)a * PW : 0);
+                              out, n_cols, base, idx_bytes, st, contiguous ? (int64_t)a * PW : 0, center);
         if (rc) return rc;
         for (int b = a + 1; b < np; ++b) {
             const int wb = (int)std::min<int64_t>(PW, n_cols - (int64_t)b * PW);
@@ -565,7 +580,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
             rc = launch_syrk<F, 16, true>(X, n, m, order_f, d, rows, n_iter, contiguous ? nullptr : vcols,
                                           PW + wb, vpos, out, n_cols, base, idx_bytes, st,
                                           contiguous ? (int64_t)a * PW : 0,
-                                          contiguous ? (int64_t)b * PW : 128);
+                                          contiguous ? (int64_t)b * PW : 128, center);
             if (rc) return rc;
         }
     }
@@ -577,7 +592,8 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
 // envelope check and f64 hand-over), the off-diagonal panel pairs on the rectangular f64 MFMA tile set.
 // 2M x 256: two int8 panels + one rectangle instead of three f64 passes (profiles/r4_regimes.txt).
 static int run_dense_sandwich_i8_wide(const double *X, int64_t n, int64_t m, const double *d,
-                                      const double *colmax, double *out, hipStream_t st) {
+                                      const double *colmax, double *out, hipStream_t st,
+                                      const double *center = nullptr) {
     TM_REQUIRE(m > 128 && m <= 512 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
                "a 16-byte aligned C-ordered float64 block of 130 .. 512 (even) columns");
     if (n == 0) {
@@ -589,7 +605,8 @@ static int run_dense_sandwich_i8_wide(const double *X, int64_t n, int64_t m, con
     for (int a = 0; a < np; ++a) {
         const int wa = (int)std::min<int64_t>(PW, m - (int64_t)a * PW);
         int rc = run_syrk_i8_panel(X + (int64_t)a * PW, m, n, wa, d, colmax + (int64_t)a * PW,
-                                   out + ((int64_t)a * PW) * m + (int64_t)a * PW, m, nullptr, nullptr, st);
+                                   out + ((int64_t)a * PW) * m + (int64_t)a * PW, m, nullptr, nullptr, st,
+                                   center ? center + (int64_t)a * PW : nullptr);
         if (rc) return rc;
     }
     void *wsv = nullptr;
@@ -607,7 +624,7 @@ static int run_dense_sandwich_i8_wide(const double *X, int64_t n, int64_t m, con
                                (const int32_t *)nullptr, b * PW, wb);
             TM_LAUNCH_CHECK();
             rc = launch_syrk<double, 16, true>(X, n, m, 0, d, nullptr, n, nullptr, PW + wb, vpos, out, m, base,
-                                               idx_bytes, st, (int64_t)a * PW, (int64_t)b * PW);
+                                               idx_bytes, st, (int64_t)a * PW, (int64_t)b * PW, center);
             if (rc) return rc;
         }
     }
@@ -1114,6 +1131,25 @@ extern "C" {
 int tm_dense_sandwich_i8_wide_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                   double *out, void *stream) {
     return tmh::run_dense_sandwich_i8_wide(X, n, m, d, colmax, out, tmh::as_stream(stream));
+}
+
+int tm_dense_sandwich_i8_wide_centered_f64(const double *X, int64_t n, int64_t m, const double *d,
+                                           const double *colmax, const double *center, double *out, void *stream) {
+    return tmh::run_dense_sandwich_i8_wide(X, n, m, d, colmax, out, tmh::as_stream(stream), center);
+}
+
+// (X - 1 center')[rows, cols]' diag(d[rows]) (X - 1 center')[rows, cols]; center: length m, indexed by the column of X
+int tm_dense_sandwich_centered_f32(const float *X, int64_t n, int64_t m, int order_f, const float *dv,
+                                   const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                                   const float *center, float *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_dense_sandwich<float>(X, n, m, order_f, dv, rows, n_rows, cols, n_cols, out, as_stream(stream), center);
+}
+int tm_dense_sandwich_centered_f64(const double *X, int64_t n, int64_t m, int order_f, const double *dv,
+                                   const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
+                                   const double *center, double *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_dense_sandwich<double>(X, n, m, order_f, dv, rows, n_rows, cols, n_cols, out, as_stream(stream), center);
 }
 
 #define TM_DENSE_ENTRY(NAME, F, RUN)                                                              \

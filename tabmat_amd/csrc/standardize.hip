@@ -54,6 +54,36 @@ __global__ void standardize_sandwich_kernel(double *__restrict__ out, const doub
              shift[i] * shift[j] * sum_d[0];
 }
 
+// The same result from a PARTLY CENTRED inner product (tm_dense_sandwich*_centered_*): column i of the inner
+// matrix was taken as x_i - c_i (c_i = 0: as it is), so that self[:, i] = mult_i (x_i - c_i) + delta_i with
+// delta_i = shift_i + c_i mult_i -- for the centre a standardized column has, c_i = -shift_i / mult_i, delta is
+// rounding-sized and the mean-sized rank-one terms of the reference's formula never form.
+//   xtd[i]   = sum_r d_r (x_ri - c_i)                      (centred column sums)
+//   group[i] = id of the block whose self term was computed centred (-1: none).  inner[i][j] is the centred
+//              product where group[i] == group[j] >= 0 and the RAW product sum_r d_r x_ri x_rj elsewhere (cross
+//              terms with sparse / categorical blocks, blocks without a centred kernel); those entries are
+//              centred here: S'_ij = S_ij - c_i t_j - c_j t_i + c_i c_j S with the raw t = xtd + c S.
+//   out[i][j] = S'_ij mi mj + mi xtd_i delta_j + delta_i mj xtd_j + delta_i delta_j S
+__global__ void standardize_sandwich_centered_kernel(double *__restrict__ out, const double *__restrict__ xtd,
+                                                     const double *__restrict__ center,
+                                                     const int32_t *__restrict__ group,
+                                                     const double *__restrict__ shift,
+                                                     const double *__restrict__ mult,
+                                                     const double *__restrict__ sum_d, int64_t k) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * k) return;
+    const int64_t i = e / k, j = e % k;
+    const double mi = mult ? mult[i] : 1.0, mj = mult ? mult[j] : 1.0;
+    const double ci = center[i], cj = center[j], S = sum_d[0];
+    const double di = __builtin_fma(ci, mi, shift[i]), dj = __builtin_fma(cj, mj, shift[j]);
+    double in = out[e];
+    if (!(group[i] >= 0 && group[i] == group[j])) {
+        const double ti = __builtin_fma(ci, S, xtd[i]), tj = __builtin_fma(cj, S, xtd[j]);
+        in = in - ci * tj - cj * ti + ci * cj * S;
+    }
+    out[e] = in * mi * mj + xtd[i] * mi * dj + di * xtd[j] * mj + di * dj * S;
+}
+
 template <typename F>
 static int run_vec_sum(const F *v, const int32_t *rows, int64_t n, double *out, hipStream_t st) {
     void *wsv = nullptr;
@@ -86,6 +116,16 @@ int tm_standardize_sandwich_f64(double *inout, const double *inner_diag, const d
     hipLaunchKernelGGL(tmh::standardize_sandwich_kernel, dim3((unsigned)tmh::ceil_div(k * k, 256)),
                        dim3(256), 0, tmh::as_stream(stream), inout, inner_diag, xtd, shift, mult,
                        sum_d, k);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+int tm_standardize_sandwich_centered_f64(double *inout, const double *xtd, const double *center,
+                                         const int32_t *group, const double *shift, const double *mult,
+                                         const double *sum_d, int64_t k, void *stream) {
+    if (k == 0) return TM_OK;
+    hipLaunchKernelGGL(tmh::standardize_sandwich_centered_kernel, dim3((unsigned)tmh::ceil_div(k * k, 256)),
+                       dim3(256), 0, tmh::as_stream(stream), inout, xtd, center, group, shift, mult, sum_d, k);
     TM_LAUNCH_CHECK();
     return TM_OK;
 }

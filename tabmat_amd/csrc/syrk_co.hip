@@ -68,7 +68,7 @@ __global__ __launch_bounds__(CO_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_cols,
                     const double *__restrict__ d, int n_items, unsigned *__restrict__ counter,
                     double *__restrict__ part, double *__restrict__ cpart, WgLogBuf *__restrict__ log,
-                    const unsigned *__restrict__ only_if) {
+                    const unsigned *__restrict__ only_if, const double *__restrict__ center) {
     // (only_if: the int8 syrk's hand-over -- this launch does the work only when the weights were
     // screened OUT of the int8 kernel's envelope, syrk_i8.hip)
     if (only_if != nullptr && *only_if == 0) return;
@@ -89,6 +89,12 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
 
     co_vec2 stage[3];
     double dstage = 0.0;
+    // center != NULL: the columns are centred on the way into LDS (x - c; this thread always stages the same
+    // two columns), so the product and the column sums are those of X - 1 c' (StandardizedMatrix.sandwich,
+    // standardized_mat.py:123-172, without the mean-sized cancellation)
+    co_vec2 cen = co_vec2{0.0, 0.0};
+    if (center != nullptr && (tid & 63) * 2 < n_cols)
+        cen = *reinterpret_cast<const co_vec2 *>(center + (tid & 63) * 2);
 
     // ---- the workgroup's chunk stream: items of CO_CPI chunks, ids from the atomic counter
     unsigned idL = blockIdx.x;            // item of the next chunk to load
@@ -112,8 +118,10 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
             const int r = q >> 6, c = (q & 63) * 2;
             const int64_t t = tb + r;
             co_vec2 v = co_vec2{0.0, 0.0};
-            if (t < n && c < n_cols)
+            if (t < n && c < n_cols) {
                 v = __builtin_nontemporal_load(reinterpret_cast<const co_vec2 *>(X + t * m + c));
+                if (center != nullptr) v -= cen;
+            }
             stage[i] = v;
         }
         if (++oL == CO_CPI) {             // the stream moves on to the next item
@@ -270,7 +278,7 @@ size_t syrk_co_ws_bytes() {
 // ldx / ldo: row strides (in elements) of X and out -- a 128-column panel of a wider block runs in place
 static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
                             int64_t ldo, double *colsum, const unsigned *only_if, void *ws_given,
-                            hipStream_t st) {
+                            hipStream_t st, const double *center) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m),
                "the co-resident syrk takes a 16-byte aligned C-ordered block of an even number of "
@@ -300,7 +308,7 @@ static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, 
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS));
     prof_begin(st);
     hipLaunchKernelGGL(syrk_co_kernel, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, ldx,
-                       (int)m, d, n_items, counter, part, cpart, wg_log_ptr(), only_if);
+                       (int)m, d, n_items, counter, part, cpart, wg_log_ptr(), only_if, center);
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_co_finish_kernel, dim3(CO_T, 4), dim3(64, 16), 0, st, part, grid, (int)m,
@@ -315,14 +323,15 @@ static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, 
 }
 
 int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out, double *colsum,
-                hipStream_t st) {
-    return run_syrk_co_impl(X, m, n, m, d, out, m, colsum, nullptr, nullptr, st);
+                hipStream_t st, const double *center) {
+    return run_syrk_co_impl(X, m, n, m, d, out, m, colsum, nullptr, nullptr, st, center);
 }
 
 // the same launches, live only when *flag != 0 (device memory): the int8 syrk's fallback
 int run_syrk_co_flagged(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
-                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st) {
-    return run_syrk_co_impl(X, ldx, n, m, d, out, ldo, colsum, flag, ws, st);
+                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st,
+                        const double *center) {
+    return run_syrk_co_impl(X, ldx, n, m, d, out, ldo, colsum, flag, ws, st, center);
 }
 
 }  // namespace tmh
@@ -334,6 +343,11 @@ extern "C" {
 int tm_dense_sandwich_co_f64(const double *X, int64_t n, int64_t m, const double *d, double *out,
                              double *colsum, void *stream) {
     return run_syrk_co(X, n, m, d, out, colsum, as_stream(stream));
+}
+
+int tm_dense_sandwich_co_centered_f64(const double *X, int64_t n, int64_t m, const double *d, const double *center,
+                                      double *out, double *colsum, void *stream) {
+    return run_syrk_co(X, n, m, d, out, colsum, as_stream(stream), center);
 }
 
 }  // extern "C"

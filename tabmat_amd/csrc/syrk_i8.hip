@@ -255,11 +255,17 @@ __global__ void i8_scale_kernel(const double *__restrict__ colmax, int m, int64_
 // one more v_fma_f64 per entry accumulates (x sqrt d) sqrt d per lane in f64 (exact arithmetic on the raw
 // values, independent of the fixed-point envelope); StandardizedMatrix.sandwich then needs no second pass
 // (reference: standardized_mat.py:149-150 calls transpose_matvec).
-template <bool CSUM>
+// CEN: the columns are CENTRED on the way in, y = sqrt(d) (x - center): the product is (X - 1 c')' diag(d) (X - 1 c')
+// and the column sums are (X - 1 c')' d.  StandardizedMatrix.sandwich (standardized_mat.py:123-172) subtracts
+// mean-sized rank-one terms from the raw product; slicing the centred columns instead keeps the fixed point
+// (and the f64 sums) at the scale of the RESULT -- an uncentred "year" column (2000 +- 5) would otherwise lose
+// (mean / std)^2 = 1.6e5 of the 2e-14.  One more v_add_f64 per entry in the conversion's shadow.
+template <bool CSUM, bool CEN>
 __global__ __launch_bounds__(I8_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void syrk_i8_kernel(const double *__restrict__ X, int64_t ldx, int64_t n, int64_t m, const double *__restrict__ d,
                     const double *__restrict__ sigma, const I8Info *__restrict__ info, int n_items,
-                    unsigned *__restrict__ counter, double *__restrict__ part, double *__restrict__ colsum) {
+                    unsigned *__restrict__ counter, double *__restrict__ part, double *__restrict__ colsum,
+                    const double *__restrict__ center) {
     if (info->flag != 0) return;                                          // the f64 kernel takes this call
     // SEPARATE static LDS objects: the compiler tracks LDS-DMA copies per LDS variable (alias scopes of
     // the module-LDS lowering) and makes every LDS access that may alias a copy in flight wait for it
@@ -331,6 +337,11 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t ldx, int64_t n, int64_
 
     // this lane's two columns and their scales
     const double sg0 = sigma[32 * wave + cl], sg1 = sigma[32 * wave + 16 + cl];
+    double cen0 = 0.0, cen1 = 0.0;
+    if constexpr (CEN) {
+        cen0 = 32 * wave + cl < m ? center[32 * wave + cl] : 0.0;
+        cen1 = 32 * wave + 16 + cl < m ? center[32 * wave + 16 + cl] : 0.0;
+    }
     double cs0 = 0.0, cs1 = 0.0;                                           // CSUM: this lane's share of X' d, columns cb = 0 / 1
     const double MAGIC = 6755399441055744.0 + 551911719040.0;             // 1.5 * 2^52 + 0x8080808080
     // one half chunk (ring slot rb) -> rows 32 hh .. 32 hh + 31 of the digit planes.  Per call: the
@@ -389,7 +400,9 @@ void syrk_i8_kernel(const double *__restrict__ X, int64_t ldx, int64_t n, int64_
             for (int j = 0; j < 4; ++j) c.dv[j] = dl[rb * I8_HS + row0 + j];
         } else if constexpr (k >= 1 && k <= 4) {
             const double sg = cb ? sg1 : sg0;
-            const double u = q.x[k - 1] * c.dv[k - 1];
+            double xv = q.x[k - 1];
+            if constexpr (CEN) xv -= cb ? cen1 : cen0;
+            const double u = xv * c.dv[k - 1];
             const double t = __builtin_fma(u, sg, MAGIC);
             if constexpr (CSUM) {
                 if constexpr (cb) cs1 = __builtin_fma(u, c.dv[k - 1], cs1);
@@ -764,12 +777,14 @@ __global__ void i8_record_diag_kernel(const double *__restrict__ out, int64_t ld
 
 // the f64 kernel's side of the hand-over: run_syrk_co_if(flag != 0)
 int run_syrk_co_flagged(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, double *out,
-                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st);
+                        int64_t ldo, double *colsum, const unsigned *flag, void *ws, hipStream_t st,
+                        const double *center);
 size_t syrk_co_ws_bytes();
 
 // X: first element of the block (or of a 128-column panel of a wider one), ldx / ldo: row strides of X / out
+// center (may be NULL): per-column centres c -- the product of X - 1 c' (colmax is then max |x - c| per column)
 int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const double *d, const double *colmax,
-                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st) {
+                      double *out, int64_t ldo, double *colsum, int *history, hipStream_t st, const double *center) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(ldx >= m && ldx % 2 == 0 && ldo >= m, "row strides");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m), "the int8 syrk takes a 16-byte aligned C-ordered f64 block of an "
@@ -803,12 +818,17 @@ int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const 
     hipLaunchKernelGGL(i8_scale_kernel, dim3(1), dim3(I8_W), 0, st, colmax, (int)m, n, info, sigma, rscale, history);
     TM_LAUNCH_CHECK();
     prof_begin(st);
-    if (colsum)
-        hipLaunchKernelGGL(syrk_i8_kernel<true>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, ldx, n, m, d, sigma,
-                           info, n_items, counter, part, colsum);
-    else
-        hipLaunchKernelGGL(syrk_i8_kernel<false>, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, ldx, n, m, d,
-                           sigma, info, n_items, counter, part, colsum);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(I8_THREADS), 0, st, X, ldx, n, m, d, sigma, info, n_items,
+                           counter, part, colsum, center);
+    };
+    if (center) {
+        if (colsum) go(syrk_i8_kernel<true, true>);
+        else go(syrk_i8_kernel<false, true>);
+    } else {
+        if (colsum) go(syrk_i8_kernel<true, false>);
+        else go(syrk_i8_kernel<false, false>);
+    }
     prof_end(st);
     TM_LAUNCH_CHECK();
     hipLaunchKernelGGL(syrk_i8_finish_kernel, dim3(I8_T, 4), dim3(64, 16), 0, st, part, grid, (int)m, rscale, info,
@@ -817,7 +837,7 @@ int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const 
     TM_LAUNCH_CHECK();
     // weights outside the envelope: the f64 kernel (its launches return at once when the flag is clear)
     prof_hold(true);               // (the event pair stays on the int8 kernel)
-    rc = run_syrk_co_flagged(X, ldx, n, m, d, out, ldo, colsum, &info->flag, wb + own_bytes, st);
+    rc = run_syrk_co_flagged(X, ldx, n, m, d, out, ldo, colsum, &info->flag, wb + own_bytes, st, center);
     prof_hold(false);
     if (rc == TM_OK && history != nullptr) {
         hipLaunchKernelGGL(i8_record_diag_kernel, dim3(1), dim3(I8_W), 0, st, out, ldo, (int)m, history);
@@ -827,8 +847,8 @@ int run_syrk_i8_panel(const double *X, int64_t ldx, int64_t n, int64_t m, const 
 }
 
 int run_syrk_i8(const double *X, int64_t n, int64_t m, const double *d, const double *colmax, double *out,
-                double *colsum, int *history, hipStream_t st) {
-    return run_syrk_i8_panel(X, m, n, m, d, colmax, out, m, colsum, history, st);
+                double *colsum, int *history, hipStream_t st, const double *center = nullptr) {
+    return run_syrk_i8_panel(X, m, n, m, d, colmax, out, m, colsum, history, st, center);
 }
 
 }  // namespace tmh
@@ -850,6 +870,12 @@ int tm_dense_sandwich_i8_xtd_f64(const double *X, int64_t n, int64_t m, const do
 int tm_dense_sandwich_i8_hist_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
                                   double *out, double *colsum, int32_t *history, void *stream) {
     return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, history, tmh::as_stream(stream));
+}
+
+int tm_dense_sandwich_i8_centered_f64(const double *X, int64_t n, int64_t m, const double *d, const double *colmax,
+                                      const double *center, double *out, double *colsum, int32_t *history,
+                                      void *stream) {
+    return tmh::run_syrk_i8(X, n, m, d, colmax, out, colsum, history, tmh::as_stream(stream), center);
 }
 
 }  // extern "C"

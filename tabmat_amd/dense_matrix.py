@@ -39,11 +39,12 @@ I8_MASKED_ROWS_SHARE = 0.25
 
 def set_strict_f64(flag: bool = True) -> bool:
     """strict = True: every float64 sandwich runs on the float64 MFMA / vector units.  By default the dense
-    self term of a qualifying block (C-ordered, 66..128 even columns, >= 4096 rows, finite) is computed in
+    self term of a qualifying block (C-ordered, 66..512 even columns, >= 4096 rows, finite) is computed in
     40-bit fixed point per column on the int8 matrix cores (K1e, csrc/syrk_i8.hip): entry-wise error below
     1e-10 * sqrt(S_ii S_jj) by its on-device envelope check (observed 2e-14 of max|S|), the bar BASELINE.json
-    sets -- but not IEEE float64 to the last bits, and StandardizedMatrix amplifies it by (mean / std)^2 of
-    uncentred columns.  Takes effect at the next call (no cache to clear); returns the previous setting.
+    sets -- but not IEEE float64 to the last bits.  (StandardizedMatrix.sandwich hands the kernels the column
+    centres, so the fixed point is spent on x - mean and nothing is amplified by (mean / std)^2: round 5.)
+    Takes effect at the next call (no cache to clear); returns the previous setting.
     TABMAT_AMD_SYRK_I8=0 sets strict mode at import."""
     global SYRK_I8
     old = not SYRK_I8
@@ -190,12 +191,13 @@ class DenseMatrix(MatrixBase):
         return type(self)(arr, column_names=self._colnames, term_names=self._terms)
 
     # ---- hot path -----------------------------------------------------------------------
-    def _i8_colmax(self):
+    def _i8_colmax(self, center=None):
         """max |x| per column (float64 device tensor) when the block qualifies for the int8-sliced
-        syrk (csrc/syrk_i8.hip), else None: finite float64 blocks of 66 .. 128 (even) columns.  One
-        pass over the block at first use.  The part of the envelope that depends on the weights
-        (negative / non-finite d, weights tiny exactly where a column is large) is checked on the
-        device inside every call, which then runs the f64 kernel instead."""
+        syrk (csrc/syrk_i8.hip), else None: finite float64 blocks of 66 .. 512 (even) columns.  One
+        pass over the block at first use (column maxima and minima are kept); with `center` the result is
+        max |x - center| per column (the envelope of the centred fixed point).  The part of the envelope that
+        depends on the weights (negative / non-finite d, weights tiny exactly where a column is large) is
+        checked on the device inside every call, which then runs the f64 kernel instead."""
         hit = getattr(self, "_i8_ok", None)
         if hit is None:
             hit = False
@@ -207,49 +209,75 @@ class DenseMatrix(MatrixBase):
                 x = blk.as_2d()
                 hi, lo = x.amax(dim=0), x.amin(dim=0)
                 if bool((torch.isfinite(hi) & torch.isfinite(lo)).all().item()):
-                    hit = torch.maximum(hi, -lo).contiguous()
+                    hit = (hi, lo, torch.maximum(hi, -lo).contiguous())
             self._i8_ok = hit
-        return None if hit is False else hit
+        if hit is False:
+            return None
+        if center is None:
+            return hit[2]
+        return torch.maximum(hit[0] - center, center - hit[1]).contiguous()
 
-    def _i8_history(self):
+    def _i8_history(self, key=None):
         """int32 words on the device: {consecutive envelope misses, calls, -, -, the previous call's diagonal
-        (128 doubles)} of this block's int8 syrk (tm_dense_sandwich_i8_hist_f64)."""
-        h = getattr(self, "_i8_hist", None)
+        (128 doubles)} of this block's int8 syrk (tm_dense_sandwich_i8_hist_f64).  One history per kind of
+        call (`key`: None = plain, "masked" = row-masked weights, "centered" = centred columns): the
+        previous-diagonal prediction compares like with like."""
+        hs = self.__dict__.setdefault("_i8_hist", {})
+        h = hs.get(key)
         if h is None:
             from ._lib import lib
 
-            h = self._i8_hist = torch.zeros(int(lib().tm_dense_sandwich_i8_history_words()), dtype=torch.int32,
-                                            device=self._dev_c().buf.device)
+            h = hs[key] = torch.zeros(int(lib().tm_dense_sandwich_i8_history_words()), dtype=torch.int32,
+                                      device=self._dev_c().buf.device)
         return h
 
-    def _sandwich_dev(self, d, rows, cols):
+    def _center_dev(self, center):
+        """`center` (length m: host array, device tensor or None) as a contiguous device tensor of the block's
+        dtype (None stays None)."""
+        if center is None:
+            return None
+        tdt = D.torch_dtype(self.dtype)
+        c = D.to_dev(center, tdt) if not isinstance(center, torch.Tensor) else center.to(tdt)
+        return c.contiguous()
+
+    def _sandwich_dev(self, d, rows, cols, center=None):
+        """center (device tensor over ALL columns of the block, block dtype, or None): the product of
+        X - 1 center' -- every dense syrk subtracts the centre on the way in (csrc/dense.hip, syrk_co.hip,
+        syrk_i8.hip); used by StandardizedMatrix.sandwich."""
         if (SYRK_I8 and cols is None and d.dtype == torch.float64
                 and (rows is None or D.nlen(rows) >= I8_MASKED_ROWS_SHARE * self.shape[0])):
-            cmax = self._i8_colmax()
+            cmax = self._i8_colmax(center)
             if cmax is not None:
+                key = None if center is None else "centered"
                 if rows is not None:
-                    # excluded rows get d = 0 (the block is finite: checked once in _i8_colmax), one full pass
+                    # excluded rows get d = 0 (the block is finite: checked once in _i8_colmax), one full pass;
+                    # index_add_: a row id that occurs twice counts twice, as in the reference's row loop
+                    # (dense_helpers-tmpl.cpp:224) and in the row-list kernels below the threshold
                     dm = torch.zeros_like(d)
                     r64 = rows.to(torch.int64)
-                    dm[r64] = d[r64]
+                    dm.index_add_(0, r64, d[r64])
                     d = dm
+                    key = "masked" if center is None else "masked-centered"
                 if self.shape[1] > 128:
-                    return xd.dense_sandwich_i8_wide(self._dev_c(), d, cmax)
-                return xd.dense_sandwich_i8(self._dev_c(), d, cmax, history=self._i8_history())
-        return xd.dense_sandwich(self._dev_c(), d, rows, cols)
+                    return xd.dense_sandwich_i8_wide(self._dev_c(), d, cmax, center=center)
+                return xd.dense_sandwich_i8(self._dev_c(), d, cmax, history=self._i8_history(key), center=center)
+        return xd.dense_sandwich(self._dev_c(), d, rows, cols, center=center)
 
-    def _sandwich_xtd_dev(self, d):
+    def _sandwich_xtd_dev(self, d, center=None):
         """(X' diag(d) X, X' d) of the unrestricted block in ONE pass over it, or None when no
         one-pass kernel takes the block (then the caller makes the reference's second pass,
         standardized_mat.py:149-150): the int8-sliced syrk (K1e) inside its envelope, else the f64
-        syrk with the column sums of its A-side fragments (K1c)."""
+        syrk with the column sums of its A-side fragments (K1c).  With `center` both are those of
+        X - 1 center'."""
         blk = self._dev_c()
         if SYRK_I8 and d.dtype == torch.float64 and blk.m <= 128:
-            cmax = self._i8_colmax()
+            cmax = self._i8_colmax(center)
             if cmax is not None:
-                return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True, history=self._i8_history())
+                return xd.dense_sandwich_i8(blk, d, cmax, want_colsum=True,
+                                            history=self._i8_history(None if center is None else "centered"),
+                                            center=center)
         if xd.co_supported(blk, d):
-            return xd.dense_sandwich_co(blk, d, want_colsum=True)
+            return xd.dense_sandwich_co(blk, d, want_colsum=True, center=center)
         return None
 
     def sandwich(self, d, rows=None, cols=None):

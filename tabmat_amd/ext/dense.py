@@ -6,14 +6,22 @@ from .._lib import call
 from ._types import DenseDev
 
 
-def dense_sandwich(X: DenseDev, d, rows, cols):
-    """ext/dense.pyx:19-44.  rows/cols: int32 device tensors or None (= all)."""
+def dense_sandwich(X: DenseDev, d, rows, cols, center=None):
+    """ext/dense.pyx:19-44.  rows/cols: int32 device tensors or None (= all).
+    center (device tensor of the block's dtype, length X.m, or None): the product of X - 1 center'
+    (tm_dense_sandwich_centered_*: the columns are centred on the way in)."""
     out_m = X.m if cols is None else D.nlen(cols)
     in_n = X.n if rows is None else D.nlen(rows)
     if in_n == 0 or out_m == 0:  # ext/dense.pyx:26-27
         return D.zeros((out_m, out_m), X.dtype)
     out = D.out_buf((out_m, out_m), X.dtype)
     D.same_float("dense_sandwich", X.buf, d)
+    if center is not None:
+        D.same_float("dense_sandwich", X.buf, center)
+        assert center.numel() == X.m and center.is_contiguous()
+        call(f"tm_dense_sandwich_centered_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(d), D.p(rows),
+             D.nlen(rows), D.p(cols), D.nlen(cols), D.p(center), D.p(out), D.stream_ptr())
+        return out
     call(f"tm_dense_sandwich_{D.fsuf(X.buf)}", D.p(X.buf), X.n, X.m, X.order_f, D.p(d), D.p(rows),
          D.nlen(rows), D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -82,16 +90,23 @@ def dense_gather_cols(X: DenseDev, cols, T, t0: int):
          D.nlen(cols), D.p(T), T.shape[1], int(t0), D.stream_ptr())
 
 
-def dense_sandwich_co(X: DenseDev, d, want_colsum=False):
+def dense_sandwich_co(X: DenseDev, d, want_colsum=False, center=None):
     """X' diag(d) X of an unrestricted C-ordered float64 block of an even number of columns
     <= 128 with the kernel that is sized to share its compute units with a partner running on
     another stream (tm_dense_sandwich_co_f64; reference: the dense term of
-    split_matrix.py:337-354).  Returns out, or (out, X' d) with want_colsum."""
+    split_matrix.py:337-354).  Returns out, or (out, X' d) with want_colsum.  center (float64 device
+    tensor, length X.m): product and column sums of X - 1 center' (tm_dense_sandwich_co_centered_f64)."""
     import torch
 
     out = D.out_buf((X.m, X.m), torch.float64)
     cs = D.out_buf((X.m,), torch.float64) if want_colsum else None
     D.same_float("dense_sandwich_co", X.buf, d, out)
+    if center is not None:
+        D.same_float("dense_sandwich_co", X.buf, center)
+        assert center.numel() == X.m and center.is_contiguous()
+        call("tm_dense_sandwich_co_centered_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(center), D.p(out), D.p(cs),
+             D.stream_ptr())
+        return (out, cs) if want_colsum else out
     call("tm_dense_sandwich_co_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(out), D.p(cs), D.stream_ptr())
     return (out, cs) if want_colsum else out
 
@@ -119,19 +134,32 @@ def dense_sandwich_bf16x3(X: DenseDev, d):
     return out
 
 
-def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False, history=None):
+def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False, history=None, center=None):
     """X' diag(d) X of an unrestricted C-ordered float64 block of an even number of columns <= 128 on
     the int8 matrix cores (tm_dense_sandwich_i8_f64: 40-bit fixed point per column, five base-256
     digits, 22 exact int8 digit-pair products).  colmax: float64 device tensor of max |x| per column.
     Weights outside the envelope (negative, non-finite, tiny exactly where a column is large) make
     the call run the f64 kernel instead (checked on the device).  want_colsum: also X' d from the
-    same pass -> (out, colsum).  history: int32 device tensor [2] kept per matrix
-    (tm_dense_sandwich_i8_hist_f64: after three misses in a row the int8 attempt is skipped)."""
+    same pass -> (out, colsum).  history: int32 device tensor of tm_dense_sandwich_i8_history_words() words
+    kept per matrix (tm_dense_sandwich_i8_hist_f64: {misses in a row, calls, -, -, the previous diagonal as
+    128 doubles}; after three misses in a row the int8 attempt is skipped).  center (float64 device tensor,
+    length X.m): product and column sums of X - 1 center', the centre subtracted BEFORE the fixed-point
+    conversion (tm_dense_sandwich_i8_centered_f64; colmax is then max |x - center| per column)."""
     import torch
+    from .._lib import lib
 
     out = D.out_buf((X.m, X.m), torch.float64)
     D.same_float("dense_sandwich_i8", X.buf, d, colmax)
     cs = D.out_buf((X.m,), torch.float64) if want_colsum else None
+    if history is not None and history.numel() < int(lib().tm_dense_sandwich_i8_history_words()):
+        # (the C ABI takes no length: a short buffer would be a silent out-of-bounds device write)
+        raise ValueError("history needs tm_dense_sandwich_i8_history_words() int32 words")
+    if center is not None:
+        D.same_float("dense_sandwich_i8", X.buf, center)
+        assert center.numel() == X.m and center.is_contiguous()
+        call("tm_dense_sandwich_i8_centered_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(center),
+             D.p(out), D.p(cs), D.p(history), D.stream_ptr())
+        return (out, cs) if want_colsum else out
     if history is not None:
         call("tm_dense_sandwich_i8_hist_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.p(cs),
              D.p(history), D.stream_ptr())
@@ -144,7 +172,7 @@ def dense_sandwich_i8(X: DenseDev, d, colmax, want_colsum=False, history=None):
     return out
 
 
-def dense_sandwich_i8_wide(X: DenseDev, d, colmax):
+def dense_sandwich_i8_wide(X: DenseDev, d, colmax, center=None):
     """X' diag(d) X of an unrestricted C-ordered float64 block of 130 .. 512 (even) columns: the diagonal
     128-column panels on the int8 matrix cores in place, the off-diagonal panel pairs on the f64 MFMA
     (tm_dense_sandwich_i8_wide_f64; reference: the j-panels of ext/dense_helpers-tmpl.cpp:289)."""
@@ -152,5 +180,11 @@ def dense_sandwich_i8_wide(X: DenseDev, d, colmax):
 
     out = D.out_buf((X.m, X.m), torch.float64)
     D.same_float("dense_sandwich_i8_wide", X.buf, d, colmax)
+    if center is not None:
+        D.same_float("dense_sandwich_i8_wide", X.buf, center)
+        assert center.numel() == X.m and center.is_contiguous()
+        call("tm_dense_sandwich_i8_wide_centered_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(center),
+             D.p(out), D.stream_ptr())
+        return out
     call("tm_dense_sandwich_i8_wide_f64", D.p(X.buf), X.n, X.m, D.p(d), D.p(colmax), D.p(out), D.stream_ptr())
     return out

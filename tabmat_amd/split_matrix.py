@@ -69,6 +69,27 @@ from . import categorical_matrix as _cm
 from . import sparse_matrix as _spm      # PART_NNZ lives there (also used by SparseMatrix itself)
 
 
+class _Centering:
+    """Column centres of a CENTRED sandwich (StandardizedMatrix.sandwich, standardized_mat.py:123-172): vec[b] =
+    device tensor over ALL columns of dense block b (block dtype).  The self term of such a block is computed
+    as (X_b - 1 c')' D (X_b - 1 c') by the dense kernels (the centre is subtracted on the way in); every other
+    block product stays raw and is centred afterwards with rank-one terms (tm_standardize_sandwich_centered_f64).
+    cs_centered collects the blocks whose column sums came out of a centred kernel ((X_b - 1 c')' d).
+    groups: None = the entries computed centred are exactly the self terms of the blocks in vec; the narrow
+    column-selection path (which computes dense AND sparse columns as one dense block, so their cross entries
+    come out centred too) leaves an int32 device vector over the RESULT's columns here instead: entries (i, j)
+    with groups[i] == groups[j] >= 0 are centred, all others raw."""
+    NARROW_GROUP = 1 << 20
+
+    def __init__(self, vec):
+        self.vec = dict(vec)
+        self.cs_centered = set()
+        self.groups = None
+
+    def get(self, b):
+        return self.vec.get(b)
+
+
 def as_tabmat(a):
     """split_matrix.py:22-37."""
     if isinstance(a, (MatrixBase, StandardizedMatrix)):
@@ -343,18 +364,22 @@ class SplitMatrix(MatrixBase):
         self.__dict__["_pos_sel"] = (key, t)
         return t
 
-    def _sandwich_xtd_dev(self, d, rows, cols_host):
+    def _sandwich_xtd_dev(self, d, rows, cols_host, center=None):
         """(X' diag(d) X, X' d) restricted to rows / cols, both float64 on the device, from ONE
         pass over the blocks where the algebra allows it (what StandardizedMatrix.sandwich needs,
         standardized_mat.py:148-150, which makes two passes): the column sums of a categorical
         block are the diagonal of its own sandwich, and for any other block B they are the sums
         over the levels of its cross term with a COMPLETE categorical C (no dropped level, no
         missing codes: every row of C has exactly one 1, so C 1 = 1 and B' D 1 = (B' D C) 1).
-        Blocks without such a partner get their own transpose_matvec launch."""
+        Blocks without such a partner get their own transpose_matvec launch.
+        center (_Centering or None): the dense blocks it names enter their self term centred; two more results
+        then: a bool device vector, True where xtd holds the CENTRED column sum (X - 1 c')' d, and the groups
+        vector of _Centering (None: the default -- the centred entries are the named blocks' self terms)."""
         colsum = [None] * len(self.matrices)
-        out = self._sandwich_dev(d, rows, cols_host, colsum=colsum)
+        out = self._sandwich_dev(d, rows, cols_host, colsum=colsum, center=center)
         pos_d, sub_d, n_cols = self._sandwich_plan(cols_host)
         xtd = D.zeros((n_cols,), torch.float64)
+        cmask = None if center is None else torch.zeros((n_cols,), dtype=torch.bool, device=xtd.device)
         for i, (mi, pd, sd) in enumerate(zip(self.matrices, pos_d, sub_d)):
             if sd is not None and D.nlen(sd) == 0:
                 continue
@@ -366,7 +391,11 @@ class SplitMatrix(MatrixBase):
                     cs = full if sd is None else full[sd.to(torch.int64)]
                 else:
                     cs = mi._matvec_dev(d, rows, sd, None, True)
+            elif center is not None and i in center.cs_centered:
+                cmask[pd] = True
             xtd[pd] = cs.to(torch.float64)
+        if center is not None:
+            return out, xtd, cmask, center.groups
         return out, xtd
 
     # levels that fit one LDS tile of doubles next to 32 dense / 33 sparse columns
@@ -494,8 +523,9 @@ class SplitMatrix(MatrixBase):
             self.__dict__["_row_parts"] = parts
         return parts
 
-    def _sandwich_parts(self, parts, d, rows, cols_host, colsum):
-        """Sum of the parts' sandwiches (and of their column sums)."""
+    def _sandwich_parts(self, parts, d, rows, cols_host, colsum, center=None):
+        """Sum of the parts' sandwiches (and of their column sums; with `center` the column sums of the centred
+        blocks are handed on RAW: a part's centred sum + centre * the part's sum of weights)."""
         out = None
         for a, b, part in parts:
             r = None
@@ -506,7 +536,19 @@ class SplitMatrix(MatrixBase):
                     continue
                 r = (sel - a).to(torch.int32)
             cs = [None] * len(self.matrices) if colsum is not None else None
-            res = part._sandwich_dev(d[a:b], r, cols_host, None, cs)
+            sub_cen = None if center is None else _Centering(center.vec)
+            res = part._sandwich_dev(d[a:b], r, cols_host, None, cs, center=sub_cen)
+            if sub_cen is not None:
+                center.groups = sub_cen.groups          # (the same path in every part: same selection)
+            if sub_cen is not None and colsum is not None:
+                dsum = (d[a:b] if r is None else d[a:b][r.to(torch.int64)]).sum(dtype=torch.float64)
+                _, sub_p, _ = self._sandwich_plan(cols_host)
+                for i in sub_cen.cs_centered:
+                    if cs[i] is not None:
+                        cv = sub_cen.get(i).to(torch.float64)
+                        if sub_p[i] is not None:
+                            cv = cv[sub_p[i].to(torch.int64)]
+                        cs[i] = cs[i].to(torch.float64) + cv * dsum
             out = res if out is None else out + res
             if colsum is not None:
                 for i, c in enumerate(cs):
@@ -613,7 +655,7 @@ class SplitMatrix(MatrixBase):
         self.__dict__["_narrow_cache"] = (key, nar)
         return nar
 
-    def _sandwich_narrow(self, nar, d, rows, colsum):
+    def _sandwich_narrow(self, nar, d, rows, colsum, center=None):
         """The sandwich under a narrow column selection: the selected dense / sparse columns as one
         dense block T, the unrestricted product of [T | categorical blocks], the selected rows and
         columns of that (small) result."""
@@ -635,31 +677,48 @@ class SplitMatrix(MatrixBase):
                                            nar["indices"])
         dm = tmp.matrices[0]
         dm._devblk = DenseDev(T, n, nar["w_pad"], 0)
+        sub_cen = None
+        if center is not None:
+            # the centres of the selected dense columns, 0 for the written-out sparse columns and the padding
+            tc = torch.zeros((nar["w_pad"],), dtype=d.dtype, device=d.device)
+            for b, t0, s, idx in nar["parts"]:
+                if center.get(b) is not None:
+                    tc[t0:t0 + s] = center.get(b)[idx.to(torch.int64)]
+            sub_cen = _Centering({0: tc})
         try:
             cs_tmp = [None] * len(tmp.matrices) if colsum is not None else None
-            full = tmp._sandwich_dev(d, rows, None, None, cs_tmp)
+            full = tmp._sandwich_dev(d, rows, None, None, cs_tmp, center=sub_cen)
         finally:
             dm._devblk = None                 # T is released with this call
         if colsum is not None:
             if cs_tmp[0] is not None:
                 for b, t0, s, _ in nar["parts"]:
                     colsum[b] = cs_tmp[0][t0:t0 + s]
+                    if sub_cen is not None and 0 in sub_cen.cs_centered:
+                        center.cs_centered.add(b)
+        if center is not None:
+            # every entry between two columns of T came out of T's centred self term
+            g = torch.full_like(nar["sel"], -1, dtype=torch.int32)
+            g[nar["sel"] < nar["w_pad"]] = _Centering.NARROW_GROUP
+            center.groups = g
             for k, i in enumerate(nar["cat"]):
                 if cs_tmp[1 + k] is not None and i in nar["cat_sub"]:
                     colsum[i] = cs_tmp[1 + k][nar["cat_sub"][i]]
         sel = nar["sel"]
         return full.index_select(0, sel).index_select(1, sel)
 
-    def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None):
+    def _sandwich_dev(self, d, rows, cols_host, plan=None, colsum=None, center=None):
         """d: device tensor; rows: int32 device tensor or None; cols_host: host list or None.
         Returns the float64 (n_cols, n_cols) device result (split_matrix.py:324-356).
         colsum: optional list (one slot per block) that receives X_block' d[rows] (restricted to
-        the block's columns) wherever it falls out of the sandwich for free."""
+        the block's columns) wherever it falls out of the sandwich for free.
+        center (_Centering or None): dense blocks whose SELF term is computed centred (the cross terms stay
+        raw); it also records which column sums are centred."""
         if cols_host is not None and len(cols_host) >= FULL_THEN_SELECT * self.shape[1] \
                 and len(cols_host) > 0 and self._full_product_pays_cols(cols_host):
             pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
             cs_full = [None] * len(self.matrices) if colsum is not None else None
-            full = self._sandwich_dev(d, rows, None, None, cs_full)
+            full = self._sandwich_dev(d, rows, None, None, cs_full, center=center)
             if colsum is not None:
                 for i, c in enumerate(cs_full):
                     if c is not None:
@@ -668,7 +727,7 @@ class SplitMatrix(MatrixBase):
             return full.index_select(0, cd).index_select(1, cd)
         parts = self._parts()
         if parts is not None:
-            return self._sandwich_parts(parts, d, rows, cols_host, colsum)
+            return self._sandwich_parts(parts, d, rows, cols_host, colsum, center)
         if cols_host is not None and plan is None and NARROW_COLS > 0:
             nar = self._narrow_plan(cols_host)
             if nar == "wide":
@@ -677,7 +736,7 @@ class SplitMatrix(MatrixBase):
                 # vs 3.5 ms at 2M rows, profiles/r3_cols_rows.txt) -- the tuned unrestricted
                 # product + selection is never slower, so the cost is monotone in the selection
                 cs_full = [None] * len(self.matrices) if colsum is not None else None
-                full = self._sandwich_dev(d, rows, None, None, cs_full)
+                full = self._sandwich_dev(d, rows, None, None, cs_full, center=center)
                 if colsum is not None:
                     _, sub_sel, _ = self._sandwich_plan(cols_host)
                     for i, c in enumerate(cs_full):
@@ -686,15 +745,15 @@ class SplitMatrix(MatrixBase):
                 cd = self._cols_dev64(cols_host)
                 return full.index_select(0, cd).index_select(1, cd)
             if nar is not None and d.dtype == D.torch_dtype(self.dtype):
-                return self._sandwich_narrow(nar, d, rows, colsum)
+                return self._sandwich_narrow(nar, d, rows, colsum, center)
         pos_d, sub_d, n_cols = plan if plan is not None else self._sandwich_plan(cols_host)
         out = D.zeros((n_cols, n_cols), torch.float64)
         mats = self.matrices
         empty = [sd is not None and D.nlen(sd) == 0 for sd in sub_d]
         done = set()
-        return self._sandwich_terms(d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done)
+        return self._sandwich_terms(d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done, center)
 
-    def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done):
+    def _sandwich_terms(self, d, rows, cols_host, colsum, out, pos_d, sub_d, empty, done, center=None):
         """The block products of one sandwich, in line on the current stream."""
         from .ext import dense as xd
 
@@ -797,9 +856,14 @@ class SplitMatrix(MatrixBase):
                     xsplit.scatter_block(diag, pos_d[i], pos_d[i], out, diag=True)
             elif (colsum is not None and colsum[i] is None and isinstance(mi, DenseMatrix)
                   and rows is None and sub_d[i] is None
-                  and (both := mi._sandwich_xtd_dev(d)) is not None):
+                  and (both := mi._sandwich_xtd_dev(d, cen_i := (center.get(i) if center else None))) is not None):
                 # X_dense' d comes out of the syrk's own pass (csrc/syrk_i8.hip, csrc/syrk_co.hip)
                 res, colsum[i] = both
+                if cen_i is not None:
+                    center.cs_centered.add(i)
+                xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
+            elif isinstance(mi, DenseMatrix) and center is not None and center.get(i) is not None:
+                res = mi._sandwich_dev(d, rows, sub_d[i], center=center.get(i))
                 xsplit.scatter_block(res, pos_d[i], pos_d[i], out)
             else:
                 res = mi._sandwich_dev(d, rows, sub_d[i])

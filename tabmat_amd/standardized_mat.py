@@ -107,33 +107,95 @@ class StandardizedMatrix:
         mult = None if self.mult is None else [self.mult[i]]
         return StandardizedMatrix(self.mat.getcol(i), [self.shift[i]], mult)
 
-    def _inner_xtd_dev(self, d, rows_d, cols_n):
-        """(inner sandwich or None, its diagonal or None, mat' d) as float64 device tensors."""
-        from .categorical_matrix import CategoricalMatrix
+    # Centred inner products (round 5).  self[:, j] = mult_j x_j + shift_j = mult_j (x_j - c_j) + delta_j with
+    # c_j = -shift_j / mult_j: for a standardized column c_j is its mean and delta_j is rounding-sized.  The
+    # reference (standardized_mat.py:148-171) forms the RAW product X' D X and subtracts mean-sized rank-one
+    # terms, which amplifies whatever error the product has by (mean / std)^2 -- 1.6e5 for a "year" column,
+    # 1e8 for an id-like one; with the int8-sliced dense term (2e-14 of the raw scale) that is outside
+    # BASELINE's 1e-10.  Here the dense kernels take the centres and compute (X - 1 c')' D (X - 1 c') directly
+    # (the fixed point / the f64 sums see x - c), and only the cross terms with sparse / categorical blocks
+    # carry first-order (mean / std) terms.
+    CENTER_DENSE = True
+
+    def _centering(self):
+        """(c over all p columns as a float64 device tensor, group int32 device tensor [-1 = not centred],
+        {block: centre over the block's columns}) or None when there is nothing to centre: float64 matrices
+        only (the contract is the float64 1e-10), dense blocks only (sparse / categorical columns stay as they
+        are: centring would densify them)."""
+        hit = self._dev_cache.get("centering", False)
+        if hit is not False:
+            return hit
+        from .dense_matrix import DenseMatrix
         from .split_matrix import SplitMatrix
+
+        res = None
+        mat = self.mat
+        if self.CENTER_DENSE and np.dtype(self.dtype) == np.float64:
+            if isinstance(mat, SplitMatrix):
+                blocks = [(b, mb, idx) for b, (mb, idx) in enumerate(zip(mat.matrices, mat.indices))
+                          if isinstance(mb, DenseMatrix) and mb.dtype == np.float64]
+            elif isinstance(mat, DenseMatrix):
+                blocks = [(0, mat, np.arange(self.shape[1]))]
+            else:
+                blocks = []
+            p = self.shape[1]
+            c = np.zeros(p)
+            grp = np.full(p, -1, dtype=np.int32)
+            with np.errstate(all="ignore"):
+                c_all = -self.shift if self.mult is None else -self.shift / self.mult
+            c_all = np.where(np.isfinite(c_all), c_all, 0.0)
+            vec = {}
+            for b, mb, idx in blocks:
+                cb = c_all[idx]
+                if np.any(cb != 0.0):
+                    c[idx] = cb
+                    grp[idx] = b
+                    vec[b] = D.to_dev(np.ascontiguousarray(cb), torch.float64)
+            if vec:
+                res = (D.to_dev(c, torch.float64), D.to_dev(grp), vec)
+        self._dev_cache["centering"] = res
+        return res
+
+    def _inner_xtd_dev(self, d, rows_d, cols_n, cen=None):
+        """(inner sandwich or None, its diagonal or None, mat' d, centred-mask or None, groups or None) as device
+        tensors.  cen: the result of _centering(): the dense self terms come out centred, the mask says
+        which entries of mat' d are centred column sums, groups (when not None) replaces the per-block group
+        vector (split_matrix._Centering)."""
+        from .categorical_matrix import CategoricalMatrix
+        from .split_matrix import SplitMatrix, _Centering
 
         mat = self.mat
         if isinstance(mat, SplitMatrix):
+            if cen is not None:
+                inner, xtd, cmask, grp = mat._sandwich_xtd_dev(d, rows_d, cols_n, center=_Centering(cen[2]))
+                return inner, None, xtd, cmask, grp
             inner, xtd = mat._sandwich_xtd_dev(d, rows_d, cols_n)
-            return inner, None, xtd
+            return inner, None, xtd, None, None
         cols_d = D.idx_dev(cols_n)
         if isinstance(mat, CategoricalMatrix):
             diag = mat._sandwich_diag_dev(d, rows_d, cols_d).to(torch.float64)
-            return None, diag, diag           # one-hot entries are 0 / 1: C' d = diag(C' D C)
+            return None, diag, diag, None, None     # one-hot entries are 0 / 1: C' d = diag(C' D C)
         from .dense_matrix import DenseMatrix
-        from .ext import dense as xd
 
+        cvec = None if cen is None else cen[2][0]
         if isinstance(mat, DenseMatrix) and rows_d is None and cols_d is None:
-            both = mat._sandwich_xtd_dev(d)                                       # one pass
+            both = mat._sandwich_xtd_dev(d, cvec)                                  # one pass
             if both is not None:
-                return both[0], None, both[1]
-        inner = mat._sandwich_dev(d, rows_d, cols_d).to(torch.float64)
+                cm = None if cvec is None else torch.ones_like(both[1], dtype=torch.bool)
+                return both[0], None, both[1], cm, None
+        if isinstance(mat, DenseMatrix) and cvec is not None:
+            inner = mat._sandwich_dev(d, rows_d, cols_d, center=cvec).to(torch.float64)
+        else:
+            inner = mat._sandwich_dev(d, rows_d, cols_d).to(torch.float64)
         xtd = mat._matvec_dev(d, rows_d, cols_d, None, True).to(torch.float64)
-        return inner, None, xtd
+        cm = None if cvec is None else torch.zeros_like(xtd, dtype=torch.bool)
+        return inner, None, xtd, cm, None
 
     def sandwich(self, d, rows=None, cols=None):
         """Inner sandwich + rank-one corrections (standardized_mat.py:123-172), float64.
-        d: numpy array (numpy result) or torch cuda tensor (device result)."""
+        d: numpy array (numpy result) or torch cuda tensor (device result).
+        float64 matrices with dense blocks: the dense self terms are computed CENTRED (see _centering),
+        so the result keeps the accuracy of the product at the scale of the standardized columns."""
         on_dev = D.is_dev(d)
         if not on_dev and not hasattr(d, "dtype"):
             d = np.asarray(d)
@@ -146,7 +208,8 @@ class StandardizedMatrix:
         if rows_n is not None and len(rows_n) == 0:
             res = D.zeros((k, k), torch.float64)
             return res if on_dev else D.to_host(res)
-        inner, diag, xtd = self._inner_xtd_dev(d_dev, rows_d, cols_n)
+        cen = self._centering() if d_dev.dtype == torch.float64 else None
+        inner, diag, xtd, cmask, grp = self._inner_xtd_dev(d_dev, rows_d, cols_n, cen)
         res = inner.contiguous() if inner is not None else D.empty((k, k), torch.float64)
         sum_d = _vec_sum(d_dev, rows_d)
         # (operands held in locals until the launch is queued: a temporary whose pointer has been
@@ -154,6 +217,15 @@ class StandardizedMatrix:
         xtd_c = xtd.contiguous()
         shift_c = self._shift_dev(cols_n).contiguous()
         mult_c = None if self.mult is None else self._mult_dev(cols_n).contiguous()
+        if cen is not None and diag is None:
+            sel = None if cols_n is None else D.idx_dev(cols_n, torch.int64)
+            c_c = (cen[0] if sel is None else cen[0][sel]).contiguous()
+            g_c = (grp if grp is not None else cen[1] if sel is None else cen[1][sel]).contiguous()
+            # raw column sums of centred columns -> centred: X' d - c sum(d)
+            xtd_c = torch.where(cmask, xtd_c, xtd_c - c_c * sum_d).contiguous()
+            call("tm_standardize_sandwich_centered_f64", D.p(res), D.p(xtd_c), D.p(c_c), D.p(g_c), D.p(shift_c),
+                 D.p(mult_c), D.p(sum_d), k, D.stream_ptr())
+            return res if on_dev else D.to_host(res)
         call("tm_standardize_sandwich_f64", D.p(res), D.p(diag), D.p(xtd_c), D.p(shift_c),
              D.p(mult_c), D.p(sum_d), k, D.stream_ptr())
         return res if on_dev else D.to_host(res)
