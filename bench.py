@@ -34,9 +34,25 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix (AMD datasheet; not in the guide's table)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 (MI355X_MICROARCH.md; 2:1-sparsity figures are never used)
+INT8_PEAK_TOPS = 5000.0        # dense int8 MFMA = the fp8 rate (MI355X_MICROARCH.md: ~5 P dense; >= 3944 TOPS measured)
 # LDS: "Aggregate with every CU streaming (~2.4 GHz): ~150 TB/s for ds_read_b64/b128" (MI355X_MICROARCH.md, LDS
 # section; 64 banks x 4 B x 256 CUs x 2.4 GHz = 157 TB/s is the array's width)
 LDS_PEAK_GBS = 150000.0
+
+
+# cfg4 (10M rows): what the CURRENT formulation -- one kernel per block product, each streaming its operands in the
+# order it works best on -- could reach with every kernel at the floor its own ablations show (profiles/r4_k3_ent.txt,
+# profiles/r4_k2b.txt, profiles/r3_syrk_i8.txt).  The north star's 2.8 ms (0.60 of HBM peak) is
+# below the f64 arithmetic of the dense term alone at any rate this chip has: the step is printed
+# against both.
+DESIGN_FLOOR_CFG4_MS = {
+    "sparse x dense (K3)": (2.56, "memory side alone: entry stream + slab copies, no batches (r4_k3_ent.txt)"),
+    "sparse self (K2b)": (3.70, "every gather served from the L2: the LDS-atomic pipe alone (r4_k2b.txt)"),
+    "dense self (K1e)": (1.91, "copy-only rate of its LDS-DMA pattern (r3_syrk_i8.txt)"),
+    "categorical x dense": (1.30, "10.4 GB at the 8 TB/s HBM peak"),
+    "categorical x sparse": (0.46, "3.7 GB at the 8 TB/s HBM peak"),
+    "tables, reductions, scatter": (0.40, "~25 small launches (r4_bench_cfg4_kernel_stats.txt)"),
+}
 
 
 def _baseline_metric():
@@ -128,9 +144,11 @@ def kernel_ops(mat, d):
                         fused.append((f"allcats_x_dense{i}", lambda mw=mw, oh=oh: xs.csr_dense_sandwich_slab(
                             oh, mw._dev(), d)))
                 elif isinstance(mw, tm.SparseMatrix):
-                    if getattr(mw, "_entblk", None) is not None:              # same choice as the product
-                        fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich_ent(
-                            cats, d, mw._ent())))
+                    # same choice as the product (`_entblk` is False when the twin was refused)
+                    ent = mw._ent() if getattr(mw, "_entblk", None) else None
+                    if ent is not None:
+                        fused.append((f"allcats_x_sparse{i}", lambda ent=ent: xsplit.multi_cat_sparse_sandwich_ent(
+                            cats, d, ent)))
                     else:
                         fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
                             cats, d, mw._slab())))
@@ -326,7 +344,10 @@ def cpu_baseline(workload, rows, mat, d):
         "unit": "GB/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": f"{workload}: first {rows} rows of the same data, min of <=3 runs, {best * 1e3:.1f} ms",
+        "sample": (f"{workload}: first {rows} rows of the same data, min of <=3 runs, {best * 1e3:.1f} ms "
+                   "(a bounded sample, not the full rows: the oracle needs host copies of the blocks -- 13.5 GB "
+                   "pulled back over PCIe and ~10 s per pass at 10M rows -- and the default run has to finish in "
+                   "minutes; the oracle's cost is linear in the rows, --cpu-rows N times any other sample)"),
         "seconds": round(best, 4),
         "reference_cpu_survey": REFERENCE_CPU_SURVEY.get(workload),
     }
@@ -487,10 +508,15 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # every rank's own clock over the same K steps: the max is the job's time (the contract), min / max side
+        # by side make the first real multi-GPU run self-diagnosing (a straggler GPU, a slow link)
+        mine = torch.zeros(world, dtype=torch.float64, device="cuda")
+        mine[rank] = elapsed
+        dist.all_reduce(mine)
+        rank_ms = [round(float(x) / args.steps * 1e3, 4) for x in mine.tolist()]
+        elapsed = float(mine.max().item())
     ms_per_step = elapsed / args.steps * 1e3
     # min over individually timed steps next to the mean (the reference harness reports the
     # minimum, benchmark/main.py:108-128); outside the timed region above
@@ -509,12 +535,12 @@ def main():
     if tdt == torch.float64 and not use_graph:
         dms = [m for m in (mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat])
                if isinstance(m, tm.DenseMatrix)]
-        took_i8 = [m for m in dms if getattr(m, "_i8_hist", None) is not None]
+        took_i8 = [m for m in dms if getattr(m, "_i8_hist", None)]
         if dms:
             dense_term = ("int8x5 (40-bit fixed point per column on the int8 matrix cores, K1e; hand-over to "
                           "the f64 MFMA kernel outside its envelope)") if took_i8 else "f64 MFMA"
         if took_i8:
-            hist = took_i8[0]._i8_history()[:2].cpu().tolist()   # {consecutive envelope misses, calls}
+            hist = took_i8[0]._i8_history(None)[:2].cpu().tolist()   # {consecutive envelope misses, calls}
             handovers = {"consecutive_envelope_misses": int(hist[0]), "calls": int(hist[1])}
             was = tm.set_strict_f64(True)
             try:
@@ -553,6 +579,36 @@ def main():
         except RuntimeError as e:      # a side measurement: the eager line stands without it
             print(f"[bench] hipgraph replay not measured: {e}", file=sys.stderr)
 
+    # matvec / transpose_matvec of the SAME resident matrix (the north star names them; the reference's harness
+    # times all three products, benchmark/main.py:58-62,108-128): per-GPU sub-records, never `value`.
+    # Algorithmic bytes = the blocks once + the input and output vectors.
+    mv = {}
+    if True:
+        blk_bytes = synth.algorithmic_bytes(mat) - n_local * np.dtype(mat.dtype).itemsize - (
+            p * p * 8 if isinstance(mat, tm.SplitMatrix) else
+            p * np.dtype(mat.dtype).itemsize if isinstance(mat, tm.CategoricalMatrix) else
+            p * p * np.dtype(mat.dtype).itemsize)
+        isz = np.dtype(mat.dtype).itemsize
+        vg = torch.Generator(device="cuda")
+        vg.manual_seed(7)
+        vcoef = torch.randn(p, dtype=tdt, device="cuda", generator=vg)
+        for name, fn in (("matvec", lambda: mat.matvec(vcoef)), ("transpose_matvec", lambda: mat.transpose_matvec(d))):
+            try:
+                for _ in range(max(1, args.warmup)):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / args.steps * 1e3
+                by = blk_bytes + (n_local + p) * isz
+                mv[name] = {"ms": round(ms, 4), "gbs": round(by / (ms * 1e-3) / 1e9, 1),
+                            "frac_hbm": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes": int(by)}
+            except Exception as e:        # a side measurement: the sandwich line stands without it
+                mv[name] = {"error": str(e)[:200]}
+
     alg_bytes = synth.algorithmic_bytes(mat)
     flops = synth.algorithmic_flops(mat) if isinstance(mat, tm.SplitMatrix) else (
         float(n_local) * p * (p + 1) if isinstance(mat, tm.DenseMatrix) else float(n_local))
@@ -582,12 +638,11 @@ def main():
         mfma_time = (dom_flops / (peak_tf * 1e12)) if dom_flops else 0.0
         dom_lds = op_lds_bytes(mat, dom)
         lds_time = (dom_lds / (LDS_PEAK_GBS * 1e9)) if dom_lds else 0.0
-        # the bounding roofline of the dominant kernel: the largest of its HBM, MFMA and LDS times
-        if lds_time > max(hbm_time, mfma_time):
-            roof = {"bound": "lds", "achieved": round(dom_lds / (dom_ms * 1e-3) / 1e9, 1),
-                    "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                    "algorithmic_lds_bytes_per_launch": int(dom_lds)}
-        elif mfma_time > hbm_time:
+        # the bounding roofline of the dominant kernel ("hbm" | "mfma"): MFMA when its matrix time
+        # exceeds its HBM time, else HBM -- `frac` is against THAT bound.  A kernel whose inner loop is an LDS
+        # gather additionally carries `frac_lds` (its algorithmic LDS bytes against the guide's aggregate LDS
+        # rate): a second opinion on what limits it, never `frac`.
+        if mfma_time > hbm_time:
             roof = {"bound": "mfma", "achieved": round(dom_flops / (dom_ms * 1e-3) / 1e12, 3),
                     "peak": peak_tf, "unit": "TFLOP/s"}
         else:
@@ -596,16 +651,35 @@ def main():
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         # (the same kernel against the HBM roofline, whatever binds it)
         roof["frac_hbm"] = round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if dom_lds:
+            roof["frac_lds"] = round(dom_lds / (dom_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4)
+            roof["algorithmic_lds_bytes_per_launch"] = int(dom_lds)
+            roof["lds_peak_gbs"] = LDS_PEAK_GBS
         # HBM bytes per launch of that kernel, measured NOW: rocprofv3 --pmc passes over a child
         # run that launches the same op (null when rocprofv3 is unavailable or N > 1)
         roof["traffic"] = None
         if world == 1 and not args.no_traffic:
             roof["traffic"] = measure_traffic(args, dom)
-        # the dense self-sandwich (MFMA syrk) against the matrix spec of its dtype
-        mfma_frac = None
+        # the dense self-sandwich: against the matrix spec of its dtype when it ran on that dtype's MFMA; when it
+        # ran in 40-bit fixed point on the INT8 matrix cores (K1e) an f64-equivalent flop rate against the f64
+        # spec would not be a utilisation: it is priced against HBM (it streams the block once) and by the int8
+        # operations it issues (22 digit-pair products of n k (k + 1) / 2 MACs each, padded to 128 columns)
+        mfma_frac, dense_self = None, None
+        i8_ran = bool(dense_term and dense_term.startswith("int8"))
         for name, ms in bd.items():
             fl = op_flops(mat, name)
-            if fl:
+            if not fl:
+                continue
+            if i8_ran:
+                by = op_algorithmic_bytes(mat, name)
+                kk = [m for m in (mat.matrices if isinstance(mat, tm.SplitMatrix) else [mat])
+                      if isinstance(m, tm.DenseMatrix)][0].shape[1]
+                kp = -(-kk // 128) * 128 if kk <= 128 else kk
+                dense_self = {"kernel": name, "ms": round(ms, 4), "arithmetic": "int8x5 digits, 22 digit pairs, int32 acc",
+                              "frac_hbm": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "int8_tops": round(22.0 * n_local * kp * (kp + 16) / (ms * 1e-3) / 1e12, 1),
+                              "int8_peak_tops_dense": INT8_PEAK_TOPS}
+            else:
                 mfma_frac = round(fl * (6.0 if mfma_note else 1.0) / (ms * 1e-3) / (peak_tf * 1e12), 4)
         if mfma_note:
             roof["note"] = mfma_note
@@ -647,12 +721,32 @@ def main():
             "mixed_roofline_ms": round(max(alg_bytes / world / (HBM_PEAK_GBS * 1e9),
                                            flops * (6.0 if mfma_note else 1.0) / world / (peak_tf * 1e12)) * 1e3, 4),
             "mfma_frac_of_spec": mfma_frac,
+            "dense_self": dense_self,
             "sum_kernel_ms": round(sum(bd.values()), 4),
+            "matvec": mv.get("matvec"),
+            "transpose_matvec": mv.get("transpose_matvec"),
             "dense_term": dense_term,
             "dense_term_handover": handovers,
             "ms_per_step_f64_only": None if ms_f64_only is None else round(ms_f64_only, 4),
             "ms_per_step_hipgraph": None if ms_graph is None else round(ms_graph, 4),
         }
+        if args.workload == "cfg4":
+            scale = n_local / 10_000_000
+            floor = sum(v[0] for v in DESIGN_FLOOR_CFG4_MS.values()) * scale
+            result["design_floor_ms"] = round(floor, 2)
+            result["design_floor"] = {
+                "what": ("per-GPU step time of the CURRENT formulation (one kernel per block product) with every "
+                         "kernel at the floor its own ablation shows; the north star's 0.60 of HBM peak would be "
+                         f"{alg_bytes / world / (0.6 * HBM_PEAK_GBS * 1e9) * 1e3:.2f} ms, below the f64 arithmetic of the "
+                         "dense term at any rate this chip has (SURVEY.md 8d)"),
+                "terms_ms_at_10M_rows": {k: {"ms": v[0], "from": v[1]} for k, v in DESIGN_FLOOR_CFG4_MS.items()},
+                "step_over_floor": round(ms_per_step / floor, 3),
+            }
+        if world > 1:
+            result["ranks"] = {"backend": backend, "world_size": world,
+                               "rccl_ranks": world if backend == "nccl" else 0,
+                               "ms_per_step_by_rank": rank_ms, "ms_per_step_min_rank": min(rank_ms),
+                               "ms_per_step_max_rank": max(rank_ms)}
         if not args.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cpu_rows = args.cpu_rows or {"cfg4": 1_000_000, "cfg2": 2_000_000,
                                          "cfg3": 50_000_000}.get(args.workload, 1_000_000)

@@ -4,7 +4,7 @@ HIP kernel in libtabmat_hip.so reached through the C ABI of include/tabmat_hip.h
 no CPU fallback."""
 from .categorical_matrix import CategoricalMatrix
 from .constructor import from_csc, from_df, from_pandas
-from .dense_matrix import DenseMatrix, set_strict_f64, strict_f64
+from .dense_matrix import DenseMatrix, set_strict_f32, set_strict_f64, strict_f32, strict_f64
 from .matrix_base import MatrixBase
 from .sparse_matrix import SparseMatrix
 from .split_matrix import SplitMatrix, as_tabmat, hstack
@@ -12,4 +12,4 @@ from .standardized_mat import StandardizedMatrix
 
 __all__ = ["DenseMatrix", "SparseMatrix", "CategoricalMatrix", "SplitMatrix",
            "StandardizedMatrix", "MatrixBase", "hstack", "as_tabmat", "from_csc", "from_df",
-           "from_pandas", "set_strict_f64", "strict_f64"]
+           "from_pandas", "set_strict_f64", "strict_f64", "set_strict_f32", "strict_f32"]

@@ -100,78 +100,248 @@ __global__ __launch_bounds__(256) void csr_rmatvec_kernel(
 constexpr int CSR_RPW = 64;          // rows per wave
 constexpr int CSR_CAP = 1024;        // staged entries per wave and chunk
 constexpr int CSR_WAVES = 4;
+constexpr int CSR_EPL = CSR_CAP / 64;   // entries per lane and tile
+
+// Round 5: both stream kernels are software-pipelined.  Round 2's versions loaded a tile with four loads per
+// array in flight, worked on it, and only then asked for the next one: with the 16 waves of a CU in step the
+// memory pipe idled through every compute phase (0.63 / 0.48 of the HBM peak).  Now a wave owns a CONTIGUOUS range
+// of row chunks and walks its nonzeros as one stream of tiles of CSR_CAP entries; a tile is fetched with 16- / 8-byte
+// vector loads (lane <-> two adjacent entries, eight pairs per lane, all sixteen loads issued back to back) into
+// registers ONE TILE AHEAD of the tile being worked on, and the row pointers / vector entries of a chunk one chunk
+// ahead.  A tile starts at an even entry (vector alignment): the entry in front of a chunk's first one, if any, is
+// fetched with it and ignored.
+template <typename F>
+struct CsrTile {
+    F x[CSR_EPL];
+    int32_t j[CSR_EPL];
+};
+
+// entries [c0, c0 + cnt) of the stream (data + c0 16- / 8-byte aligned, cnt <= CSR_CAP; nnz = entries in the arrays):
+// lane holds e = 2 lane + 128 k + {0, 1}.  Pairs are fetched whole; a pair whose second entry lies behind the tile
+// is fetched anyway (the consumers ignore slots >= cnt) unless it would leave the arrays -- only the first tile
+// of an odd-aligned view (c0 = -1) and the last tile of the arrays can, and they take the entry-by-entry path.
+template <typename F>
+__device__ __forceinline__ void csr_tile_load(const F *__restrict__ data, const int32_t *__restrict__ ind, int64_t c0,
+                                              int cnt, int64_t nnz, int lane, CsrTile<F> &t) {
+    typedef F f2 __attribute__((ext_vector_type(2)));
+    typedef int32_t i2 __attribute__((ext_vector_type(2)));
+    const F *dp = data + c0 + 2 * lane;
+    const int32_t *ip = ind + c0 + 2 * lane;
+    if (cnt == CSR_CAP && c0 >= 0) {
+#pragma unroll
+        for (int k = 0; k < CSR_EPL / 2; ++k) {
+            const f2 xv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(dp + 128 * k));
+            const i2 jv = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(ip + 128 * k));
+            t.x[2 * k] = xv[0];
+            t.x[2 * k + 1] = xv[1];
+            t.j[2 * k] = jv[0];
+            t.j[2 * k + 1] = jv[1];
+        }
+        return;
+    }
+    if (c0 >= 0 && c0 + cnt + 1 <= nnz) {
+        // a partial tile inside the arrays: whole pairs under one predicate each -- no element-wise merges, so
+        // none of these loads is waited for before its use (the entry-by-entry path below serialises them)
+#pragma unroll
+        for (int k = 0; k < CSR_EPL / 2; ++k) {
+            f2 xv = f2{F(0), F(0)};
+            i2 jv = i2{0, 0};
+            if (2 * lane + 128 * k < cnt) {
+                xv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(dp + 128 * k));
+                jv = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(ip + 128 * k));
+            }
+            t.x[2 * k] = xv[0];
+            t.x[2 * k + 1] = xv[1];
+            t.j[2 * k] = jv[0];
+            t.j[2 * k + 1] = jv[1];
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < CSR_EPL / 2; ++k) {
+        const int e = 2 * lane + 128 * k;
+        F x0 = F(0), x1 = F(0);
+        int32_t j0 = 0, j1 = 0;
+        if (e < cnt && c0 + e >= 0) {
+            x0 = dp[128 * k];
+            j0 = ip[128 * k];
+        }
+        if (e + 1 < cnt) {
+            x1 = dp[128 * k + 1];
+            j1 = ip[128 * k + 1];
+        }
+        t.x[2 * k] = x0;
+        t.x[2 * k + 1] = x1;
+        t.j[2 * k] = j0;
+        t.j[2 * k + 1] = j1;
+    }
+}
+
+// a wave-uniform 64-bit value out of lane `src` (scalar registers: the tile bookkeeping stays off the VALU)
+__device__ __forceinline__ int64_t csr_uniform(int64_t v, int src) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(uint64_t)v, src);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// The tile walk shared by both kernels.  chunk range [cb, ce) of this wave; per chunk c lane <-> row c * 64 + lane
+// with its entry range [rlo, rhi); `Per` = per-row payload fetched with the pointers (rmatvec: v[row]).
+// body(tile, c0, cnt, rlo, rhi, first, payload) works on one tile; end_chunk(row, payload) closes a chunk.
+template <typename F, typename Per, typename LoadPer, typename Body, typename EndChunk>
+__device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, const int32_t *__restrict__ ind,
+                                                const int64_t *__restrict__ ptr, int64_t n, int64_t cb, int64_t ce,
+                                                int lane, LoadPer load_per, Body body, EndChunk end_chunk) {
+    if (cb >= ce) return;
+    // element parity of the arrays' first entry (a row-sliced view starts anywhere): tiles start where data + c0
+    // is vector-aligned (the host checked that data and ind share the parity)
+    const int64_t off = (int64_t)((reinterpret_cast<uintptr_t>(data) / sizeof(F)) & 1);
+    const int64_t nnz = ptr[n];
+    auto load_ptrs = [&](int64_t c, int64_t &lo, int64_t &hi, Per &pp) {
+        const int64_t row = c * CSR_RPW + lane;
+        lo = ptr[min(row, n)];
+        hi = ptr[min(row + 1, n)];
+        pp = load_per(row);
+    };
+    int64_t c = cb, rlo, rhi, rloN = 0, rhiN = 0;
+    Per per, perN = Per();
+    load_ptrs(c, rlo, rhi, per);
+    if (c + 1 < ce) load_ptrs(c + 1, rloN, rhiN, perN);
+    int64_t p0 = csr_uniform(rlo, 0), p1 = csr_uniform(rhi, 63);
+    int64_t c0 = p0 - ((p0 + off) & 1);
+    CsrTile<F> A, B;
+    csr_tile_load(data, ind, c0, (int)min((int64_t)CSR_CAP, p1 - c0), nnz, lane, A);
+    // one step: request the tile after (c, c0) into `nxt`, work on `cur`; false when `cur` was the last one
+    auto step = [&](CsrTile<F> &cur, CsrTile<F> &nxt) -> bool {
+        const bool same = c0 + CSR_CAP < p1;           // the chunk goes on in the next tile
+        const bool more = same || c + 1 < ce;
+        int64_t c0n = c0 + CSR_CAP, p0n = p0, p1n = p1;
+        int64_t rlo2 = rlo, rhi2 = rhi;
+        Per per2 = per;
+        if (!same && more) {
+            rlo2 = rloN;
+            rhi2 = rhiN;
+            per2 = perN;
+            p0n = csr_uniform(rlo2, 0);
+            p1n = csr_uniform(rhi2, 63);
+            c0n = p0n - ((p0n + off) & 1);
+            if (c + 2 < ce) load_ptrs(c + 2, rloN, rhiN, perN);
+        }
+        if (more) csr_tile_load(data, ind, c0n, (int)min((int64_t)CSR_CAP, p1n - c0n), nnz, lane, nxt);
+        body(cur, c0, (int)min((int64_t)CSR_CAP, p1 - c0), rlo, rhi, (int)(p0 > c0 ? p0 - c0 : 0), per);
+        if (!same) {
+            end_chunk(c * CSR_RPW + lane, per);
+            ++c;
+        }
+        c0 = c0n;
+        p0 = p0n;
+        p1 = p1n;
+        rlo = rlo2;
+        rhi = rhi2;
+        per = per2;
+        return more;
+    };
+    while (true) {
+        if (!step(A, B)) break;
+        if (!step(B, A)) break;
+    }
+}
+
+struct CsrNoPer {};
 
 template <typename F>
 __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
-    const F *__restrict__ v, int64_t n, int m, F *__restrict__ out) {
+    const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_wave, F *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *vl = reinterpret_cast<F *>(smem_raw);                       // [m]
+    F *vl = reinterpret_cast<F *>(smem_raw);                       // [m] (padded to an even count)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    F *prod = vl + m + wave * CSR_CAP;                             // [CSR_CAP] per wave
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    F *prod = vl + ((m + 1) & ~1) + wave * CSR_CAP;                // [CSR_CAP] per wave
     for (int j = threadIdx.x; j < m; j += blockDim.x) vl[j] = v[j];
     __syncthreads();
     const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
-    for (int64_t c = (int64_t)blockIdx.x * CSR_WAVES + wave; c < nchunk;
-         c += (int64_t)gridDim.x * CSR_WAVES) {
-        const int64_t row = c * CSR_RPW + lane;
-        const int64_t rlo = ptr[min(row, n)];
-        const int64_t rhi = ptr[min(row + 1, n)];
-        const int64_t p0 = __shfl(rlo, 0, 64);
-        const int64_t p1 = ptr[min(c * CSR_RPW + CSR_RPW, n)];
-        F acc = F(0);
-        for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
-            const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
-#pragma unroll 4
-            for (int e = lane; e < cnt; e += 64)
-                prod[e] = __builtin_nontemporal_load(data + c0 + e) * vl[__builtin_nontemporal_load(ind + c0 + e)];
+    const int64_t cb = ((int64_t)blockIdx.x * CSR_WAVES + wave) * chunks_per_wave;
+    const int64_t ce = min(cb + chunks_per_wave, nchunk);
+    typedef F f2 __attribute__((ext_vector_type(2)));
+    F acc = F(0);
+    csr_stream_walk<F, CsrNoPer>(
+        data, ind, ptr, n, cb, ce, lane, [](int64_t) { return CsrNoPer(); },
+        [&](const CsrTile<F> &t, int64_t c0, int cnt, int64_t rlo, int64_t rhi, int first, CsrNoPer) {
+            // (entries beyond cnt hold x = 0, j = 0: their slots are written and never summed)
+            // (v from its LDS copy: gathering it from global memory instead -- L1-resident -- to relieve the LDS pipe
+            // was 30 % slower, profiles/r5_matvec.txt)
+#pragma unroll
+            for (int k = 0; k < CSR_EPL / 2; ++k) {
+                f2 pv;
+                pv[0] = t.x[2 * k] * vl[t.j[2 * k]];
+                pv[1] = t.x[2 * k + 1] * vl[t.j[2 * k + 1]];
+                *reinterpret_cast<f2 *>(prod + 2 * lane + 128 * k) = pv;
+            }
             __builtin_amdgcn_wave_barrier();
             const int lo = (int)(max(rlo, c0) - c0);
-            const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
-            for (int e = lo; e < hi; ++e) acc += prod[e];
+            const int hi = (int)(min(rhi, c0 + cnt) - c0);
+            // the row's part of the tile, two slots per LDS read (the LDS pipe is what this kernel runs on: 16
+            // gathers + 8 stores + the segment reads per tile; with one slot per read the latter were 40 of 64)
+            int e = lo;
+            if ((e & 1) && e < hi) acc += prod[e++];
+            F acc2 = F(0);
+            for (; e + 1 < hi; e += 2) {
+                const f2 pv = *reinterpret_cast<const f2 *>(prod + e);
+                acc += pv[0];
+                acc2 += pv[1];
+            }
+            acc += acc2;
+            if (e < hi) acc += prod[e];
             __builtin_amdgcn_wave_barrier();
-        }
-        if (row < n) out[row] += acc;
-    }
+            (void)first;
+        },
+        [&](int64_t row, CsrNoPer) {
+            if (row < n) out[row] += acc;
+            acc = F(0);
+        });
 }
 
 template <typename F>
 __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
-    const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_block, F *__restrict__ ws,
+    const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_wave, F *__restrict__ ws,
     int square) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     lds_acc_t *bins = reinterpret_cast<lds_acc_t *>(smem_raw);     // [m] doubles
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    F *vrow = reinterpret_cast<F *>(bins + m) + wave * CSR_CAP;    // [CSR_CAP] per wave
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    F *vrow = reinterpret_cast<F *>(bins + ((m + 1) & ~1)) + wave * CSR_CAP;    // [CSR_CAP] per wave, 16-byte aligned
     for (int j = threadIdx.x; j < m; j += blockDim.x) bins[j] = 0.0;
     __syncthreads();
     const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
-    const int64_t cb0 = (int64_t)blockIdx.x * chunks_per_block;
-    const int64_t cb1 = min(cb0 + chunks_per_block, nchunk);
-    for (int64_t c = cb0 + wave; c < cb1; c += CSR_WAVES) {
-        const int64_t row = c * CSR_RPW + lane;
-        const int64_t rlo = ptr[min(row, n)];
-        const int64_t rhi = ptr[min(row + 1, n)];
-        const F vr = row < n ? v[row] : F(0);
-        const int64_t p0 = __shfl(rlo, 0, 64);
-        const int64_t p1 = ptr[min(c * CSR_RPW + CSR_RPW, n)];
-        for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
-            const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
+    const int64_t cb = ((int64_t)blockIdx.x * CSR_WAVES + wave) * chunks_per_wave;
+    const int64_t ce = min(cb + chunks_per_wave, nchunk);
+    typedef F f2 __attribute__((ext_vector_type(2)));
+    csr_stream_walk<F, F>(
+        data, ind, ptr, n, cb, ce, lane, [&](int64_t row) { return row < n ? v[row] : F(0); },
+        [&](const CsrTile<F> &t, int64_t c0, int cnt, int64_t rlo, int64_t rhi, int first, F vr) {
+            // lane <-> row: v[row] over the row's part of the tile, then lane <-> entry
             const int lo = (int)(max(rlo, c0) - c0);
-            const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
+            const int hi = (int)(min(rhi, c0 + cnt) - c0);
             for (int e = lo; e < hi; ++e) vrow[e] = vr;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int e = lane; e < cnt; e += 64) {
-                const F x = data[c0 + e];
-                atomic_add(&bins[ind[c0 + e]], (lds_acc_t)((square ? x * x : x) * vrow[e]));
+#pragma unroll
+            for (int k = 0; k < CSR_EPL / 2; ++k) {
+                const int e = 2 * lane + 128 * k;
+                const f2 vv = *reinterpret_cast<const f2 *>(vrow + e);
+                // (slots in front of the chunk's first entry and behind the tile's last were not written: skipped)
+                if (e >= first && e < cnt) {
+                    const F x = t.x[2 * k];
+                    atomic_add(&bins[t.j[2 * k]], (lds_acc_t)((square ? x * x : x) * vv[0]));
+                }
+                if (e + 1 >= first && e + 1 < cnt) {
+                    const F x = t.x[2 * k + 1];
+                    atomic_add(&bins[t.j[2 * k + 1]], (lds_acc_t)((square ? x * x : x) * vv[1]));
+                }
             }
             __builtin_amdgcn_wave_barrier();
-        }
-    }
+        },
+        [](int64_t, F) {});
     __syncthreads();
     F *dst = ws + (int64_t)blockIdx.x * m;
     for (int j = threadIdx.x; j < m; j += blockDim.x) dst[j] = (F)bins[j];
@@ -782,6 +952,14 @@ __global__ void untile_kernel(const F *__restrict__ tmp, int64_t nA, int64_t nB,
 // ---------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// the stream kernels fetch PAIRS of entries: element-aligned arrays whose first entries share their parity (any
+// row-sliced view of arrays that were allocated together does)
+template <typename F>
+static inline bool csr_stream_aligned(const F *data, const int32_t *ind) {
+    const uintptr_t d = reinterpret_cast<uintptr_t>(data), i = reinterpret_cast<uintptr_t>(ind);
+    return d % sizeof(F) == 0 && i % 4 == 0 && ((d / sizeof(F)) & 1) == ((i / 4) & 1);
+}
+
 template <typename F>
 static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
                           int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
@@ -789,17 +967,21 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     const int64_t n_iter = rows ? n_rows : n;
     if (n_iter == 0 || m == 0) return TM_OK;
     if (cols && n_cols == 0) return TM_OK;
-    if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
-        const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
+    if (!rows && !cols && sizeof(F) * (size_t)(m + 2 + CSR_WAVES * CSR_CAP) <= 64 * 1024 &&
+        csr_stream_aligned(data, ind)) {
+        const size_t lds = sizeof(F) * (size_t)(((m + 1) & ~(int64_t)1) + CSR_WAVES * CSR_CAP);
         auto kern = &csr_matvec_stream_kernel<F>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t nchunk = ceil_div(n, CSR_RPW);
-        const int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
+        // every wave a contiguous range of chunks
+        const int64_t nwave = std::min<int64_t>(nchunk, (int64_t)NUM_CU * 4 * CSR_WAVES);
+        const int64_t cpw = ceil_div(nchunk, nwave);
+        const int64_t nblk = ceil_div(ceil_div(nchunk, cpw), CSR_WAVES);
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind, ptr,
-                           v, n, (int)m, out);
+                           v, n, (int)m, cpw, out);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
@@ -832,23 +1014,24 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     const int64_t n_out = cols ? n_cols : m;
     if (n_iter == 0 || n_out == 0) return TM_OK;
     if (!rows && !cols &&
-        sizeof(lds_acc_t) * (size_t)m + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= 64 * 1024) {
-        const size_t lds = sizeof(lds_acc_t) * (size_t)m + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
+        sizeof(lds_acc_t) * (size_t)(m + 1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= 64 * 1024 &&
+        csr_stream_aligned(data, ind)) {
+        const size_t lds = sizeof(lds_acc_t) * (size_t)((m + 1) & ~(int64_t)1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
         auto kern = &csr_rmatvec_stream_kernel<F>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t nchunk = ceil_div(n, CSR_RPW);
-        int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
-        const int64_t cpb = ceil_div(nchunk, nblk);
-        nblk = ceil_div(nchunk, cpb);
+        const int64_t nwave = std::min<int64_t>(nchunk, (int64_t)NUM_CU * 4 * CSR_WAVES);
+        const int64_t cpw = ceil_div(nchunk, nwave);
+        const int64_t nblk = ceil_div(ceil_div(nchunk, cpw), CSR_WAVES);
         void *wsv = nullptr;
         int rc = get_workspace(sizeof(F) * (size_t)(nblk * m) + 256, &wsv, st);
         if (rc) return rc;
         F *ws = reinterpret_cast<F *>(wsv);
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind, ptr,
-                           v, n, (int)m, cpb, ws, square);
+                           v, n, (int)m, cpw, ws, square);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return launch_reduce_partials<F>(ws, m, (int)nblk, 1, out, m, true, st);

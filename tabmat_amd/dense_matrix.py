@@ -56,6 +56,30 @@ def strict_f64() -> bool:
     return not SYRK_I8
 
 
+_STRICT_F32 = os.environ.get("TABMAT_AMD_SYRK_BF16", "1") == "0"
+
+
+def set_strict_f32(flag: bool = True) -> bool:
+    """strict = True: every float32 sandwich runs on the float32 MFMA.  By default an unrestricted C-ordered
+    float32 block of 129..256 columns is computed as a three-piece bf16 split on the bf16 matrix cores (K1d,
+    csrc/syrk_bf16.hip: 3.5 instead of 5.8 ms at BASELINE configs[1]) with a relative error of 6.6e-7 of
+    max|S| against 8e-8 for the f32 MFMA -- inside the reference's own float32 tolerance (sqrt(eps),
+    tests/test_fast_sandwich.py), but not the last bits of float32.  The counterpart of set_strict_f64; sets
+    the library's `syrk_bf16` knob.  TABMAT_AMD_SYRK_BF16=0 sets strict mode at import.  Returns the previous
+    setting."""
+    global _STRICT_F32
+    from ._lib import call
+
+    old = _STRICT_F32
+    _STRICT_F32 = bool(flag)
+    call("tm_tune_set", b"syrk_bf16", 0 if flag else 1)
+    return old
+
+
+def strict_f32() -> bool:
+    return _STRICT_F32
+
+
 class DenseMatrix(MatrixBase):
     """Dense block.  Construct from a numpy array (kept on the host, uploaded lazily on the
     first product) or from an (n, m) torch cuda tensor (no host copy)."""
@@ -363,3 +387,10 @@ class DenseMatrix(MatrixBase):
         """self[:, cols] @ vec[cols] (dense_matrix.py:249-257)."""
         check_matvec_out_shape(self, out)
         return self._matvec_helper(vec, None, cols, out, False)
+
+
+if _STRICT_F32:        # TABMAT_AMD_SYRK_BF16=0: the knob lives in the library
+    try:
+        set_strict_f32(True)
+    except Exception:   # library not built yet: every product will raise TabmatHipError anyway
+        pass

@@ -178,7 +178,11 @@ class SparseMatrix(MatrixBase):
             self._dev().pair_blocks()
         ent = None
         if dense_width is not None and dense_width > 0:
-            ent = self._ent() if dense_width > 64 else None
+            # (the entry twin only when the sparse x dense term will run on it: not for a few nonzeros per row in a
+            # wide block, which takes the column-sorted kernel -- same test as _cross_sandwich_dev)
+            sorted_k3 = (self._dev().data.numel() <= SORTED_K3_NNZ_PER_ROW * self.shape[0]
+                         and self.shape[1] >= 1024)
+            ent = self._ent() if dense_width > 64 and not sorted_k3 else None
             if dense_width <= 64 or (ent is None and self._lg() is None):
                 self._ell(wide=dense_width > 64)
         if ent is None:
@@ -309,12 +313,15 @@ class SparseMatrix(MatrixBase):
         from . import categorical_matrix as _cm
 
         if _cm.DETERMINISTIC and A.data.numel() > 0 and self.shape[0] > 0:
-            res = self._sandwich_deterministic(d, rows)
+            res = self._sandwich_deterministic(d, rows, cols)
             if res is not None:
-                if cols is not None:
-                    c64 = cols.to(torch.int64)
-                    res = res[c64][:, c64].contiguous()
                 return res
+            import warnings
+
+            # (2^28 rows or more in one block, or a stream of 2^27 batches: no entry twin at all)
+            warnings.warn("TABMAT_AMD_DETERMINISTIC=1: this sparse block has no entry twin, its self sandwich "
+                          "falls back to the LDS-atomic kernels and is NOT bit-reproducible from run to run",
+                          RuntimeWarning, stacklevel=3)
         if getattr(self, "_direct_pays", None) is None:
             self._direct_pays = xs.direct_sandwich_pays(A)
         w = D.nlen(cols) if cols is not None else 0
@@ -378,7 +385,20 @@ class SparseMatrix(MatrixBase):
             return res
         return xs.sparse_sandwich(A, d, rows, cols)
 
-    def _sandwich_deterministic(self, d, rows):
+    def _ent_det(self):
+        """The entry twin for the deterministic mode: the one the products use, else (a block so sparse that the
+        padded stream exceeds ELL_MAX_PAD x its nonzeros) one built without that limit -- reproducibility was
+        asked for, the padding is its price."""
+        ent = self._ent()
+        if ent is None:
+            hit = getattr(self, "_entblk_det", None)
+            if hit is None:
+                twin = SlabEnt.from_csr(self._dev(), max_pad=None)
+                hit = self._entblk_det = twin if twin is not None else False
+            ent = hit or None
+        return ent
+
+    def _sandwich_deterministic(self, d, rows, cols=None):
         """TABMAT_AMD_DETERMINISTIC=1: the sparse self sandwich with a FIXED summation order, bit-identical
         from run to run -- the property the reference's kernel has by construction (thread-owned output rows,
         ext/sparse.pyx:55-74) and the LDS-atomic pair kernels (K2 / K2b) do not.  The block's columns are
@@ -386,10 +406,11 @@ class SparseMatrix(MatrixBase):
         csrc/sparse_ent.hip): an accumulator there receives its entries in stream order, the workgroups'
         partial sums are added in a fixed order.  out[i, j] and out[j, i] see the same terms in the same
         order but multiply them in a different one, so the lower triangle is mirrored.  About 4x the time of
-        the atomic kernel at BASELINE configs[3]; opt-in."""
+        the atomic kernel at BASELINE configs[3]; opt-in.  With `cols` only the selected columns are written out
+        (k / 128 passes instead of m / 128) and the (k, k) result of the selection is returned."""
         from .ext._types import DenseDev
 
-        ent = self._ent()
+        ent = self._ent_det()
         if ent is None:
             return None
         n, m = self.shape
@@ -397,20 +418,23 @@ class SparseMatrix(MatrixBase):
         if rows is not None:
             dm = torch.zeros_like(d)
             r64 = rows.to(torch.int64)
-            dm[r64] = d[r64]
+            dm.index_add_(0, r64, d[r64])           # (a repeated row id counts once per occurrence)
             d = dm
-        out = torch.empty((m, m), dtype=d.dtype, device=d.device)
+        sel = torch.arange(m, dtype=torch.int64, device=d.device) if cols is None else cols.to(torch.int64)
+        k = int(sel.numel())
+        out = torch.empty((m, k), dtype=d.dtype, device=d.device)
         W = 128
-        for c0 in range(0, m, W):
-            w = min(W, m - c0)
+        for c0 in range(0, k, W):
+            w = min(W, k - c0)
             w_pad = (w + 3) // 4 * 4                     # 16-byte aligned rows for the kernel's slab copy
             colmap = torch.full((m,), -1, dtype=torch.int32, device=d.device)
-            colmap[c0:c0 + w] = torch.arange(w, dtype=torch.int32, device=d.device)
+            colmap[sel[c0:c0 + w]] = torch.arange(w, dtype=torch.int32, device=d.device)
             T = torch.zeros((n, w_pad), dtype=A.data.dtype, device=d.device)
             xs.csr_densify_cols(A, colmap, T)
             res = xs.csr_dense_sandwich_ent(ent, DenseDev(T, n, w_pad, 0), d)
             out[:, c0:c0 + w] = res[:, :w]
             del T
+        out = out if cols is None else out[sel]
         low = torch.tril(out)
         return low + torch.tril(out, -1).T
 
@@ -457,7 +481,7 @@ class SparseMatrix(MatrixBase):
                     dm[r64] = d[r64]
                     d = dm
                 if (A.data.numel() <= SORTED_K3_NNZ_PER_ROW * self.shape[0] and self.shape[1] >= 1024
-                        and xs.ell_supported(Bd)):
+                        and xs.ell_supported(Bd)):      # (to_device applies the same test before building twins)
                     # a few nonzeros per row in a wide block: column by column on the CSC form
                     res = xs.csc_dense_sandwich_sorted(A, Bd, d)
                     if L_cols is not None:

@@ -60,3 +60,39 @@ def nat_err(a, b):
     err = np.abs(a - b)
     out = np.where(den > 0, err / np.where(den > 0, den, 1.0), np.where(err == 0, 0.0, np.inf))
     return float(out.max())
+
+
+def wdiag(M, d, rows=None, cols=None):
+    """diag(M[rows, cols]' diag(d[rows]) M[rows, cols]) in float64 for a host operand M: a dense array, a
+    scipy.sparse matrix, or a categorical spec ("cat", codes, n_columns, drop_first) (one-hot, -1 = missing)."""
+    from scipy import sparse as sps
+
+    d = np.asarray(d, dtype=np.float64)
+    r = slice(None) if rows is None else np.asarray(rows, dtype=np.int64)
+    if isinstance(M, tuple):
+        _, codes, ncol, drop = M
+        code = np.asarray(codes)[r].astype(np.int64) - (1 if drop else 0)
+        ok = code >= 0
+        out = np.bincount(code[ok], weights=d[r][ok], minlength=ncol)[:ncol]
+    elif sps.issparse(M):
+        Mr = M.tocsr()[r].astype(np.float64)
+        out = np.asarray(Mr.multiply(Mr).T @ d[r]).ravel()
+    else:
+        Mr = np.asarray(M, dtype=np.float64)[r]
+        out = (Mr * Mr).T @ d[r]
+    return out if cols is None else out[np.asarray(cols, dtype=np.int64)]
+
+
+def cross_err(a, b, d, L, R, rows=None, lc=None, rc=None):
+    """Entry-wise error of a CROSS sandwich L' D R at its natural scale sqrt((L'DL)_ii (R'DR)_jj) (Cauchy-Schwarz
+    bound of the entry for nonnegative d): the rectangular counterpart of nat_err -- a wrong strip cannot hide
+    under the largest entry of the block.  L / R: the host operands (see wdiag)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if not b.size:
+        return 0.0
+    den = np.sqrt(np.outer(np.abs(wdiag(L, d, rows, lc)), np.abs(wdiag(R, d, rows, rc))))
+    err = np.abs(a - b)
+    out = np.where(den > 0, err / np.where(den > 0, den, 1.0), np.where(err == 0, 0.0, np.inf))
+    return float(out.max())

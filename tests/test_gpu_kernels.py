@@ -7,7 +7,7 @@ import pytest
 from scipy import sparse as sps
 
 import _cases as cs
-from _gpu_util import nat_err, rel_err, to_tm_block, to_tm_split
+from _gpu_util import cross_err, nat_err, rel_err, to_tm_block, to_tm_split
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def test_dense_sandwich_f64(order, n, k):
     d = rng.random(n)
     res = tm.DenseMatrix(X).sandwich(d)
     ref = _orc().dense_sandwich(X, d, None, None)
-    assert rel_err(res, ref) < F64_TOL
+    assert nat_err(res, ref) < F64_TOL
     assert np.array_equal(res, res.T)
 
 
@@ -56,9 +56,9 @@ def test_dense_sandwich_rows_cols(order):
         cols = rng.choice(k, size=max(1, k // 2), replace=False).astype(np.int32)
         res = tm.DenseMatrix(X).sandwich(d, rows, cols)
         ref = _orc().dense_sandwich(X, d, rows, cols)
-        assert rel_err(res, ref) < F64_TOL
+        assert nat_err(res, ref) < F64_TOL
         Xs = X[:, cols]
-        assert rel_err(res, (Xs.T * d) @ Xs) < F64_TOL
+        assert nat_err(res, (Xs.T * d) @ Xs) < F64_TOL
 
 
 @pytest.mark.parametrize("n,k", [(3000, 32), (50000, 256), (1500, 300)])
@@ -73,7 +73,7 @@ def test_dense_sandwich_f32(n, k):
     res = tm.DenseMatrix(X).sandwich(d)
     assert res.dtype == np.float32
     ref = _orc().dense_sandwich(X.astype(np.float64), d.astype(np.float64), None, None)
-    assert rel_err(res, ref) < 2e-5
+    assert nat_err(res, ref) < 2e-5
 
 
 # ------------------------------------------------------------------ K5 dense matvec
@@ -151,8 +151,8 @@ def test_dense_f_order_stream_paths(dtype, n, k):
     X64 = X.astype(np.float64)
     mf = tm.DenseMatrix(XF)
     ref = X64.T @ (d.astype(np.float64)[:, None] * X64)
-    assert rel_err(mf.sandwich(d), ref) < tol
-    assert rel_err(mf.sandwich(d), _orc().dense_sandwich(XF, d, None, None)) < tol
+    assert nat_err(mf.sandwich(d), ref) < tol
+    assert nat_err(mf.sandwich(d), _orc().dense_sandwich(XF, d, None, None)) < tol
     ref_t = X64.T @ w.astype(np.float64)
     assert np.abs(mf.transpose_matvec(w) - ref_t).max() / max(1.0, np.abs(ref_t).max()) < tol
     wts = rng.random(n).astype(dtype)
@@ -178,12 +178,12 @@ def test_sparse_sandwich(idx_dtype, n, m, dens):
     mat = tm.SparseMatrix(S)
     ref = _orc().sparse_sandwich(S, S.tocsr(), d, None, None)
     res = mat.sandwich(d)
-    assert rel_err(res, ref) < F64_TOL
+    assert nat_err(res, ref) < F64_TOL
     assert np.array_equal(res, res.T)
     rows = _rows_subset(rng, n)
     cols = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
     ref = _orc().sparse_sandwich(S, S.tocsr(), d, rows, cols)
-    assert rel_err(mat.sandwich(d, rows, cols), ref) < F64_TOL
+    assert nat_err(mat.sandwich(d, rows, cols), ref) < F64_TOL
 
 
 def test_sparse_sandwich_reference_seeds():
@@ -217,13 +217,13 @@ def test_csr_dense_sandwich(order, n, m, r):
     sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
     orc = _orc()
     ref = orc.csr_dense_sandwich(S.tocsr(), B, d, None, None, None)
-    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < F64_TOL
-    assert rel_err(dm._cross_sandwich(sm, d, None), ref.T) < F64_TOL
+    assert cross_err(sm._cross_sandwich(dm, d, None), ref, d, S, B) < F64_TOL
+    assert cross_err(dm._cross_sandwich(sm, d, None), ref.T, d, B, S) < F64_TOL
     rows = _rows_subset(rng, n)
     Ac = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
     Bc = np.sort(rng.choice(r, size=max(1, r // 2), replace=False)).astype(np.int32)
     ref = orc.csr_dense_sandwich(S.tocsr(), B, d, rows, Ac, Bc)
-    assert rel_err(sm._cross_sandwich(dm, d, rows, Ac, Bc), ref) < F64_TOL
+    assert cross_err(sm._cross_sandwich(dm, d, rows, Ac, Bc), ref, d, S, B, rows, Ac, Bc) < F64_TOL
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -247,11 +247,11 @@ def test_csr_dense_sandwich_wide_ell(dtype, n, m, r, dens):
     ref = _orc().csr_dense_sandwich(S.tocsr().astype(np.float64), B.astype(np.float64),
                                     d.astype(np.float64), None, None, None)
     tol = F64_TOL if dtype == np.float64 else 1e-4
-    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < tol
+    assert cross_err(sm._cross_sandwich(dm, d, None), ref, d, S, B) < tol
     rows = _rows_subset(rng, n)
     ref_r = _orc().csr_dense_sandwich(S.tocsr().astype(np.float64), B.astype(np.float64),
                                       d.astype(np.float64), rows, None, None)
-    assert rel_err(sm._cross_sandwich(dm, d, rows), ref_r) < tol
+    assert cross_err(sm._cross_sandwich(dm, d, rows), ref_r, d, S, B, rows) < tol
 
 
 def test_very_sparse_block_keeps_the_compact_stream():
@@ -268,7 +268,7 @@ def test_very_sparse_block_keeps_the_compact_stream():
     sm, dm = tm.SparseMatrix(S), tm.DenseMatrix(B)
     assert sm._ell(wide=True) is None
     ref = _orc().csr_dense_sandwich(S.tocsr(), B, d, None, None, None)
-    assert rel_err(sm._cross_sandwich(dm, d, None), ref) < F64_TOL
+    assert cross_err(sm._cross_sandwich(dm, d, None), ref, d, S, B) < F64_TOL
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -291,12 +291,12 @@ def test_f_ordered_dense_block_uses_row_major_twin(dtype):
     dense = mat.matrices[0]
     assert dense._dev().order_f == 1 and dense._dev_c().order_f == 0
     assert dense._dev_c() is dense._dev_c()          # built once
-    assert rel_err(res_twin, ref) < tol
+    assert rel_err(res_twin, ref) < tol and nat_err(res_twin, ref) < tol
     dmod.ROW_MAJOR_TWIN = False
     try:
         mat2 = to_tm_split(specs, idx, dtype)
         assert mat2.matrices[0]._dev_c().order_f == 1
-        assert rel_err(mat2.sandwich(d), ref) < tol
+        assert nat_err(mat2.sandwich(d), ref) < tol
     finally:
         dmod.ROW_MAJOR_TWIN = True
     v = rng.standard_normal(mat.shape[1]).astype(dtype)
@@ -429,7 +429,8 @@ def test_cat_cat(ni, nj, drops):
     orc = _orc()
     for r in (None, rows):
         ref = orc.sandwich_cat_cat(ci, cj, mi.shape[1], mj.shape[1], d, r, drops[0], drops[1])
-        assert rel_err(mi._cross_sandwich(mj, d, r), ref) < F64_TOL
+        assert cross_err(mi._cross_sandwich(mj, d, r), ref, d, ("cat", ci, mi.shape[1], drops[0]),
+                         ("cat", cj, mj.shape[1], drops[1]), r) < F64_TOL
     ones = np.ones(n)
     ref = orc.sandwich_cat_cat(ci, cj, mi.shape[1], mj.shape[1], ones, None, drops[0], drops[1])
     assert np.array_equal(mi._cross_sandwich(mj, ones, None), ref)  # counts: bit-exact
@@ -450,13 +451,14 @@ def test_cat_dense(order, ncat, k):
     d = rng.random(n)
     orc = _orc()
     ref = orc.sandwich_cat_dense(codes, cm.shape[1], d, X, None, None, True)
-    assert rel_err(cm._cross_sandwich(dm, d), ref) < F64_TOL
-    assert rel_err(dm._cross_sandwich(cm, d), ref.T) < F64_TOL
+    cspec = ("cat", codes, cm.shape[1], True)
+    assert cross_err(cm._cross_sandwich(dm, d), ref, d, cspec, X) < F64_TOL
+    assert cross_err(dm._cross_sandwich(cm, d), ref.T, d, X, cspec) < F64_TOL
     rows = _rows_subset(rng, n)
     jc = np.sort(rng.choice(k, size=max(1, k // 2), replace=False)).astype(np.int32)
     lc = np.sort(rng.choice(cm.shape[1], size=max(1, cm.shape[1] // 3), replace=False)).astype(np.int32)
     ref = orc.sandwich_cat_dense(codes, cm.shape[1], d, X, rows, jc, True)[lc]
-    assert rel_err(cm._cross_sandwich(dm, d, rows, lc, jc), ref) < F64_TOL
+    assert cross_err(cm._cross_sandwich(dm, d, rows, lc, jc), ref, d, cspec, X, rows, lc, jc) < F64_TOL
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -492,7 +494,7 @@ def test_multi_cat_dense_wide_kernel(dtype, n, k, ncats):
     tol = F64_TOL if dtype == np.float64 else 1e-4
     for codes, ncol, drop in blocks:
         ref = orc.sandwich_cat_dense(codes, ncol, d.astype(np.float64), Xc, None, None, drop)
-        assert rel_err(res[off:off + ncol], ref) < tol
+        assert cross_err(res[off:off + ncol], ref, d, ("cat", codes, ncol, drop), Xc) < tol
         off += ncol
     assert off == res.shape[0]
 
@@ -510,17 +512,18 @@ def test_cat_sparse(ncat, m):
     d = rng.random(n)
     orc = _orc()
     ref = orc.sandwich_cat_sparse(codes, ncat, d, S.tocsr(), None, None, None)
-    assert rel_err(cm._cross_sandwich(sm, d), ref) < F64_TOL
-    assert rel_err(sm._cross_sandwich(cm, d, None), ref.T) < F64_TOL
+    cspec = ("cat", codes, ncat, False)
+    assert cross_err(cm._cross_sandwich(sm, d), ref, d, cspec, S) < F64_TOL
+    assert cross_err(sm._cross_sandwich(cm, d, None), ref.T, d, S, cspec) < F64_TOL
     rows = _rows_subset(rng, n)
     rc = np.sort(rng.choice(m, size=max(1, m // 2), replace=False)).astype(np.int32)
     lc = np.sort(rng.choice(ncat, size=max(1, ncat // 3), replace=False)).astype(np.int32)
     ref = orc.sandwich_cat_sparse(codes, ncat, d, S.tocsr(), rows, lc, rc)
-    assert rel_err(cm._cross_sandwich(sm, d, rows, lc, rc), ref) < F64_TOL
+    assert cross_err(cm._cross_sandwich(sm, d, rows, lc, rc), ref, d, cspec, S, rows, lc, rc) < F64_TOL
     # the reference computes this term with scipy.sparse (categorical_matrix.py:825-838)
     onehot = sps.csr_matrix((d[codes >= 0], (np.nonzero(codes >= 0)[0], codes[codes >= 0])),
                             shape=(n, ncat))
-    assert rel_err(cm._cross_sandwich(sm, d), (onehot.T @ S.tocsr()).toarray()) < F64_TOL
+    assert cross_err(cm._cross_sandwich(sm, d), (onehot.T @ S.tocsr()).toarray(), d, cspec, S) < F64_TOL
 
 
 # ------------------------------------------------------------------ SplitMatrix, cfg4 shape
@@ -646,7 +649,7 @@ def test_row_restriction_ignores_non_finite_excluded_rows():
     Sc[int(excluded[7]), 3] = 0.0
     clean = [("dense", Xc), ("sparse", sps.csc_matrix(Sc))] + list(specs[2:])
     ref = _orc().split_sandwich([cs.to_oracle_block(s) for s in clean], idx, d, rows)
-    assert rel_err(res, ref) < F64_TOL
+    assert nat_err(res, ref) < F64_TOL
 
 
 def test_sandwich_graph_replay_matches_eager():
@@ -666,16 +669,16 @@ def test_sandwich_graph_replay_matches_eager():
         d = torch.from_numpy(np.random.default_rng(seed).random(20_000)).cuda()
         got = f(d).clone()
         ref = X.sandwich(d)
-        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < F64_TOL
+        assert nat_err(got.cpu().numpy(), ref.cpu().numpy()) < F64_TOL
     rows = _rows_subset(rng, 20_000)
     cols = np.sort(rng.choice(X.shape[1], 40, replace=False))
     fr = X.sandwich_graph(d0, rows, cols)
-    assert rel_err(fr(d0).cpu().numpy(), X.sandwich(d0, rows, cols).cpu().numpy()) < F64_TOL
+    assert nat_err(fr(d0).cpu().numpy(), X.sandwich(d0, rows, cols).cpu().numpy()) < F64_TOL
     # a larger product moves the workspace: the captured graphs must notice and re-capture
     big = tm.DenseMatrix(rng.standard_normal((300_000, 700)))
     big.sandwich(rng.random(300_000))
     d = torch.from_numpy(np.random.default_rng(9).random(20_000)).cuda()
-    assert rel_err(f(d).cpu().numpy(), X.sandwich(d).cpu().numpy()) < F64_TOL
+    assert nat_err(f(d).cpu().numpy(), X.sandwich(d).cpu().numpy()) < F64_TOL
 
 
 def test_sandwich_graph_replay_of_the_round_3_kernels():
@@ -693,7 +696,7 @@ def test_sandwich_graph_replay_of_the_round_3_kernels():
     for seed, shift in ((1, 0.0), (2, 0.3), (3, 0.0)):          # 0.3: negative weights -> f64 kernel at replay
         dh = np.random.default_rng(seed).random(20_000) - shift
         got = f(torch.from_numpy(dh).cuda()).cpu().numpy()
-        assert rel_err(got, _orc().split_sandwich(blocks, idx, dh)) < F64_TOL
+        assert rel_err(got, _orc().split_sandwich(blocks, idx, dh)) < F64_TOL   # (weights of both signs: no natural scale)
 
 
 @pytest.mark.gpu

@@ -270,6 +270,41 @@ def test_deterministic_sparse_self_sandwich(dtype, monkeypatch):
 
 
 @gpu
+def test_deterministic_mode_builds_its_own_twin_for_a_very_sparse_block(monkeypatch):
+    """a block too sparse for the product path's entry twin (padded stream beyond ELL_MAX_PAD x the
+    nonzeros) used to fall through silently to the LDS-atomic kernels under TABMAT_AMD_DETERMINISTIC=1; the mode
+    now builds a twin without that limit, and says so (RuntimeWarning) when no twin can exist at all."""
+    import warnings
+
+    import tabmat_amd as tm
+    import tabmat_amd.categorical_matrix as cmod
+    import tabmat_amd.sparse_matrix as smod
+
+    rng = np.random.default_rng(13)
+    n, m = 2_400_000, 512
+    S = sps.random(n, m, density=0.0005, format="csc", random_state=rng)
+    d = rng.random(n)
+    sm = tm.SparseMatrix(S)
+    # ~600k nonzeros in ~500k (slab, group) blocks of >= 16 slots each: > 8 x nnz slots and > the 4M-slot floor
+    assert sm._ent() is None                       # refused for the products (SlabEnt.from_csr)
+    monkeypatch.setattr(cmod, "DETERMINISTIC", True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = sm.sandwich(d)
+        b = sm.sandwich(d)
+    assert sm._ent_det() is not None
+    assert np.array_equal(a, b) and np.array_equal(a, a.T)
+    want = (S.T.multiply(d)).dot(S).toarray()
+    assert np.abs(a - want).max() / np.abs(want).max() < 1e-12
+    cols = np.sort(rng.choice(m, 40, replace=False)).astype(np.int32)
+    assert np.array_equal(sm.sandwich(d, None, cols), a[np.ix_(cols, cols)])
+    # no twin at all -> a warning, not silence
+    monkeypatch.setattr(smod.SparseMatrix, "_ent_det", lambda self: None)
+    with pytest.warns(RuntimeWarning, match="NOT bit-reproducible"):
+        sm.sandwich(d)
+
+
+@gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,levels", [(9000, 100, (7, 5)), (20_011, 512, (256, 96, 32)), (70, 16, (3,)),
                                         (30_000, 40, (40, 30, 20, 10, 5, 4, 3, 2))])
