@@ -243,6 +243,19 @@ int tm_sparse_sandwich_chunked_f64(const double *cm_data, const int32_t *cm_indi
                                    const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                    const double *d, double *out, void *stream);
 
+/* K2e (round 5): the unrestricted sparse self sandwich of WIDE blocks at a cost proportional to the entries and
+ * PAIRS of nonzeros of a row, as the reference's loop is (ext/sparse.pyx:55-74), instead of rows x tiles: the
+ * output is accumulated tile by tile in LDS (128 x 128, lower triangle of tiles) and the work of tile (I, J) is the
+ * stream of the entries of column chunk I, lane <-> entry; every lane walks its row's list in chunk J (diagonal
+ * tiles: its own row's list up to itself), one LDS atomic per pair.  Operands: cptr int32 [ceil(m / 128)][n + 1] of
+ * the chunk-major twin (tm_sparse_sandwich_chunked_*) and cm_rec int32 [nnz][4], one 16-byte record per
+ * chunk-major entry: f64 {value low word, value high word, column, row}, f32 {value bits, column, row, 0}.
+ * m <= 8192, nnz < 2^31.  out (m, m) is overwritten. */
+int tm_sparse_sandwich_pairs_f32(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                 const float *d, float *out, void *stream);
+int tm_sparse_sandwich_pairs_f64(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                 const double *d, double *out, void *stream);
+
 /* The same product on a static BLOCK LIST (csrc/sparse_blocks.hip): every (row, tile) of the
  * chunk-major twin is cut, once per matrix, into blocks of at most 8 x 8 entries -- block (a, b)
  * pairs entries 8a .. 8a+7 of the row's list in chunk I with entries 8b .. 8b+7 of its list in chunk

@@ -99,6 +99,37 @@ class CsrDev:
             self._cm = cm
         return cm
 
+    def chunk_records(self):
+        """cm_rec int32 [nnz, 4]: one 16-byte record {value, column, row} per entry of the chunk-major twin
+        (f64: value as two words; f32: {value bits, column, row, 0}) for tm_sparse_sandwich_pairs_*.  Built on first
+        use (the rows from the chunk pointers: inside a chunk the entries are in row order), cached.  (Filled
+        column by column: a 2-D gather of more than 2^32 bytes came back scrambled on this stack.)"""
+        cr = getattr(self, "_cm_rec", None)
+        if cr is None:
+            cm_data, cm_ind, cptr = self.chunk_major()
+            dev = cptr.device
+            nnz = int(cm_data.numel())
+            ar = torch.arange(self.n, device=dev, dtype=torch.int32)
+            cr = torch.zeros((nnz, 4), dtype=torch.int32, device=dev)
+            f64 = cm_data.dtype == torch.float64
+            if f64:
+                words = cm_data.view(torch.int32).view(nnz, 2)
+                cr[:, 0] = words[:, 0]
+                cr[:, 1] = words[:, 1]
+                cr[:, 2] = cm_ind
+            else:
+                cr[:, 0] = cm_data.view(torch.int32)
+                cr[:, 1] = cm_ind
+            pos = 0
+            for c in range(int(cptr.shape[0])):
+                k = int(cptr[c, -1].item()) - int(cptr[c, 0].item())
+                if k:
+                    cnt = (cptr[c, 1:] - cptr[c, :-1]).to(torch.int64)
+                    cr[pos:pos + k, 3 if f64 else 2] = torch.repeat_interleave(ar, cnt, output_size=k)
+                pos += k
+            self._cm_rec = cr
+        return cr
+
     def pair_blocks(self, n_wg: int = 0, nw: int = 16, cyclic=None):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of

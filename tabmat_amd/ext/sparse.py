@@ -267,6 +267,20 @@ def sparse_sandwich_blocks(A: CsrDev, d):
     return out
 
 
+def sparse_sandwich_pairs(A: CsrDev, d):
+    """ext/sparse.pyx:17-77, unrestricted, for WIDE blocks: LDS tiles fed by the stream of a chunk's entries, one
+    LDS atomic per pair of nonzeros of a row (tm_sparse_sandwich_pairs_*, csrc/sparse_pairs.hip)."""
+    if A.m == 0 or A.n == 0:
+        return D.zeros((A.m, A.m), A.dtype)
+    out = D.out_buf((A.m, A.m), A.dtype)
+    D.same_float("sparse_sandwich_pairs", A.data, d)
+    _, _, cptr = A.chunk_major()
+    rec = A.chunk_records()
+    call(f"tm_sparse_sandwich_pairs_{D.fsuf(A.data)}", D.p(rec), D.p(cptr), A.n, A.m, int(rec.shape[0]), D.p(d),
+         D.p(out), D.stream_ptr())
+    return out
+
+
 def csc_dense_sandwich_sorted(A: CsrDev, B: DenseDev, d):
     """ext/sparse.pyx:211-260 for blocks with only a few nonzeros per row: column by column on
     the CSC form, a workgroup sums d[k] * A[k, j] * B[k, :] over (a block of) column j's entries
@@ -310,6 +324,36 @@ def direct_sandwich_pays(A: CsrDev) -> bool:
     if per_row / nch > 0.6:
         return False
     return pairs / 15e9 < n * (nch * (nch + 1) / 2) * 15e-12
+
+
+# the pair-stream form of the unrestricted sparse self sandwich (csrc/sparse_pairs.hip): "auto" / "0" / "1"
+K2_PAIRS = "auto"
+
+
+def pairs_sandwich_pays(A: CsrDev) -> bool:
+    """Cost model of the self-sandwich kernels for WIDE blocks (measured at 2M rows, profiles/r5_k2_pairs.txt):
+      tiled (chunked kernel)   ~20 ps per (row, tile); block list ~1.15 ps per pair when rows hold > 4.5 entries
+                               per 128-column chunk
+      direct                   one L2 atomic per pair at ~21 G/s
+      pairs (this kernel)      ~2.3 ps per visit of an entry (once per tile of its chunk's tile row), more when
+                               the chunk's entries are thin over the rows (the gathers of d / the chunk pointers
+                               span rows without entries: x (1.6 / k)^0.8 for k entries per row and chunk, at
+                               most x 6) + 2.7 ps per pair + ~0.8 us per tile (LDS tile set-up and partials)."""
+    if K2_PAIRS != "auto":
+        return K2_PAIRS == "1" and A.m <= 8192 and 0 < int(A.data.numel()) < 2**31
+    nnz, n, m = int(A.data.numel()), A.n, A.m
+    if n == 0 or nnz == 0 or m <= 1024 or m > 8192 or nnz >= 2**31:
+        return False
+    nch = (m + 127) // 128
+    parts = nch * (nch + 1) / 2
+    per_row = nnz / n
+    k = per_row / nch
+    pairs = n * per_row * (per_row + 2.0) / 2.0
+    t_pairs = (nnz * (nch + 1) / 2.0 * 2.3e-12 * min(6.0, max(1.0, (1.6 / k) ** 0.8)) + pairs * 2.7e-12
+               + parts * 0.8e-6)
+    t_direct = pairs / 21e9
+    t_tiled = pairs * 1.15e-12 if k > 4.5 and nch <= 32 else n * parts * 20e-12
+    return t_pairs < 0.8 * min(t_direct, t_tiled)
 
 
 def transpose_square_dot_weights(A: CsrDev, weights):

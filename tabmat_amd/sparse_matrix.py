@@ -345,6 +345,23 @@ class SparseMatrix(MatrixBase):
             xs.csc_densify_cols(rws, vls, seg, torch.arange(w, dtype=torch.int32, device=A.data.device),
                                 mx, T)
             return xd.dense_sandwich(DenseDev(T, self.shape[0], w, 0), d, rows, None)
+        pp = getattr(self, "_pairs_pay", None)
+        if pp is None:
+            pp = self._pairs_pay = xs.pairs_sandwich_pays(A)
+        if pp and (rows is None or D.nlen(rows) > 0.3 * self.shape[0]):
+            # wide block: the pair-stream kernel (cost follows the entries and pairs of a row, csrc/sparse_pairs.hip);
+            # a long row list is a masked d (the kernel never touches the entries of a row with d == 0); short
+            # ones keep the row-list kernels below
+            if rows is not None:
+                dm = torch.zeros_like(d)
+                r64 = rows.to(torch.int64)
+                dm.index_add_(0, r64, d[r64])
+                d = dm
+            res = xs.sparse_sandwich_pairs(A, d)
+            if cols is not None:
+                c64 = cols.to(torch.int64)
+                res = res[c64][:, c64].contiguous()
+            return res
         pays = getattr(self, "_direct_pays", None)
         if pays is None:
             pays = self._direct_pays = xs.direct_sandwich_pays(A)
