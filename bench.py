@@ -147,8 +147,9 @@ def kernel_ops(mat, d):
                     # same choice as the product (`_entblk` is False when the twin was refused)
                     ent = mw._ent() if getattr(mw, "_entblk", None) else None
                     if ent is not None:
-                        fused.append((f"allcats_x_sparse{i}", lambda ent=ent: xsplit.multi_cat_sparse_sandwich_ent(
-                            cats, d, ent)))
+                        pk = xsplit.pack_codes(cats)                          # as SplitMatrix._fused_cats does
+                        fused.append((f"allcats_x_sparse{i}", lambda ent=ent, pk=pk: xsplit.multi_cat_sparse_sandwich_ent(
+                            cats, d, ent, pk)))
                     else:
                         fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
                             cats, d, mw._slab())))

@@ -608,6 +608,21 @@ int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
                                          int64_t mk, double *out, void *stream);
+/* The same with the categoricals' codes PACKED (round 5; at most 3 categoricals, 1022 stacked levels):
+ * packed[row] = sum_c field_c << (10 c), field_c = the stacked output row of the row's level in categorical c
+ * (offset of c + code - drop_first) or 1023 when the row has none there.  tm_multi_cat_pack_codes builds the
+ * vector once per set of categoricals (it depends on the codes only); the kernel then gathers ONE word per entry
+ * slot instead of one code per categorical. */
+int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first, int n_cats,
+                            int64_t n, uint32_t *packed, void *stream);
+int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
+                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          int64_t mk, const uint32_t *packed, float *out, void *stream);
+int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
+                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          int64_t mk, const uint32_t *packed, double *out, void *stream);
 
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,

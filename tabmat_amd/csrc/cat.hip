@@ -951,7 +951,11 @@ template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
     const unsigned *__restrict__ bstart, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
-    F *__restrict__ ws, int64_t stride) {
+    F *__restrict__ ws, int64_t stride, const unsigned *__restrict__ packed) {
+    // packed (round 5, may be NULL; NC <= 3): packed[row] = the tile rows of the row's levels, 10 bits each (1023 =
+    // none: missing / dropped level), built once per matrix by tm_multi_cat_pack_codes -- ONE gather per slot
+    // instead of NC (the kernel is bound by its dependent loads: no gathers at all 0.60 ms against 1.02,
+    // profiles/r4_catsparse.txt)
     constexpr int GC = 32, TSTR = GC + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][33]
@@ -989,6 +993,15 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
             for (int u = 0; u < U; ++u) {
                 const unsigned row = t.m[u] >> 4;
                 t.dk[u] = d[row];
+                if (NC <= 3 && packed != nullptr) {
+                    const unsigned pk = packed[row];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int f = (int)((pk >> (10 * c)) & 1023u);
+                        t.c[u][c] = f == 1023 ? -1 : f - cs.off[c];
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) t.c[u][c] = cs.codes[c][row] - cs.drop[c];
             }
@@ -1322,11 +1335,30 @@ static int run_multi_cat_sparse(const void *const *h_codes, const int64_t *h_nco
     return TM_OK;
 }
 
+// packed[row] = sum_c field_c << (10 c), field_c = tile row of the row's level in categorical c (cs.off[c] + code -
+// drop) or 1023 when the row has none there (missing code, dropped first level)
+__global__ __launch_bounds__(256) void multi_cat_pack_codes_kernel(CatSet cs, int64_t n, unsigned *__restrict__ out) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            unsigned f = 1023u;
+            if (c < cs.n_cats) {
+                const int col = cs.codes[c][r] - cs.drop[c];
+                if (col >= 0 && col < cs.ncol[c]) f = (unsigned)(cs.off[c] + col);
+            }
+            pk |= f << (10 * c);
+        }
+        out[r] = pk;
+    }
+}
+
 // entry-twin form (see multi_cat_sparse_ent_kernel): out [total levels][mk], mk = 16 * groups kernel columns
 template <typename F>
 static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
                                     int n_cats, int64_t n, const F *d, const F *vals, const unsigned *meta,
-                                    const unsigned *bstart, int64_t mk, F *out, hipStream_t st) {
+                                    const unsigned *bstart, int64_t mk, F *out, hipStream_t st,
+                                    const unsigned *packed = nullptr) {
     CatSet cs;
     int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
     if (rc) return rc;
@@ -1371,8 +1403,9 @@ static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h
         TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
+    TM_REQUIRE(packed == nullptr || (n_cats <= 3 && cs.total < 1023), "packed codes: at most 3 categoricals, 1022 levels");
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds, st, cs, d, vals, meta,
-                       bstart, n_groups, n_slabs, spb, ws, stride);
+                       bstart, n_groups, n_slabs, spb, ws, stride, packed);
     prof_end(st);
     TM_LAUNCH_CHECK();
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_pairs, tmp, (int64_t)n_pairs * stride, false, st);
@@ -1543,6 +1576,32 @@ int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64
                                          int64_t mk, double *out, void *stream) {
     return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
                                             out, as_stream(stream));
+}
+int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first, int n_cats,
+                            int64_t n, uint32_t *packed, void *stream) {
+    CatSet cs;
+    int rc = make_catset(h_codes, h_ncols, h_drop_first, n_cats, &cs);
+    if (rc) return rc;
+    TM_REQUIRE(n_cats <= 3 && cs.total < 1023, "packed codes: at most 3 categoricals, 1022 stacked levels");
+    if (n == 0) return TM_OK;
+    hipLaunchKernelGGL(multi_cat_pack_codes_kernel, dim3((unsigned)std::min<int64_t>(4 * NUM_CU, ceil_div(n, 256))),
+                       dim3(256), 0, as_stream(stream), cs, n, packed);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
+                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          int64_t mk, const uint32_t *packed, float *out, void *stream) {
+    return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk, out,
+                                           as_stream(stream), packed);
+}
+int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
+                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          int64_t mk, const uint32_t *packed, double *out, void *stream) {
+    return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
+                                            out, as_stream(stream), packed);
 }
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

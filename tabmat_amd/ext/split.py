@@ -420,15 +420,37 @@ def multi_cat_sparse_sandwich(cats, d, S: SlabCsc):
     return res
 
 
-def multi_cat_sparse_sandwich_ent(cats, d, E):
+PACKED_CODES = True       # categorical x sparse on the entry twin: the codes of <= 3 categoricals as one word per row
+
+
+def pack_codes(cats):
+    """uint32 device vector for tm_multi_cat_sparse_sandwich_entp_* (None when the set does not qualify: more than
+    3 categoricals or 1022 stacked levels).  Depends on the codes only: the caller caches it."""
+    import torch
+
+    total = sum(int(c[1]) for c in cats)
+    if not PACKED_CODES or len(cats) > 3 or total >= 1023 or len(cats) == 0:
+        return None
+    codes, ncols, drop, n = _cat_args(cats)
+    nrow = int(cats[0][0].numel())
+    out = torch.empty((nrow,), dtype=torch.int32, device=cats[0][0].device)
+    call("tm_multi_cat_pack_codes", codes, ncols, drop, n, nrow, D.p(out), D.stream_ptr())
+    return out
+
+
+def multi_cat_sparse_sandwich_ent(cats, d, E, packed=None):
     """The same on the ENTRY twin of the sparse block (E: SlabEnt, the stream of the sparse x dense kernel of
-    round 4): stacked [sum(n_cols) x E.m]; no slab-form twin needed."""
+    round 4): stacked [sum(n_cols) x E.m]; no slab-form twin needed.  packed: the result of pack_codes(cats)."""
     total = sum(int(c[1]) for c in cats)
     if total == 0 or E.m == 0 or E.n == 0:
         return D.zeros((total, E.m), E.vals.dtype)
     res = D.out_buf((total, E.mk), E.vals.dtype)
     codes, ncols, drop, n = _cat_args(cats)
     D.same_float("multi_cat_sparse_sandwich_ent", E.vals, d)
+    if packed is not None:
+        call(f"tm_multi_cat_sparse_sandwich_entp_{D.fsuf(E.vals)}", codes, ncols, drop, n, E.n, D.p(d),
+             D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.mk, D.p(packed), D.p(res), D.stream_ptr())
+        return res[:, E.inv]
     call(f"tm_multi_cat_sparse_sandwich_ent_{D.fsuf(E.vals)}", codes, ncols, drop, n, E.n, D.p(d),
          D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.mk, D.p(res), D.stream_ptr())
     return res[:, E.inv]      # kernel columns -> the block's columns

@@ -491,7 +491,11 @@ class SplitMatrix(MatrixBase):
                     for mo in self.matrices)):
                 ent = mw._ent()
             if ent is not None:
-                return xsplit.multi_cat_sparse_sandwich_ent(cats, d_eff, ent)
+                pk_cache = self.__dict__.setdefault("_packed_codes", {})
+                key = tuple(cat_ids)
+                if key not in pk_cache:          # (static per set of categoricals: one word of tile rows per row)
+                    pk_cache[key] = xsplit.pack_codes(cats)
+                return xsplit.multi_cat_sparse_sandwich_ent(cats, d_eff, ent, pk_cache[key])
             return xsplit.multi_cat_sparse_sandwich(cats, d_eff, mw._slab())
         return None
 

@@ -339,6 +339,19 @@ def test_cat_sparse_cross_terms_on_the_entry_twin(n, m, levels, dtype):
     assert got.shape == want.shape
     tol = 1e-10 if dtype == np.float64 else 3e-5
     assert np.abs(got - want).max() / max(np.abs(want).max(), 1e-300) < tol
+    # round 5: the codes of up to 3 categoricals packed into one word per row (tm_multi_cat_pack_codes / _entp_)
+    pk = xsplit.pack_codes(cats)
+    assert (pk is not None) == (len(levels) <= 3)
+    if pk is not None:
+        pkh = pk.cpu().numpy().view(np.uint32)
+        off = 0
+        for k, (ct, ncol, drop) in enumerate(cats):
+            col = ct.cpu().numpy().astype(np.int64) - int(drop)
+            want_f = np.where(col >= 0, off + col, 1023)
+            assert np.array_equal((pkh >> (10 * k)) & 1023, want_f)
+            off += ncol
+        got_p = xsplit.multi_cat_sparse_sandwich_ent(cats, torch.from_numpy(d).cuda(), tw, pk).cpu().numpy()
+        assert np.abs(got_p - want).max() / max(np.abs(want).max(), 1e-300) < tol
 
 
 @gpu
