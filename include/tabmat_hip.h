@@ -465,6 +465,44 @@ int tm_csr_col_sq_f64(const double *csr_data, const int32_t *csr_indices,
                       const int64_t *csr_indptr, int64_t n, int64_t m, const double *w,
                       double *out, void *stream);
 
+/* int64 COLUMN-INDEX forms of the sparse entry points (ext/sparse.pyx:13-15 `win_integral`: the reference's Cython
+ * functions take int32 or int64 index arrays).  Every kernel reads int32 column indices; a binding that holds int64
+ * ones should narrow them once per block (tm_index_narrow_i64) and call the int32 symbols.  These forms do it per
+ * call, on the device, into a scratch buffer the library owns per (device, stream) -- one extra pass over the index
+ * array -- and then run the int32 kernel; nnz = number of stored entries (= csr_indptr[n]).  A column index outside
+ * [0, m) is clamped to 0 and remembered: tm_index_check_i64 reports it (synchronises the stream, clears the flag). */
+int tm_index_check_i64(void *stream, int32_t *h_bad);
+int tm_sparse_sandwich_i64_f32(const float *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr,
+                               int64_t n, int64_t m, int64_t nnz, const float *d, const int32_t *rows,
+                               int64_t n_rows, const int32_t *cols, int64_t n_cols, float *out, void *stream);
+int tm_sparse_sandwich_i64_f64(const double *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr,
+                               int64_t n, int64_t m, int64_t nnz, const double *d, const int32_t *rows,
+                               int64_t n_rows, const int32_t *cols, int64_t n_cols, double *out, void *stream);
+int tm_csr_dense_sandwich_i64_f32(const float *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr,
+                                  int64_t n, int64_t m, int64_t nnz, const float *B, int64_t r, int order_f,
+                                  const float *d, const int32_t *rows, int64_t n_rows, const int32_t *A_cols,
+                                  int64_t nA, const int32_t *B_cols, int64_t nB, float *out, void *stream);
+int tm_csr_dense_sandwich_i64_f64(const double *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr,
+                                  int64_t n, int64_t m, int64_t nnz, const double *B, int64_t r, int order_f,
+                                  const double *d, const int32_t *rows, int64_t n_rows, const int32_t *A_cols,
+                                  int64_t nA, const int32_t *B_cols, int64_t nB, double *out, void *stream);
+int tm_csr_matvec_i64_f32(const float *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                          int64_t m, int64_t nnz, const float *v, const int32_t *rows, int64_t n_rows,
+                          const int32_t *cols, int64_t n_cols, float *out, void *stream);
+int tm_csr_matvec_i64_f64(const double *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                          int64_t m, int64_t nnz, const double *v, const int32_t *rows, int64_t n_rows,
+                          const int32_t *cols, int64_t n_cols, double *out, void *stream);
+int tm_csr_rmatvec_i64_f32(const float *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                           int64_t m, int64_t nnz, const float *v, const int32_t *rows, int64_t n_rows,
+                           const int32_t *cols, int64_t n_cols, float *out, void *stream);
+int tm_csr_rmatvec_i64_f64(const double *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                           int64_t m, int64_t nnz, const double *v, const int32_t *rows, int64_t n_rows,
+                           const int32_t *cols, int64_t n_cols, double *out, void *stream);
+int tm_csr_col_sq_i64_f32(const float *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                          int64_t m, int64_t nnz, const float *w, float *out, void *stream);
+int tm_csr_col_sq_i64_f64(const double *csr_data, const int64_t *csr_indices, const int64_t *csr_indptr, int64_t n,
+                          int64_t m, int64_t nnz, const double *w, double *out, void *stream);
+
 /* =====================================================================================
  * Categorical block  (reference: ext/categorical.pyx, ext/split.pyx,
  * ext/cat_split_helpers-tmpl.cpp).  codes[n] int32: -1 = missing (contributes nothing);

@@ -205,3 +205,38 @@ def test_centred_c_abi_entry_points_match_explicit_centring():
     r, cc = rows.cpu().numpy(), cols.cpu().numpy()
     w5 = (Xc[np.ix_(r, cc)].T * d[r]) @ Xc[np.ix_(r, cc)]
     assert nat_err(g5.cpu().numpy(), w5) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order,n,k", [("F", 6000, 80), ("F", 6001, 37), ("C", 5000, 300), ("F", 4000, 200),
+                                       ("C", 3000, 18), ("C", 7000, 131)])
+def test_generic_centred_syrk_every_load_mode(dtype, order, n, k, monkeypatch):
+    """tm_dense_sandwich_centered_{f32,f64} through every load mode of the generic MFMA syrk: column-major vector
+    loads (n a multiple of the vector) and element loads (odd n) WITHOUT the row-major twin, 128-column panels of a
+    wide block (contiguous offsets and column lists), row lists and column lists -- against explicit centring."""
+    import tabmat_amd.dense_matrix as dmod
+    from tabmat_amd.ext import dense as xd
+    from tabmat_amd.ext._types import DenseDev
+
+    monkeypatch.setattr(dmod, "ROW_MAJOR_TWIN", False)
+    rng = np.random.default_rng(n + k)
+    X = _dense_cols(rng, n, k, order).astype(dtype)
+    c = np.round(X.astype(np.float64).mean(axis=0), 2).astype(dtype)
+    Xc = (X - c[None, :]).astype(dtype).astype(np.float64)      # (the kernel rounds x - c to the block's dtype)
+    d = rng.random(n).astype(dtype)
+    d64 = d.astype(np.float64)
+    dev = DenseDev.from_host(X)
+    assert bool(dev.order_f) == (order == "F")
+    dd, cd = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    want = (Xc.T * d64) @ Xc
+    assert nat_err(xd.dense_sandwich(dev, dd, None, None, center=cd).cpu().numpy(), want) < tol
+    rows = np.sort(rng.choice(n, n // 7, replace=False)).astype(np.int32)
+    cols = np.sort(rng.choice(k, max(2, (2 * k) // 3), replace=False)).astype(np.int32)
+    rd, cld = torch.from_numpy(rows).cuda(), torch.from_numpy(cols).cuda()
+    w_r = (Xc[rows].T * d64[rows]) @ Xc[rows]
+    assert nat_err(xd.dense_sandwich(dev, dd, rd, None, center=cd).cpu().numpy(), w_r) < tol
+    w_c = (Xc[:, cols].T * d64) @ Xc[:, cols]
+    assert nat_err(xd.dense_sandwich(dev, dd, None, cld, center=cd).cpu().numpy(), w_c) < tol
+    w_rc = (Xc[np.ix_(rows, cols)].T * d64[rows]) @ Xc[np.ix_(rows, cols)]
+    assert nat_err(xd.dense_sandwich(dev, dd, rd, cld, center=cd).cpu().numpy(), w_rc) < tol
