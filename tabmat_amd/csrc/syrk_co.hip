@@ -35,7 +35,7 @@ constexpr int CO_T = 36;                  // lower-triangular 16 x 16 tiles of 8
 constexpr int CO_NWAVES = 4;
 constexpr int CO_THREADS = CO_NWAVES * 64;
 constexpr int CO_CHUNK = CO_RS * CO_LDW;  // doubles per LDS buffer
-constexpr size_t CO_LDS = sizeof(double) * (size_t)(2 * CO_CHUNK + 2 * CO_RS) + 16;
+constexpr size_t CO_LDS = sizeof(double) * (size_t)(2 * CO_CHUNK + 2 * CO_RS) + 32 + sizeof(double) * CO_W;   // + slot, centres
 
 typedef double co_acc_t __attribute__((ext_vector_type(4)));
 typedef double co_vec2 __attribute__((ext_vector_type(2)));
@@ -64,6 +64,9 @@ __device__ __forceinline__ void co_mfma_set(const double (&xa)[8], const double 
     }
 }
 
+// CEN: the columns are centred on the way into LDS (a template parameter, not a run-time branch: with the test inside
+// the load loop the uncentred kernel went from 3.37 to 4.93 ms, profiles/r5_bench_cfg4_kernel_stats.txt of the first run)
+template <bool CEN>
 __global__ __launch_bounds__(CO_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_cols,
                     const double *__restrict__ d, int n_items, unsigned *__restrict__ counter,
@@ -92,9 +95,12 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
     // center != NULL: the columns are centred on the way into LDS (x - c; this thread always stages the same
     // two columns), so the product and the column sums are those of X - 1 c' (StandardizedMatrix.sandwich,
     // standardized_mat.py:123-172, without the mean-sized cancellation)
-    co_vec2 cen = co_vec2{0.0, 0.0};
-    if (center != nullptr && (tid & 63) * 2 < n_cols)
-        cen = *reinterpret_cast<const co_vec2 *>(center + (tid & 63) * 2);
+    // (the centres sit in LDS and are read where a chunk is staged: held in registers over the chunk loop they
+    // were the four registers too many for the 168 this kernel is capped at)
+    double *cl = reinterpret_cast<double *>(slot + 4);          // [CO_W]
+    if constexpr (CEN) {
+        if (tid < CO_W) cl[tid] = tid < n_cols ? center[tid] : 0.0;
+    }
 
     // ---- the workgroup's chunk stream: items of CO_CPI chunks, ids from the atomic counter
     unsigned idL = blockIdx.x;            // item of the next chunk to load
@@ -120,7 +126,6 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
             co_vec2 v = co_vec2{0.0, 0.0};
             if (t < n && c < n_cols) {
                 v = __builtin_nontemporal_load(reinterpret_cast<const co_vec2 *>(X + t * m + c));
-                if (center != nullptr) v -= cen;
             }
             stage[i] = v;
         }
@@ -135,10 +140,13 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
     auto store_chunk = [&](int buf) {
         double *lb = lds + buf * CO_CHUNK;
         if (tid < CO_RS) dl[buf * CO_RS + tid] = dstage;
+        co_vec2 cen = co_vec2{0.0, 0.0};
+        if constexpr (CEN) cen = *reinterpret_cast<const co_vec2 *>(cl + (tid & 63) * 2);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int q = tid + i * CO_THREADS;
-            *reinterpret_cast<co_vec2 *>(lb + (q >> 6) * CO_LDW + (q & 63) * 2) = stage[i];
+            // (rows beyond n hold 0 - c: their d is 0, so they add nothing)
+            *reinterpret_cast<co_vec2 *>(lb + (q >> 6) * CO_LDW + (q & 63) * 2) = CEN ? stage[i] - cen : stage[i];
         }
     };
 
@@ -304,10 +312,11 @@ static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, 
     double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(wsv) + 256);
     double *cpart = part + (size_t)grid * CO_T * 256;
     TM_HIP(hipMemsetAsync(counter, 0, 256, st));
-    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(syrk_co_kernel),
+    auto kern = center ? &syrk_co_kernel<true> : &syrk_co_kernel<false>;
+    TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS));
     prof_begin(st);
-    hipLaunchKernelGGL(syrk_co_kernel, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, ldx,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CO_THREADS), CO_LDS, st, X, n, ldx,
                        (int)m, d, n_items, counter, part, cpart, wg_log_ptr(), only_if, center);
     prof_end(st);
     TM_LAUNCH_CHECK();
