@@ -8,7 +8,8 @@ from tabmat_amd import synth
 N = 2_000_000
 for name, kw in (("cfg4 shape", dict()), ("density 20 %", dict(density=0.20)),
                  ("sparse 2048 cols @ 1.25 %", dict(k_sparse=2048, density=0.0125)),
-                 ("dense 256 cols", dict(k_dense=256)), ("sparse 4096 cols @ 0.2 %", dict(k_sparse=4096, density=0.002))):
+                 ("dense 256 cols", dict(k_dense=256)), ("sparse 4096 cols @ 0.2 %", dict(k_sparse=4096, density=0.002)),
+                 ("sparse 8192 cols @ 0.05 %", dict(k_sparse=8192, density=0.0005))):
     X = synth.mixed_split(N, **kw)
     d = torch.rand(N, dtype=torch.float64, device="cuda")
     for _ in range(2):
