@@ -113,8 +113,8 @@ int tm_dense_sandwich_f64(const double *X, int64_t n, int64_t m, int order_f, co
                           const int32_t *rows, int64_t n_rows, const int32_t *cols,
                           int64_t n_cols, double *out, void *stream);
 
-/* The same product for an unrestricted, 16-byte aligned, C-ordered f64 block of an even number
- * m <= 128 of columns, as a kernel sized to SHARE its compute units with an LDS- or HBM-bound
+/* The same product for an unrestricted, 16-byte aligned, C-ordered f64 block of m <= 128 columns
+ * (any parity since round 5), as a kernel sized to SHARE its compute units with an LDS- or HBM-bound
  * partner that runs on another stream (27.8 KB of LDS, <= 168 registers, work items handed out
  * through an atomic counter): the dense term of SplitMatrix.sandwich (split_matrix.py:337-354,
  * ext/dense_helpers-tmpl.cpp:266-311) overlapped with the sparse / categorical terms.
@@ -122,8 +122,8 @@ int tm_dense_sandwich_f64(const double *X, int64_t n, int64_t m, int order_f, co
 int tm_dense_sandwich_co_f64(const double *X, int64_t n, int64_t m, const double *d, double *out,
                              double *colsum, void *stream);
 
-/* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered f64 block of an even number m <= 128 of
- * columns on the INT8 matrix cores (Ozaki-style slicing): diag(sqrt d) X in 40-bit fixed point per
+/* X' diag(d) X of an unrestricted, 16-byte aligned, C-ordered f64 block of m <= 128 columns (any parity
+ * since round 5) on the INT8 matrix cores (Ozaki-style slicing): diag(sqrt d) X in 40-bit fixed point per
  * column (scale from colmax[i] = max_r |X[r][i]|, length m, computed once per block by the caller,
  * and from max d), five balanced base-256 digits per entry, the 22 digit-pair products of weight
  * >= 2^16 accumulated exactly in int32 with v_mfma_i32_16x16x64_i8 and folded into f64 every 2048

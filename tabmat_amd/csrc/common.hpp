@@ -53,13 +53,14 @@ void prof_hold(bool on);      // keep the recorded pair on the current kernel wh
 // integer tuning knob set with tm_tune_set (default when unset)
 int64_t tune(const char *key, int64_t dflt);
 
-// K1c (syrk_co.hip): X' diag(d) X of an unrestricted C-ordered f64 block of an even number of
-// columns <= 128; colsum (may be NULL) receives X' d.  syrk_co_ok() says whether a block qualifies.
+// K1c (syrk_co.hip): X' diag(d) X of an unrestricted C-ordered f64 block of <= 128 columns (any parity since
+// round 5: the 16-byte loads of an odd-width block start at 8-byte aligned addresses, which the hardware takes);
+// colsum (may be NULL) receives X' d.  syrk_co_ok() says whether a block qualifies.
 // center (may be NULL): per-column centres c -- the product (and column sums) of X - 1 c'.
 int run_syrk_co(const double *X, int64_t n, int64_t m, const double *d, double *out,
                 double *colsum, hipStream_t st, const double *center = nullptr);
 inline bool syrk_co_ok(const void *X, int64_t m) {
-    return m > 0 && m <= 128 && m % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    return m > 0 && m <= 128 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
 }
 // ... and pays: the kernel always works on the 36 tiles of a 128-column panel, so narrower blocks
 // stay with the syrk_kernel instantiations of 16 / 32 / 64 columns

@@ -152,7 +152,9 @@ __device__ __forceinline__ void syrk_wave_main(
 }
 
 // One workgroup: rows [blockIdx.x * rows_per_block, +rows_per_block) of the row list.
-template <typename F, int NBLK, int MODE, bool RECT>
+// XT (round 5): the extras of the load stage -- per-column centres and the odd-width row-end pair -- are compiled in
+// only where a call needs them (run-time tests in the load loop cost the plain kernel 6-9 % at 32 / 64 columns).
+template <typename F, int NBLK, int MODE, bool RECT, bool XT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void syrk_kernel(const F *__restrict__ X, int64_t n, int64_t m,
                                                    const F *__restrict__ d,
                                                    const int32_t *__restrict__ rows,
@@ -212,8 +214,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     // (streamed once: nontemporal, 3.68 -> 3.60 ms at cfg4)
                     const int64_t xc = c < 128 ? coff0 + c : coff1 + c - 128;
-                    v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(X + row * m + xc));
-                    if (center != nullptr) v -= *reinterpret_cast<const vec_t *>(center + xc);
+                    if (XT && sizeof(F) == 8 && (m & 1) && xc + C::VEC > m && row + 1 >= n) {
+                        // odd width (round 5): the pair that straddles the end of the LAST row is one element
+                        // (elsewhere its second half is the next row's first entry: the padded column, dropped)
+                        v[0] = X[row * m + xc];
+                    } else {
+                        v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(X + row * m + xc));
+                    }
+                    if (XT && center != nullptr) {
+                        if (sizeof(F) == 8 && (m & 1) && xc + C::VEC > m) v[0] -= center[xc];
+                        else v -= *reinterpret_cast<const vec_t *>(center + xc);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < C::VEC; ++e) stage[i * C::VEC + e] = v[e];
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                         for (int e = 0; e < C::VEC; ++e)
                             if (t + e < t1) v[e] = src[e];
                     }
-                    if (center != nullptr) {
+                    if (XT && center != nullptr) {
                         const F cc = center[c];
 #pragma unroll
                         for (int e = 0; e < C::VEC; ++e)
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     const int64_t col = cols ? (int64_t)cols[c] : c;
                     v = X[row * m + col];
-                    if (center != nullptr) v -= center[col];
+                    if (XT && center != nullptr) v -= center[col];
                 }
                 stage[i] = v;
             }
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
                     const int64_t row = rows ? (int64_t)rows[t] : t;
                     const int64_t col = cols ? (int64_t)cols[c] : c;
                     v = X[col * n + row];
-                    if (center != nullptr) v -= center[col];
+                    if (XT && center != nullptr) v -= center[col];
                 }
                 stage[i] = v;
             }
@@ -428,7 +439,9 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
     nblk = ceil_div(n_iter, rpb);
     F *part = reinterpret_cast<F *>(wsbase + ws_off);   // [nblk][T][256]
     F *tmp = part + (size_t)nblk * C::T * 256;          // [T][256]
-    const bool vec_ok = !order_f && cols == nullptr && (m % C::VEC == 0) &&
+    // (float64 rows of an odd width start at 8-byte aligned addresses every other row: the 16-byte loads take
+    // that -- 4M x 63: 1.2 ms through the element loads, see profiles/r5_odd_widths.txt)
+    const bool vec_ok = !order_f && cols == nullptr && (m % C::VEC == 0 || sizeof(F) == 8) &&
                         ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     // (the 256-column f32 panel has no registers to spare for the column-major addressing)
     const bool fvec_ok = order_f && cols == nullptr && rows == nullptr && (n % C::VEC == 0) &&
@@ -447,10 +460,18 @@ static int launch_syrk(const F *X, int64_t n, int64_t m, int order_f, const F *d
         return TM_OK;
     };
     int rc;
-    if (mode == LOAD_C_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_C_VEC, RECT>);
-    else if (mode == LOAD_C_GEN) rc = go(&syrk_kernel<F, NBLK, LOAD_C_GEN, RECT>);
-    else if (mode == LOAD_F_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_F_VEC, RECT>);
-    else rc = go(&syrk_kernel<F, NBLK, LOAD_F_GEN, RECT>);
+    const bool xt = center != nullptr || (sizeof(F) == 8 && (m & 1) && mode == LOAD_C_VEC);
+    if (xt) {
+        if (mode == LOAD_C_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_C_VEC, RECT, true>);
+        else if (mode == LOAD_C_GEN) rc = go(&syrk_kernel<F, NBLK, LOAD_C_GEN, RECT, true>);
+        else if (mode == LOAD_F_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_F_VEC, RECT, true>);
+        else rc = go(&syrk_kernel<F, NBLK, LOAD_F_GEN, RECT, true>);
+    } else {
+        if (mode == LOAD_C_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_C_VEC, RECT, false>);
+        else if (mode == LOAD_C_GEN) rc = go(&syrk_kernel<F, NBLK, LOAD_C_GEN, RECT, false>);
+        else if (mode == LOAD_F_VEC) rc = go(&syrk_kernel<F, NBLK, LOAD_F_VEC, RECT, false>);
+        else rc = go(&syrk_kernel<F, NBLK, LOAD_F_GEN, RECT, false>);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL((syrk_reduce_kernel<F>), dim3(C::T, 4), dim3(64, 16), 0, st, part, (int)nblk,
                        C::T, tmp);
@@ -558,7 +579,7 @@ static int run_dense_sandwich(const F *X, int64_t n, int64_t m, int order_f, con
     // kernels (a column list would send them down the element-wise load path: 5.9 instead of
     // 3.4 ms for 2M x 256 f64)
     constexpr int VECW = 16 / (int)sizeof(F);
-    const bool contiguous = cols == nullptr && !order_f && m % VECW == 0 &&
+    const bool contiguous = cols == nullptr && !order_f && (m % VECW == 0 || sizeof(F) == 8) &&
                             (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     for (int a = 0; a < np; ++a) {
         const int wa = (int)std::min<int64_t>(PW, n_cols - (int64_t)a * PW);

@@ -66,7 +66,10 @@ __device__ __forceinline__ void co_mfma_set(const double (&xa)[8], const double 
 
 // CEN: the columns are centred on the way into LDS (a template parameter, not a run-time branch: with the test inside
 // the load loop the uncentred kernel went from 3.37 to 4.93 ms, profiles/r5_bench_cfg4_kernel_stats.txt of the first run)
-template <bool CEN>
+// ODD: an odd number of columns -- the pair of columns that straddles the end of a row holds the next row's first
+// entry in its second half (the padded column: its tiles are dropped), except behind the LAST row, where nothing may
+// be read: that one pair is fetched as a single element.
+template <bool CEN, bool ODD>
 __global__ __launch_bounds__(CO_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_cols,
                     const double *__restrict__ d, int n_items, unsigned *__restrict__ counter,
@@ -124,7 +127,9 @@ void syrk_co_kernel(const double *__restrict__ X, int64_t n, int64_t m, int n_co
             const int r = q >> 6, c = (q & 63) * 2;
             const int64_t t = tb + r;
             co_vec2 v = co_vec2{0.0, 0.0};
-            if (t < n && c < n_cols) {
+            if (ODD && t + 1 >= n && c + 1 >= n_cols) {
+                if (t < n && c < n_cols) v[0] = X[t * m + c];
+            } else if (t < n && c < n_cols) {
                 v = __builtin_nontemporal_load(reinterpret_cast<const co_vec2 *>(X + t * m + c));
             }
             stage[i] = v;
@@ -289,8 +294,7 @@ static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, 
                             hipStream_t st, const double *center) {
     TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
     TM_REQUIRE(m == 0 || syrk_co_ok(X, m),
-               "the co-resident syrk takes a 16-byte aligned C-ordered block of an even number of "
-               "columns <= 128");
+               "the co-resident syrk takes a 16-byte aligned C-ordered block of <= 128 columns");
     if (m == 0) return TM_OK;
     if (n == 0) {
         TM_HIP(hipMemset2DAsync(out, sizeof(double) * (size_t)ldo, 0, sizeof(double) * (size_t)m, (size_t)m, st));
@@ -312,7 +316,8 @@ static int run_syrk_co_impl(const double *X, int64_t ldx, int64_t n, int64_t m, 
     double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(wsv) + 256);
     double *cpart = part + (size_t)grid * CO_T * 256;
     TM_HIP(hipMemsetAsync(counter, 0, 256, st));
-    auto kern = center ? &syrk_co_kernel<true> : &syrk_co_kernel<false>;
+    auto kern = (m & 1) ? (center ? &syrk_co_kernel<true, true> : &syrk_co_kernel<false, true>)
+                        : (center ? &syrk_co_kernel<true, false> : &syrk_co_kernel<false, false>);
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)CO_LDS));
     prof_begin(st);

@@ -39,7 +39,7 @@ I8_MASKED_ROWS_SHARE = 0.25
 
 def set_strict_f64(flag: bool = True) -> bool:
     """strict = True: every float64 sandwich runs on the float64 MFMA / vector units.  By default the dense
-    self term of a qualifying block (C-ordered, 66..512 even columns, >= 4096 rows, finite) is computed in
+    self term of a qualifying block (C-ordered, 65..128 or 130..512 even columns, >= 4096 rows, finite) is computed in
     40-bit fixed point per column on the int8 matrix cores (K1e, csrc/syrk_i8.hip): entry-wise error below
     1e-10 * sqrt(S_ii S_jj) by its on-device envelope check (observed 2e-14 of max|S|), the bar BASELINE.json
     sets -- but not IEEE float64 to the last bits.  (StandardizedMatrix.sandwich hands the kernels the column
@@ -217,7 +217,7 @@ class DenseMatrix(MatrixBase):
     # ---- hot path -----------------------------------------------------------------------
     def _i8_colmax(self, center=None):
         """max |x| per column (float64 device tensor) when the block qualifies for the int8-sliced
-        syrk (csrc/syrk_i8.hip), else None: finite float64 blocks of 66 .. 512 (even) columns.  One
+        syrk (csrc/syrk_i8.hip), else None: finite float64 blocks of 65 .. 128 columns or 130 .. 512 even ones.  One
         pass over the block at first use (column maxima and minima are kept); with `center` the result is
         max |x - center| per column (the envelope of the centred fixed point).  The part of the envelope that
         depends on the weights (negative / non-finite d, weights tiny exactly where a column is large) is
@@ -226,8 +226,10 @@ class DenseMatrix(MatrixBase):
         if hit is None:
             hit = False
             blk = self._dev_c()
+            # (odd widths up to 128 columns since round 5; the 128-column panels of wider blocks need even ones)
             if (not blk.order_f and blk.buf.dtype == torch.float64 and 64 < blk.m <= I8_MAX_COLS
-                    and blk.m % 2 == 0 and blk.n >= I8_MIN_ROWS and blk.buf.data_ptr() % 16 == 0):
+                    and (blk.m % 2 == 0 or blk.m <= 128) and blk.n >= I8_MIN_ROWS
+                    and blk.buf.data_ptr() % 16 == 0):
                 # (two reductions, no |X| copy of the block: it is 10 GB at BASELINE configs[3]; a NaN
                 # propagates through amax / amin, +-inf shows in one of them)
                 x = blk.as_2d()

@@ -118,7 +118,7 @@ def co_supported(X: DenseDev, d, any_width=False) -> bool:
     import torch
 
     return (not X.order_f and X.buf.dtype == torch.float64 and d.dtype == torch.float64
-            and X.m <= 128 and X.m % 2 == 0 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0
+            and X.m <= 128 and X.m > 0 and X.n > 0 and X.buf.data_ptr() % 16 == 0
             and (any_width or X.m > 64))
 
 

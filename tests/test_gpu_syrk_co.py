@@ -37,9 +37,10 @@ def knobs(monkeypatch):
 
 
 # chunk = 12 rows, item = 768 rows: sizes around both, column counts around the 16 / 32-column
-# virtual blocks (even counts only: odd widths take the plain syrk)
+# virtual blocks; odd counts since round 5 (the pair that straddles a row's end; the single-element load behind
+# the last row)
 @pytest.mark.parametrize("n", [1, 11, 12, 13, 767, 768, 769, 1537, 5000, 100003])
-@pytest.mark.parametrize("m", [2, 16, 30, 34, 64, 100, 128])
+@pytest.mark.parametrize("m", [2, 16, 30, 34, 64, 100, 128, 1, 3, 33, 65, 101, 127])
 def test_syrk_co_vs_oracle(n, m):
     import torch
 
