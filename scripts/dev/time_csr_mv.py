@@ -6,7 +6,7 @@ n = int(os.environ.get("N", 10_000_000))
 sm = synth.sparse_block(n, 512, 0.05, torch.float64, 1003)
 v = torch.rand(512, dtype=torch.float64, device="cuda"); w = torch.rand(n, dtype=torch.float64, device="cuda")
 _lib.call("tm_profile_enable", 1)
-def t(f, k=6):
+def t(f, k=25):
     ts = []
     for _ in range(k):
         f(); ms = C.c_float(0); _lib.call("tm_profile_last_ms", C.byref(ms)); ts.append(ms.value)

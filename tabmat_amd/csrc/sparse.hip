@@ -102,7 +102,7 @@ constexpr int CSR_CAP = 1024;        // staged entries per wave and chunk
 constexpr int CSR_WAVES = 4;
 constexpr int CSR_EPL = CSR_CAP / 64;   // entries per lane and tile
 
-// Round 5: both stream kernels are software-pipelined.  Round 2's versions loaded a tile with four loads per
+// Round 5: the TRANSPOSE stream kernel is software-pipelined (matvec: see below).  Round 2's versions loaded a tile with four loads per
 // array in flight, worked on it, and only then asked for the next one: with the 16 waves of a CU in step the
 // memory pipe idled through every compute phase (0.63 / 0.48 of the HBM peak).  Now a wave owns a CONTIGUOUS range
 // of row chunks and walks its nonzeros as one stream of tiles of CSR_CAP entries; a tile is fetched with 16- / 8-byte
@@ -246,59 +246,44 @@ __device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, cons
     }
 }
 
-struct CsrNoPer {};
-
+// matvec keeps round 2's form (a tile of products staged in LDS with four loads per array in flight, lane <-> row
+// sums its segment): the pipelined walk above brought it nothing -- same-box A/B 0.641 vs 0.625 ms, 0.63 vs 0.65 of
+// the HBM peak -- because this kernel lives on the LDS pipe (16 random gathers of v + the stores and segment reads of
+// the products per 1024 entries), not on its loads; an 8-lanes-per-row form without LDS staging took 0.87 ms
+// (profiles/r5_matvec.txt).
 template <typename F>
 __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
-    const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_wave, F *__restrict__ out) {
+    const F *__restrict__ v, int64_t n, int m, F *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    F *vl = reinterpret_cast<F *>(smem_raw);                       // [m] (padded to an even count)
+    F *vl = reinterpret_cast<F *>(smem_raw);                       // [m]
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    F *prod = vl + ((m + 1) & ~1) + wave * CSR_CAP;                // [CSR_CAP] per wave
+    const int wave = threadIdx.x >> 6;
+    F *prod = vl + m + wave * CSR_CAP;                             // [CSR_CAP] per wave
     for (int j = threadIdx.x; j < m; j += blockDim.x) vl[j] = v[j];
     __syncthreads();
     const int64_t nchunk = ceil_div_dev(n, (int64_t)CSR_RPW);
-    const int64_t cb = ((int64_t)blockIdx.x * CSR_WAVES + wave) * chunks_per_wave;
-    const int64_t ce = min(cb + chunks_per_wave, nchunk);
-    typedef F f2 __attribute__((ext_vector_type(2)));
-    F acc = F(0);
-    csr_stream_walk<F, CsrNoPer>(
-        data, ind, ptr, n, cb, ce, lane, [](int64_t) { return CsrNoPer(); },
-        [&](const CsrTile<F> &t, int64_t c0, int cnt, int64_t rlo, int64_t rhi, int first, CsrNoPer) {
-            // (entries beyond cnt hold x = 0, j = 0: their slots are written and never summed)
-            // (v from its LDS copy: gathering it from global memory instead -- L1-resident -- to relieve the LDS pipe
-            // was 30 % slower, profiles/r5_matvec.txt)
-#pragma unroll
-            for (int k = 0; k < CSR_EPL / 2; ++k) {
-                f2 pv;
-                pv[0] = t.x[2 * k] * vl[t.j[2 * k]];
-                pv[1] = t.x[2 * k + 1] * vl[t.j[2 * k + 1]];
-                *reinterpret_cast<f2 *>(prod + 2 * lane + 128 * k) = pv;
-            }
+    for (int64_t c = (int64_t)blockIdx.x * CSR_WAVES + wave; c < nchunk;
+         c += (int64_t)gridDim.x * CSR_WAVES) {
+        const int64_t row = c * CSR_RPW + lane;
+        const int64_t rlo = ptr[min(row, n)];
+        const int64_t rhi = ptr[min(row + 1, n)];
+        const int64_t p0 = __shfl(rlo, 0, 64);
+        const int64_t p1 = ptr[min(c * CSR_RPW + CSR_RPW, n)];
+        F acc = F(0);
+        for (int64_t c0 = p0; c0 < p1; c0 += CSR_CAP) {
+            const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
+#pragma unroll 4
+            for (int e = lane; e < cnt; e += 64)
+                prod[e] = __builtin_nontemporal_load(data + c0 + e) * vl[__builtin_nontemporal_load(ind + c0 + e)];
             __builtin_amdgcn_wave_barrier();
             const int lo = (int)(max(rlo, c0) - c0);
-            const int hi = (int)(min(rhi, c0 + cnt) - c0);
-            // the row's part of the tile, two slots per LDS read (the LDS pipe is what this kernel runs on: 16
-            // gathers + 8 stores + the segment reads per tile; with one slot per read the latter were 40 of 64)
-            int e = lo;
-            if ((e & 1) && e < hi) acc += prod[e++];
-            F acc2 = F(0);
-            for (; e + 1 < hi; e += 2) {
-                const f2 pv = *reinterpret_cast<const f2 *>(prod + e);
-                acc += pv[0];
-                acc2 += pv[1];
-            }
-            acc += acc2;
-            if (e < hi) acc += prod[e];
+            const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
+            for (int e = lo; e < hi; ++e) acc += prod[e];
             __builtin_amdgcn_wave_barrier();
-            (void)first;
-        },
-        [&](int64_t row, CsrNoPer) {
-            if (row < n) out[row] += acc;
-            acc = F(0);
-        });
+        }
+        if (row < n) out[row] += acc;
+    }
 }
 
 template <typename F>
@@ -967,21 +952,17 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     const int64_t n_iter = rows ? n_rows : n;
     if (n_iter == 0 || m == 0) return TM_OK;
     if (cols && n_cols == 0) return TM_OK;
-    if (!rows && !cols && sizeof(F) * (size_t)(m + 2 + CSR_WAVES * CSR_CAP) <= 64 * 1024 &&
-        csr_stream_aligned(data, ind)) {
-        const size_t lds = sizeof(F) * (size_t)(((m + 1) & ~(int64_t)1) + CSR_WAVES * CSR_CAP);
+    if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
+        const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
         auto kern = &csr_matvec_stream_kernel<F>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t nchunk = ceil_div(n, CSR_RPW);
-        // every wave a contiguous range of chunks
-        const int64_t nwave = std::min<int64_t>(nchunk, (int64_t)NUM_CU * 4 * CSR_WAVES);
-        const int64_t cpw = ceil_div(nchunk, nwave);
-        const int64_t nblk = ceil_div(ceil_div(nchunk, cpw), CSR_WAVES);
+        const int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind, ptr,
-                           v, n, (int)m, cpw, out);
+                           v, n, (int)m, out);
         prof_end(st);
         TM_LAUNCH_CHECK();
         return TM_OK;
