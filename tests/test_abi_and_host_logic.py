@@ -498,3 +498,23 @@ def test_pair_block_list_covers_every_pair_once(seed, m, dens):
     full = np.tril(out) + np.tril(out, -1).T
     want = (A.T.multiply(d)).dot(A).toarray()
     assert np.abs(full - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0)
+
+
+def test_pairs_cost_model_picks_the_regimes_it_was_measured_in():
+    """profiles/r5_k2_pairs.txt (2M rows): 2048 columns @ 1.25 % and 4096 @ 0.625 % take the pair-stream kernel; the
+    BASELINE shape (512 @ 5 %), 2048 @ 5 % (the block list serves dense rows better) and 8192 @ 0.05 % (the direct
+    kernel) do not."""
+    from tabmat_amd.ext import sparse as xs
+
+    class Fake:
+        def __init__(self, n, m, dens):
+            self.n, self.m = n, m
+            self._nnz = int(n * m * dens)
+            self.data = type("T", (), {"numel": lambda s_: self._nnz})()
+
+    n = 2_000_000
+    assert xs.pairs_sandwich_pays(Fake(n, 2048, 0.0125))
+    assert xs.pairs_sandwich_pays(Fake(n, 4096, 0.00625))
+    assert not xs.pairs_sandwich_pays(Fake(n, 512, 0.05))
+    assert not xs.pairs_sandwich_pays(Fake(n, 2048, 0.05))
+    assert not xs.pairs_sandwich_pays(Fake(n, 8192, 0.0005))

@@ -119,24 +119,3 @@ def test_public_sandwich_takes_the_pairs_kernel_for_wide_blocks(monkeypatch):
     assert len(calls) == 2                                           # short list: not through the masked pass
     cols = np.sort(rng.choice(m, 900, replace=False))
     assert nat_err(sm.sandwich(d, cols=cols), ref[np.ix_(cols, cols)]) < 1e-10
-
-
-def test_pairs_cost_model_picks_the_regimes_it_was_measured_in():
-    """profiles/r5_k2_pairs.txt (2M rows): 2048 columns @ 1.25 % and 4096 @ 0.625 % take the pair-stream kernel; the
-    BASELINE shape (512 @ 5 %), 2048 @ 5 % (the block list serves dense rows better) and 8192 @ 0.05 % (the direct
-    kernel) do not."""
-    from tabmat_amd.ext import sparse as xs
-
-    class Fake:
-        def __init__(self, n, m, dens):
-            self.n, self.m = n, m
-            self.data = torch.empty(0)
-            self._nnz = int(n * m * dens)
-            self.data = type("T", (), {"numel": lambda s_: self._nnz})()
-
-    n = 2_000_000
-    assert xs.pairs_sandwich_pays(Fake(n, 2048, 0.0125))
-    assert xs.pairs_sandwich_pays(Fake(n, 4096, 0.00625))
-    assert not xs.pairs_sandwich_pays(Fake(n, 512, 0.05))
-    assert not xs.pairs_sandwich_pays(Fake(n, 2048, 0.05))
-    assert not xs.pairs_sandwich_pays(Fake(n, 8192, 0.0005))
