@@ -136,3 +136,59 @@ def test_random_split_products(seed):
         want = Esf.T @ (d64[rows, None] * Esf)
         scale = max(1.0, float(np.abs(want).max()))
         assert float(np.abs(np.asarray(got) - want).max()) / scale < (tol if dtype == np.float64 else 5e-3)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TM_FUZZ_STD_CASES", "24"))))
+def test_random_standardized_sandwich(seed):
+    """Round 5: StandardizedMatrix.sandwich over random designs with UNCENTRED dense columns (mean up to 300 standard
+    deviations), random shift / mult (also ones that are NOT the columns' means: the centring is algebra, not
+    statistics), rows / cols restrictions, numpy and device vectors -- against float64 dense algebra on the
+    explicitly standardized matrix, entry by entry at the natural scale.  float64 designs only (float32 keeps the
+    reference's formula)."""
+    import torch
+
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(7000 + seed)
+    X, E = None, None
+    while X is None:
+        X, E = _random_split(rng, np.float64)
+    n, p = E.shape
+    # move the dense columns off zero: x -> mean + x (in the matrix AND its dense image)
+    mats = X.matrices if isinstance(X, tm.SplitMatrix) else [X]
+    idxs = X.indices if isinstance(X, tm.SplitMatrix) else [np.arange(p)]
+    new = []
+    for mb, ix in zip(mats, idxs):
+        if isinstance(mb, tm.DenseMatrix):
+            mu = rng.choice([0.0, 3.0, -40.0, 300.0], size=mb.shape[1])
+            A = mb.toarray() + mu[None, :]
+            E[:, ix] = A
+            new.append(tm.DenseMatrix(np.asfortranarray(A) if A.flags["F_CONTIGUOUS"] and A.ndim == 2 and rng.random() < 0.5 else A))
+        else:
+            new.append(mb)
+    X = tm.SplitMatrix(new, [np.asarray(i) for i in idxs]) if isinstance(X, tm.SplitMatrix) else new[0]
+    if seed % 3 == 0:                   # the statistics glum would use
+        w = rng.random(n) + 0.1
+        w /= w.sum()
+        std = X.standardize(w, True, bool(seed % 2))[0]
+    else:                               # arbitrary shift / mult
+        mult = rng.uniform(0.2, 3.0, p) if seed % 2 else None
+        shift = rng.standard_normal(p) * rng.choice([0.0, 1.0, 50.0], size=p)
+        std = tm.StandardizedMatrix(X, shift, mult)
+    Z = E * (std.mult[None, :] if std.mult is not None else 1.0) + std.shift[None, :]
+    d = rng.random(n)
+    d[rng.random(n) < 0.1] = 0.0
+    rows = np.sort(rng.choice(n, max(1, n // 2), replace=False)) if seed % 4 == 1 and n > 1 else None
+    cols = np.sort(rng.choice(p, max(1, int(p * rng.choice([0.2, 0.7]))), replace=False)) if seed % 4 >= 2 else None
+    Zr = Z[rows if rows is not None else slice(None)][:, cols if cols is not None else slice(None)]
+    dr = d[rows] if rows is not None else d
+    want = (Zr.T * dr) @ Zr
+    for dd in (d, torch.from_numpy(d).cuda()):
+        got = std.sandwich(dd, rows=rows, cols=cols)
+        got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+        # (the float64 reference itself carries eps * (mean / std) per entry of Z: 1e-9 at the natural scale)
+        dg = np.sqrt(np.abs(np.diag(want)))
+        den = np.outer(dg, dg)
+        err = np.abs(got - want)
+        ok = np.where(den > 0, err <= 1e-9 * den + 1e-12 * (np.abs(want).max() + 1.0), err <= 1e-12 * (np.abs(want).max() + 1.0))
+        assert ok.all(), (float((err / np.where(den > 0, den, 1.0)).max()), rows is not None, cols is not None)
