@@ -766,6 +766,187 @@ __global__ __launch_bounds__(256) void dense_matvec_c_stream_kernel(const F *__r
     }
 }
 
+// C-order matvec for row lengths the streaming kernel has no lane split for (any m up to
+// MV_TILE_MAX_M, all rows, all columns, 16-byte aligned X).  A row of 10 doubles is 80 bytes: one
+// wave per row keeps 80 bytes per wave in flight and the launch runs at 0.38 TB/s.  Here a block
+// copies TR whole rows (TR * m contiguous elements) from HBM to LDS with flat 16-byte loads, so
+// the loads are coalesced whatever m is, then TPR lanes per row sum the products from LDS.  The
+// LDS rows are padded to an odd number of elements: lanes of different rows hit different banks.
+constexpr int MV_TILE_MAX_M = 1280;
+constexpr int MV_TILE_BYTES = 40960;
+constexpr int MV_TILE_V = MV_TILE_BYTES / 16 / 256;    // 16-byte vectors per lane and tile
+
+template <typename F>
+__global__ __launch_bounds__(256) void dense_matvec_c_tile_kernel(const F *__restrict__ X, int64_t n,
+                                                                 int m, int tpr_log2, int tr,
+                                                                 const F *__restrict__ v,
+                                                                 F *__restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(F);
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char mv_tile_smem[];
+    const int ms = m | 1;                              // padded row length in LDS
+    const int tpr = 1 << tpr_log2;
+    const int rstep = 256 >> tpr_log2;                 // rows summed at a time; tr = rows per tile
+    F *vl = reinterpret_cast<F *>(mv_tile_smem);
+    F *tile = vl + ((m + 1) & ~1);
+    for (int j = threadIdx.x; j < m; j += 256) vl[j] = v[j];
+    // flat position of this lane's first vector inside a tile, and the step between its vectors;
+    // both are the same for every tile because a tile starts at a row boundary
+    const int e0 = threadIdx.x * VEC;
+    const int r_first = e0 / m, c_first = e0 - r_first * m;
+    const int dr = (256 * VEC) / m, dc = (256 * VEC) - dr * m;
+    const int my_row = threadIdx.x >> tpr_log2, my_s = threadIdx.x & (tpr - 1);
+    const int64_t ntiles = (n + tr - 1) / tr;
+    vec_t x[MV_TILE_V];
+    // the tile's vectors go to registers one tile ahead: they are in flight while the previous
+    // tile is summed from LDS
+    auto fetch = [&](int64_t t) {
+        const int64_t row0 = t * tr;
+        const int nvec = (int)(min((int64_t)tr, n - row0) * m) / VEC;
+        const vec_t *src = reinterpret_cast<const vec_t *>(X + row0 * (int64_t)m);
+#pragma unroll
+        for (int u = 0; u < MV_TILE_V; ++u) {
+            const int q = (int)threadIdx.x + u * 256;
+            if (q < nvec) x[u] = __builtin_nontemporal_load(src + q);
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row0 = t * tr;
+        const int rows_here = (int)min((int64_t)tr, n - row0);
+        const int elems = rows_here * m;
+        const int nvec = elems / VEC;
+        __syncthreads();                               // previous tile fully read (and vl written)
+        int r = r_first, c = c_first;
+#pragma unroll
+        for (int u = 0; u < MV_TILE_V; ++u) {
+            if ((int)threadIdx.x + u * 256 < nvec) {
+                int rr = r, cc = c;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    tile[rr * ms + cc] = x[u][e];
+                    if (++cc == m) { cc = 0; ++rr; }
+                }
+            }
+            r += dr; c += dc;
+            if (c >= m) { c -= m; ++r; }
+        }
+        // the elems % VEC elements a whole vector does not cover (partial last tile only)
+        if ((int)threadIdx.x < elems - nvec * VEC) {
+            const int e = nvec * VEC + threadIdx.x;
+            const int rr = e / m;
+            tile[rr * ms + (e - rr * m)] = X[row0 * (int64_t)m + e];
+        }
+        __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+        for (int row = my_row; row < rows_here; row += rstep) {
+            const F *lr = tile + row * ms;
+            F acc = F(0);
+            for (int j = my_s; j < m; j += tpr) acc = fma(lr[j], vl[j], acc);
+            for (int s = 1; s < tpr; s <<= 1) acc += __shfl_xor(acc, s, 64);
+            if (my_s == 0) out[row0 + row] += acc;
+        }
+    }
+}
+
+// C-order transpose_matvec for narrow or oddly sized rows (any m <= RMV_FLAT_MAX_M, all rows, all
+// columns, 16-byte aligned X).  The streaming kernel gives every lane one 16-byte piece of a row,
+// so a 10-column matrix uses 5 lanes of 64.  Here the lanes walk the slab's elements as one flat
+// array of 16-byte vectors.  With P = m / gcd(m, VEC) vectors per column period and A = the
+// largest multiple of P <= 256 active lanes, lane t reads the vectors t, t + A, t + 2A, ...: their
+// elements always fall in the same VEC columns, so the lane keeps VEC running sums and only the
+// row index (for v[row]) moves, by A * VEC / m whole rows per step.
+constexpr int RMV_FLAT_MAX_M = 1024;
+constexpr int RMV_FLAT_U = 4;
+constexpr int64_t RMV_SLAB_BYTES = 128 * 1024;
+constexpr int64_t RMV_FLAT_V_BYTES = 32 * 1024;
+
+template <typename F>
+__global__ __launch_bounds__(256) void dense_rmatvec_c_flat_kernel(
+    const F *__restrict__ X, int64_t n, int m, int active, const F *__restrict__ v,
+    int64_t rows_per_block, F *__restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(F);
+    typedef F vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ F red[256 * VEC];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rmv_flat_smem[];
+    F *vs = reinterpret_cast<F *>(rmv_flat_smem);       // the slab's part of v
+    const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;     // a multiple of VEC
+    const int64_t t1 = min(t0 + rows_per_block, n);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)(t1 - t0); i += 256) vs[i] = v[t0 + i];
+    __syncthreads();
+    const int drow = active * VEC / m;                 // whole rows per step
+    vec_t acc;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = F(0);
+    if (tid < active) {
+        int ro[VEC];                                   // row (relative to the step's first row) of
+        {                                              // each element of this lane's vector
+            int rr = (tid * VEC) / m, cc = tid * VEC - rr * m;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                ro[e] = rr;
+                if (++cc == m) { cc = 0; ++rr; }
+            }
+        }
+        const int64_t total = (t1 - t0) * m;           // elements of the slab
+        const F *src = X + t0 * (int64_t)m;
+        const int64_t nrow = t1 - t0;
+        const int64_t estep = (int64_t)active * VEC;
+        int64_t e0 = (int64_t)tid * VEC;
+        int rbase = 0;
+        // whole steps: every lane's vector and rows are inside the slab
+        for (; e0 + (RMV_FLAT_U - 1) * estep + VEC <= total &&
+               rbase + (RMV_FLAT_U - 1) * drow + ro[VEC - 1] < nrow;
+             e0 += RMV_FLAT_U * estep, rbase += RMV_FLAT_U * drow) {
+            vec_t x[RMV_FLAT_U];
+            F w[RMV_FLAT_U][VEC];
+#pragma unroll
+            for (int u = 0; u < RMV_FLAT_U; ++u) {
+                x[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src + e0 + u * estep));
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) w[u][e] = vs[rbase + u * drow + ro[e]];
+            }
+#pragma unroll
+            for (int u = 0; u < RMV_FLAT_U; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = fma(x[u][e], w[u][e], acc[e]);
+        }
+        // the slab's last steps, element by element
+        for (; e0 < total; e0 += estep, rbase += drow) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (e0 + e < total) acc[e] = fma(src[e0 + e], vs[rbase + ro[e]], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[tid * VEC + e] = acc[e];
+    __syncthreads();
+    // flat element i of the active lanes belongs to column i % m: fold the active * VEC sums, a
+    // whole number of rows, to one row (by 8 per round, at most 256 / m rows wide)
+    int cnt = active * VEC;
+    if (m <= 256) {
+        const int maxg = 256 / m;
+        while (cnt > m) {
+            const int nw = min(maxg, (cnt / m + 7) / 8) * m;
+            F s = F(0);
+            if (tid < nw)
+                for (int i = tid; i < cnt; i += nw) s += red[i];
+            __syncthreads();
+            if (tid < nw) red[tid] = s;
+            __syncthreads();
+            cnt = nw;
+        }
+        if (tid < m) atomic_add(&out[tid], red[tid]);
+    } else {
+        for (int j = tid; j < m; j += 256) {
+            F s = F(0);
+            for (int i = j; i < cnt; i += m) s += red[i];
+            atomic_add(&out[j], s);
+        }
+    }
+}
+
 // F-order matvec: one thread per output row.
 template <typename F>
 __global__ __launch_bounds__(256) void dense_matvec_f_kernel(
@@ -1061,6 +1242,23 @@ static int run_dense_matvec(const F *X, int64_t n, int64_t m, int order_f, const
             TM_LAUNCH_CHECK();
             return TM_OK;
         }
+        if (!rows && !cols && aligned && m <= MV_TILE_MAX_M) {
+            // rows per tile: as many as MV_TILE_BYTES hold, a power of two between 4 and 256
+            const int64_t ms = m | 1;
+            int tpr_log2 = 0;
+            while ((256 >> tpr_log2) * ms * (int64_t)sizeof(F) > MV_TILE_BYTES && tpr_log2 < 6) ++tpr_log2;
+            // (narrow rows: several rows per lane)
+            const int tr = (256 >> tpr_log2) * (int)std::max<int64_t>(1, MV_TILE_BYTES / (256 * ms * (int64_t)sizeof(F)));
+            const size_t lds = (size_t)(tr * ms + ((m + 1) & ~(int64_t)1)) * sizeof(F);
+            const int64_t per_cu = std::min<int64_t>(8, (144 * 1024) / (int64_t)lds);
+            const int64_t nblk = std::min<int64_t>(ceil_div(n, tr), NUM_CU * per_cu);
+            prof_begin(st);
+            hipLaunchKernelGGL((dense_matvec_c_tile_kernel<F>), dim3((unsigned)nblk), dim3(256), lds, st,
+                               X, n, (int)m, tpr_log2, tr, v, out);
+            prof_end(st);
+            TM_LAUNCH_CHECK();
+            return TM_OK;
+        }
         const int64_t nblk = std::min<int64_t>(ceil_div(n_iter, 4), NUM_CU * 8);
         prof_begin(st);
         hipLaunchKernelGGL((dense_matvec_c_kernel<F>), dim3((unsigned)nblk), dim3(256), 0, st, X, m,
@@ -1082,6 +1280,32 @@ static int run_dense_rmatvec(const F *X, int64_t n, int64_t m, int order_f, cons
     const int64_t rpb = ceil_div(n_iter, nblk);
     nblk = ceil_div(n_iter, rpb);
     constexpr int VEC = 16 / (int)sizeof(F);
+    // rows that do not fill the streaming kernel's 64 lanes with whole vectors: the flat kernel
+    // keeps all lanes loading
+    const int64_t flat_max = tune("rmv_flat_max", RMV_FLAT_MAX_M);
+    int g = VEC;                                       // gcd(m, VEC), VEC a power of two
+    while (m % g) g >>= 1;
+    const int period = (int)std::min<int64_t>(m / g, 1 << 20);   // vectors per column period
+    // (measured at 4 GB, profiles/r5_dense_matvec_widths.txt: the streaming kernel is the faster
+    // one exactly when one pass of a wave is 32 .. 64 whole vectors)
+    const bool one_pass = m % VEC == 0 && m / VEC >= 32 && m / VEC <= 64;
+    if (!order_f && !rows && !cols && m <= flat_max && period <= 256 && !one_pass &&
+        (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        const int active = (256 / period) * period;
+        // a slab of about RMV_SLAB_BYTES per block, a multiple of 32 rows (so that it starts on
+        // a 16-byte boundary) and at most RMV_FLAT_ROWS rows (its part of v is staged in LDS)
+        constexpr int64_t RMV_FLAT_ROWS = RMV_FLAT_V_BYTES / (int64_t)sizeof(F);
+        const int64_t want = std::min<int64_t>(RMV_FLAT_ROWS, std::max<int64_t>(32, RMV_SLAB_BYTES / (m * (int64_t)sizeof(F))));
+        int64_t nb = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n, want)), NUM_CU * 8);
+        int64_t rp = std::min<int64_t>(RMV_FLAT_ROWS, ceil_div(ceil_div(n, nb), 32) * 32);
+        nb = ceil_div(n, rp);
+        prof_begin(st);
+        hipLaunchKernelGGL((dense_rmatvec_c_flat_kernel<F>), dim3((unsigned)nb), dim3(256),
+                           (size_t)rp * sizeof(F), st, X, n, (int)m, active, v, rp, out);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+        return TM_OK;
+    }
     if (!order_f && !rows && !cols && m % VEC == 0 &&
         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         prof_begin(st);

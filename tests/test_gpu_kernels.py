@@ -101,6 +101,43 @@ def test_dense_matvec_rmatvec(order, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7, 10, 12, 15, 18, 20, 31, 33, 63, 100, 127, 129, 200,
+                               333, 500, 1000, 1279, 1280, 1281])
+def test_dense_matvec_any_width(dtype, k):
+    """Row lengths the streaming kernels have no lane split for: matvec stages whole rows in LDS
+    (dense.hip dense_matvec_c_tile_kernel, any m <= 1280), transpose_matvec walks the slab as a
+    flat vector array (dense_rmatvec_c_flat_kernel, column period <= 256).  Row counts around the tile and
+    slab sizes, accumulation into out, a NaN in the last row staying in the last row."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(900 + k)
+    tol = F64_TOL if dtype == np.float64 else 2e-4
+    for n in (1, 2, 3, 5, 255, 256, 257, 1000, 4099, 70001):
+        if n * k > 3e7:
+            continue
+        X = rng.standard_normal((n, k)).astype(dtype)
+        v = rng.standard_normal(k).astype(dtype)
+        mat = tm.DenseMatrix(X)
+        ref = X.astype(np.float64) @ v.astype(np.float64)
+        scale_mv = max(1.0, np.abs(ref).max())
+        assert np.abs(mat.matvec(v) - ref).max() / scale_mv < tol, (n, k)
+        out = np.full(n, 2.5, dtype=dtype)
+        res = mat.matvec(v, out=out)
+        assert res is out and np.abs(out - (ref + 2.5)).max() / scale_mv < tol
+        w = rng.standard_normal(n).astype(dtype)
+        ref_t = X.astype(np.float64).T @ w.astype(np.float64)
+        scale = max(1.0, np.abs(ref_t).max())
+        assert np.abs(mat.transpose_matvec(w) - ref_t).max() / scale < tol, (n, k)
+        out_t = np.full(k, -1.5, dtype=dtype)
+        mat.transpose_matvec(w, out=out_t)
+        assert np.abs(out_t - (ref_t - 1.5)).max() / scale < tol
+    X = rng.standard_normal((777, k)).astype(dtype)
+    X[-1, -1] = np.nan
+    got = tm.DenseMatrix(X).matvec(np.ones(k, dtype=dtype))
+    assert np.isnan(got[-1]) and np.isfinite(got[:-1]).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("k", [4, 16, 32, 64, 128, 256, 512, 520])
 def test_dense_matvec_stream_path(dtype, k):
     """Unrestricted C-order matvec takes the 16-byte streaming kernel when a row is 8..128
