@@ -250,7 +250,7 @@ int tm_sparse_sandwich_chunked_f64(const double *cm_data, const int32_t *cm_indi
  * tiles: its own row's list up to itself), one LDS atomic per pair.  Operands: cptr int32 [ceil(m / 128)][n + 1] of
  * the chunk-major twin (tm_sparse_sandwich_chunked_*) and cm_rec int32 [nnz][4], one 16-byte record per
  * chunk-major entry: f64 {value low word, value high word, column, row}, f32 {value bits, column, row, 0}.
- * m <= 8192, nnz < 2^31.  out (m, m) is overwritten. */
+ * m <= 16384, nnz < 2^31.  out (m, m) is overwritten. */
 int tm_sparse_sandwich_pairs_f32(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                  const float *d, float *out, void *stream);
 int tm_sparse_sandwich_pairs_f64(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,

@@ -995,7 +995,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     const int64_t n_out = cols ? n_cols : m;
     if (n_iter == 0 || n_out == 0) return TM_OK;
     if (!rows && !cols &&
-        sizeof(lds_acc_t) * (size_t)(m + 1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= 64 * 1024 &&
+        sizeof(lds_acc_t) * (size_t)(m + 1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= SP_LDS_MAX &&
         csr_stream_aligned(data, ind)) {
         const size_t lds = sizeof(lds_acc_t) * (size_t)((m + 1) & ~(int64_t)1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
         auto kern = &csr_rmatvec_stream_kernel<F>;
@@ -1019,7 +1019,9 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
     }
     const size_t map_bytes = cols ? align256(sizeof(int32_t) * (size_t)m) : 0;
     const bool use_lds = sizeof(lds_acc_t) * (size_t)n_out <= SP_LDS_MAX;
-    int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, 2048)), NUM_CU * 2);
+    // (a short, wide block -- the reference's 'sparse_wide' design is 40k x 10k -- still gets a workgroup per
+    // 256 rows: 20 workgroups of 2048 rows ran at 0.09 TB/s)
+    int64_t nblk = std::min<int64_t>(std::max<int64_t>(1, ceil_div(n_iter, n_out > 4096 ? 256 : 2048)), NUM_CU * 2);
     const int64_t rpb = ceil_div(n_iter, nblk);
     nblk = ceil_div(n_iter, rpb);
     void *wsv = nullptr;

@@ -194,7 +194,7 @@ static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, in
     constexpr int TS = KP_TS;
     TM_REQUIRE(nnz < (1ll << 31) && n < (1ll << 31) - 1, "sparse block too large for 32-bit entry positions");
     const int nchunk = (int)ceil_div(m, TS);
-    TM_REQUIRE(nchunk <= 64, "at most 8192 columns (the tile partials are kept per workgroup)");
+    TM_REQUIRE(nchunk <= 128, "at most 16384 columns (the tile partials are kept per workgroup)");
     const int n_parts = nchunk * (nchunk + 1) / 2;
     const int64_t n_ranges = ceil_div(n, KP_RANGE);
     // ~3 rounds of workgroups over the chip, the same number of row segments for every tile
@@ -202,12 +202,13 @@ static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, in
     n_slots = std::min(n_slots, 64);
     const size_t lds = sizeof(lds_acc_t) * (size_t)(TS * TS);
     const size_t tmp_bytes = (sizeof(F) * (size_t)n_parts * TS * TS + 255) / 256 * 256;
-    const size_t ws_bytes = sizeof(F) * (size_t)n_parts * (size_t)n_slots * TS * TS;
+    // (one row segment: the workgroups write the assembled-tile buffer themselves)
+    const size_t ws_bytes = n_slots > 1 ? sizeof(F) * (size_t)n_parts * (size_t)n_slots * TS * TS : 0;
     void *wsv = nullptr;
     int rc = get_workspace(tmp_bytes + ws_bytes + 256, &wsv, st);
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
-    F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
+    F *ws = n_slots > 1 ? reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes) : tmp;
     auto kern = &sparse_sandwich_pairs_kernel<F>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -217,8 +218,10 @@ static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, in
                        reinterpret_cast<const kp_rec_t *>(rec), cptr, n, d, n_slots, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
-    rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, n_slots, n_parts, tmp, (int64_t)n_parts * TS * TS, false, st);
-    if (rc) return rc;
+    if (n_slots > 1) {
+        rc = launch_reduce_partials<F>(ws, (int64_t)TS * TS, n_slots, n_parts, tmp, (int64_t)n_parts * TS * TS, false, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((pairs_assemble_kernel<F>), dim3((unsigned)ceil_div(m, 64), (unsigned)m), dim3(64), 0, st,
                        tmp, (int)m, out);
     TM_LAUNCH_CHECK();

@@ -328,6 +328,7 @@ def direct_sandwich_pays(A: CsrDev) -> bool:
 
 # the pair-stream form of the unrestricted sparse self sandwich (csrc/sparse_pairs.hip): "auto" / "0" / "1"
 K2_PAIRS = "auto"
+K2_PAIRS_MAX_M = 16384      # tm_sparse_sandwich_pairs_*: at most 128 column chunks
 
 
 def pairs_sandwich_pays(A: CsrDev) -> bool:
@@ -340,19 +341,24 @@ def pairs_sandwich_pays(A: CsrDev) -> bool:
                                span rows without entries: x (1.6 / k)^0.8 for k entries per row and chunk, at
                                most x 6) + 2.7 ps per pair + ~0.8 us per tile (LDS tile set-up and partials)."""
     if K2_PAIRS != "auto":
-        return K2_PAIRS == "1" and A.m <= 8192 and 0 < int(A.data.numel()) < 2**31
+        return K2_PAIRS == "1" and A.m <= K2_PAIRS_MAX_M and 0 < int(A.data.numel()) < 2**31
     nnz, n, m = int(A.data.numel()), A.n, A.m
-    if n == 0 or nnz == 0 or m <= 1024 or m > 8192 or nnz >= 2**31:
+    if n == 0 or nnz == 0 or m <= 1024 or m > K2_PAIRS_MAX_M or nnz >= 2**31:
         return False
     nch = (m + 127) // 128
     parts = nch * (nch + 1) / 2
     per_row = nnz / n
     k = per_row / nch
     pairs = n * per_row * (per_row + 2.0) / 2.0
+    # (beyond 768 tiles every tile is one workgroup writing its tile once: ~0.1 us each, measured on the reference's
+    # 'sparse_wide' design 40k x 10k @ 1 %: 1.63 ms, and on 40k x 16k @ 0.5 %: 2.71 ms)
     t_pairs = (nnz * (nch + 1) / 2.0 * 2.3e-12 * min(6.0, max(1.0, (1.6 / k) ** 0.8)) + pairs * 2.7e-12
-               + parts * 0.8e-6)
+               + min(parts, 768) * 0.8e-6 + max(0.0, parts - 768) * 0.1e-6)
     t_direct = pairs / 21e9
-    t_tiled = pairs * 1.15e-12 if k > 4.5 and nch <= 32 else n * parts * 20e-12
+    if nch > 32:
+        t_tiled = n * parts * 0.3e-9      # only the generic tiled kernel is left (direct_sandwich_pays)
+    else:
+        t_tiled = pairs * 1.15e-12 if k > 4.5 else n * parts * 20e-12
     return t_pairs < 0.8 * min(t_direct, t_tiled)
 
 

@@ -518,3 +518,8 @@ def test_pairs_cost_model_picks_the_regimes_it_was_measured_in():
     assert not xs.pairs_sandwich_pays(Fake(n, 512, 0.05))
     assert not xs.pairs_sandwich_pays(Fake(n, 2048, 0.05))
     assert not xs.pairs_sandwich_pays(Fake(n, 8192, 0.0005))
+    # the reference's own 'sparse_wide' design (benchmark/generate_matrices.py): pair stream 1.63 ms, direct 9.7 ms;
+    # the same width ten times sparser over ten times the rows: direct 1.9 ms, pair stream 2.2 ms
+    assert xs.pairs_sandwich_pays(Fake(40_000, 10_000, 0.01))
+    assert not xs.pairs_sandwich_pays(Fake(400_000, 10_000, 0.001))
+    assert not xs.pairs_sandwich_pays(Fake(40_000, 20_000, 0.01))          # beyond 128 column chunks

@@ -31,7 +31,7 @@ def _pairs(S, d, dtype=np.float64):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,dens", [(20_000, 2048, 0.0125), (9_001, 1500, 0.02), (30_000, 4096, 0.003),
                                       (5_000, 130, 0.1), (4_097, 512, 0.05), (700, 40, 0.5), (2_049, 8192, 0.001),
-                                      (64, 300, 0.02), (3, 129, 0.9)])
+                                      (64, 300, 0.02), (3, 129, 0.9), (1_500, 10_000, 0.01), (300, 16_384, 0.002)])
 def test_pairs_kernel_matches_the_oracle(dtype, n, m, dens):
     rng = np.random.default_rng(n + m)
     S = sps.random(n, m, density=dens, format="csc", random_state=rng)

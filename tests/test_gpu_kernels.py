@@ -365,11 +365,14 @@ def test_sparse_matvec_rmatvec(dtype):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,dens", [(1, 5, 1.0), (63, 40, 0.3), (64, 40, 0.3), (65, 40, 0.3),
-                                      (300, 3000, 0.5), (20011, 512, 0.05), (5000, 64, 0.0)])
+                                      (300, 3000, 0.5), (20011, 512, 0.05), (5000, 64, 0.0),
+                                      (4000, 10_000, 0.01), (1500, 15_000, 0.004), (1200, 20_000, 0.003)])
 def test_sparse_matvec_stream_path(dtype, n, m, dens):
     """Unrestricted CSR matvec / transpose_matvec take the streaming kernels (sparse.hip K6 fast
     paths): row counts around the 64-row wave chunk, rows longer than the 1024-entry staging
-    buffer (300 x 3000 at 50 %), an empty matrix, accumulation into out."""
+    buffer (300 x 3000 at 50 %), an empty matrix, accumulation into out; short and wide blocks (the
+    reference's 'sparse_wide' design is 40k x 10k: accumulators up to 128 KB of LDS, beyond that the
+    generic kernel with a workgroup per 256 rows)."""
     import tabmat_amd as tm
 
     rng = np.random.default_rng(n * 7 + m)
