@@ -135,9 +135,12 @@ def kernel_ops(mat, d):
                 if isinstance(mw, tm.DenseMatrix):
                     from tabmat_amd.ext import sparse as xs
 
-                    if xsplit.multi_cat_dense_wide_ok(cats, mw._dev()):      # same choice as the product
+                    # same choice as the product (SplitMatrix._fused_cats)
+                    if xsplit.multi_cat_dense_wide_ok(cats, mw._dev()) or xsplit.multi_cat_dense_tile_ok(cats, mw._dev()):
                         fused.append((f"allcats_x_dense{i}", lambda mw=mw: xsplit.multi_cat_dense_sandwich(
                             cats, d, mw._dev())))
+                    elif xsplit.cat_dense_sorted_ok(mw._dev()):
+                        pass                                               # pair by pair: the per-pair ops stay
                     else:
                         cat_ids = [k for k, m in enumerate(mats) if isinstance(m, tm.CategoricalMatrix)]
                         oh, _ = mat._onehot_slab(cat_ids)
@@ -154,8 +157,9 @@ def kernel_ops(mat, d):
                         fused.append((f"allcats_x_sparse{i}", lambda mw=mw: xsplit.multi_cat_sparse_sandwich(
                             cats, d, mw._slab())))
             # the fused kernels replace the per-pair categorical cross terms
-            ops = [o for o in ops if not (("categorical" in o[0]) and ("dense" in o[0] or "sparse" in o[0])
-                                          and "x" in o[0])] + fused
+            done = {name.split("_x_")[1] for name, _ in fused}
+            ops = [o for o in ops if not ("categorical" in o[0] and "x" in o[0]
+                                          and any(o[0].endswith("x" + w) or o[0].startswith(w + "x") for w in done))] + fused
     return ops
 
 

@@ -76,6 +76,32 @@ def test_dense_sandwich_f32(n, k):
     assert nat_err(res, ref) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("k", list(range(1, 12)))
+def test_dense_sandwich_narrow_widths(dtype, order, k):
+    """1 .. 11 columns (csrc/syrk_narrow.hip; the reference's 'dense' design is 4M x 10): C-ordered blocks
+    are staged through LDS with flat 16-byte loads, F-ordered ones read directly; row counts around the
+    256-row tile and the 4-row alignment of a workgroup's slab."""
+    import tabmat_amd as tm
+
+    from tabmat_amd._lib import call
+
+    rng = np.random.default_rng(7000 + k)
+    tol = F64_TOL if dtype == np.float64 else 2e-5
+    for n in (1, 2, 3, 5, 255, 256, 257, 1023, 5000, 70_001, 600_013):
+        call("tm_tune_set", b"syrk_narrow_staged", n % 2)       # both forms at every width (default: by width)
+        X = rng.standard_normal((n, k)).astype(dtype)
+        X = np.asfortranarray(X) if order == "F" else X
+        d = rng.random(n).astype(dtype)
+        res = tm.DenseMatrix(X).sandwich(d)
+        X64 = X.astype(np.float64)
+        ref = X64.T @ (X64 * d.astype(np.float64)[:, None])
+        assert res.shape == (k, k) and nat_err(res, ref) < tol, (n, k)
+        assert np.array_equal(res, res.T)
+    call("tm_tune_set", b"syrk_narrow_staged", -1)
+
+
 # ------------------------------------------------------------------ K5 dense matvec
 @pytest.mark.parametrize("order", ["C", "F"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
