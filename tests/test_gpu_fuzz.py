@@ -22,7 +22,7 @@ def _random_split(rng, dtype):
         kinds += ["cat_small"] * int(rng.integers(2, 12))   # (few levels each: E stays small)
     for kind in kinds:
         if kind == "dense":
-            k = int(rng.choice([1, 3, 16, 17, 64, 128, 130]))
+            k = int(rng.choice([1, 3, 5, 8, 10, 11, 12, 16, 17, 24, 33, 50, 64, 100, 128, 130]))
             X = rng.standard_normal((n, k)).astype(dtype)
             if rng.random() < 0.5:
                 X = np.asfortranarray(X)
