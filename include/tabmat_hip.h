@@ -533,6 +533,16 @@ int tm_cat_matvec_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_
                       const double *v, const int32_t *cols, int64_t n_cols_sel, double *out,
                       void *stream);
 
+/* The same into FRESH storage: out[i] = v[col(i)] for the rows whose column is selected, 0 for every other row
+ * (out need not be initialised; no read of out).  What CategoricalMatrix.matvec computes when the caller passes
+ * no `out` (categorical_matrix.py:495-541 allocates zeros and adds). */
+int tm_cat_matvec_assign_f32(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                             const float *v, const int32_t *cols, int64_t n_cols_sel, float *out,
+                             void *stream);
+int tm_cat_matvec_assign_f64(const int32_t *codes, int64_t n, int64_t n_cols, int drop_first,
+                             const double *v, const int32_t *cols, int64_t n_cols_sel, double *out,
+                             void *stream);
+
 /* out[i_ncol x j_ncol] (row-major): out[col_i(k), col_j(k)] = sum_{k in rows} d[k].
  * Replaces _sandwich_cat_cat_{fast,complex} (cat_split_helpers-tmpl.cpp:44-94) as bound by
  * sandwich_cat_cat (ext/split.pyx:83-111). */

@@ -284,7 +284,10 @@ class CategoricalMatrix(MatrixBase):
         if cols is not None and D.nlen(cols) == self.shape[1]:
             cols = None
         if out is None:
-            out = D.zeros((self.shape[0],), other.dtype)
+            # fresh storage is written, not zero-filled and added to
+            out = D.out_buf((self.shape[0],), other.dtype)
+            xc.matvec_assign(self._dev(), other, self.shape[0], cols, self.shape[1], out, self.drop_first)
+            return out
         xc.matvec(self._dev(), other, self.shape[0], cols, self.shape[1], out, self.drop_first)
         return out
 

@@ -38,6 +38,16 @@ def matvec(indices, other, n_rows, cols, n_cols, out_vec, drop_first=False):
          D.p(other), D.p(cols), D.nlen(cols), D.p(out_vec), D.stream_ptr())
 
 
+def matvec_assign(indices, other, n_rows, cols, n_cols, out_vec, drop_first=False):
+    """The same into fresh storage (out_vec need not be initialised): out_vec[i] = other[col(i)] or 0."""
+    if cols is not None and D.nlen(cols) == 0:      # (an empty tensor has no pointer to tell it from "all columns")
+        out_vec.zero_()
+        return
+    D.same_float("matvec", other, out_vec)
+    call(f"tm_cat_matvec_assign_{D.fsuf(out_vec)}", D.p(indices), n_rows, n_cols, int(drop_first),
+         D.p(other), D.p(cols), D.nlen(cols), D.p(out_vec), D.stream_ptr())
+
+
 def sandwich_categorical(indices, d, rows, n_cols, drop_first=False):
     """ext/categorical.pyx:183-218 (sandwich_categorical_fast/_complex): the diagonal."""
     res = D.zeros((n_cols,), d.dtype)

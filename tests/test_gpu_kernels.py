@@ -418,6 +418,39 @@ def test_sparse_matvec_stream_path(dtype, n, m, dens):
     assert res is out and np.abs(out - (ref_tmv - 1.25)).max() / scale_tmv < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("drop_first,missing", [(False, False), (True, False), (False, True), (True, True)])
+def test_categorical_matvec_quads_and_fresh_output(dtype, drop_first, missing):
+    """CategoricalMatrix.matvec (cat.hip cat_matvec_quad_kernel): four rows per lane, row counts around a quad and
+    around the grid stride; without `out` the result is written into fresh storage (tm_cat_matvec_assign_*), with
+    `out` it is added; column selections; bit-exact (one term per row)."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(4242)
+    for n in (1, 2, 3, 4, 5, 7, 1023, 1024, 100_003, 2_100_001, 1_300_002):
+        # (7000 / 12000 levels over >= 64 rows per level: the coefficient vector is staged in LDS)
+        ncat = 7000 if n == 2_100_001 else 12_000 if n == 1_300_002 else int(rng.choice([1, 3, 50, 7000]))
+        codes = rng.integers(0, ncat, n)
+        if missing:
+            codes = np.where(rng.random(n) < 0.2, -1, codes)
+        mat = tm.CategoricalMatrix(codes, categories=np.arange(ncat), drop_first=drop_first, dtype=dtype,
+                                   cat_missing_method="zero" if missing else "fail")
+        k = mat.shape[1]
+        v = rng.standard_normal(k).astype(dtype)
+        col = codes - int(drop_first)
+        ref = np.where(col >= 0, v[np.clip(col, 0, max(k - 1, 0))] if k else 0.0, 0.0).astype(dtype)
+        got = mat.matvec(v)
+        assert got.dtype == dtype and np.array_equal(got, ref), (n, ncat)
+        out = np.full(n, 1.5, dtype=dtype)
+        res = mat.matvec(v, out=out)
+        assert res is out and np.array_equal(out, (ref + dtype(1.5)).astype(dtype))
+        if k >= 2:
+            cols = np.sort(rng.choice(k, size=max(1, k // 2), replace=False))
+            keep = np.isin(col, cols)
+            assert np.array_equal(mat.matvec(v, cols=cols), np.where(keep, ref, 0).astype(dtype))
+        assert np.array_equal(mat.matvec(v, cols=np.array([], dtype=np.int64)), np.zeros(n, dtype=dtype))
+
+
 # ------------------------------------------------------------------ K4 categorical family
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("ncat", [3, 1000, 10_000, 58_059])
