@@ -569,6 +569,20 @@ int tm_cat_cat_sandwich_atomic_f64(const int32_t *i_codes, const int32_t *j_code
                                    int64_t j_ncol, int i_drop_first, int j_drop_first, double *out,
                                    void *stream);
 
+/* The same table from rows GROUPED BY the level of categorical i (static per pair, built by the host layer
+ * once): perm[p] = row of position p (rows without a column of i left out), ci_sorted[p] / cj_sorted[p] = the
+ * column indices of that row (drop_first applied; cj_sorted < 0: the row has no column of j), lptr[c] = first
+ * position of level c (i_ncol + 1 entries).  out[i_ncol][j_ncol] is overwritten with
+ * sum over p of d[perm[p]] at (ci_sorted[p], cj_sorted[p]).  One pass over the rows whatever the size of the
+ * table (each LDS tile of levels reads only its own positions); needs j_ncol * 8 <= 128 KB.  A row restriction
+ * is a d masked with zeros.  Reference: ext/split.pyx:83-111. */
+int tm_cat_cat_sandwich_sorted_f32(const int32_t *ci_sorted, const int32_t *cj_sorted, const int32_t *perm,
+                                   const int64_t *lptr, int64_t n_sorted, const float *d, int64_t i_ncol,
+                                   int64_t j_ncol, float *out, void *stream);
+int tm_cat_cat_sandwich_sorted_f64(const int32_t *ci_sorted, const int32_t *cj_sorted, const int32_t *perm,
+                                   const int64_t *lptr, int64_t n_sorted, const double *d, int64_t i_ncol,
+                                   int64_t j_ncol, double *out, void *stream);
+
 /* out[i_ncol x n_j] (row-major): out[col(k), jc] = sum_{k in rows} d[k] * M[k, j_cols[jc]].
  * Replaces _sandwich_cat_dense{C,F}_{fast,complex} (cat_split_helpers-tmpl.cpp:97-151) as bound
  * by sandwich_cat_dense (ext/split.pyx:32-80). */

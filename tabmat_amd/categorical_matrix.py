@@ -469,11 +469,42 @@ class CategoricalMatrix(MatrixBase):
                                              R_cols, self.drop_first)
             return self._restrict(res, L_cols, None)
         if isinstance(other, CategoricalMatrix):
+            if (other is not self and d.dtype in (torch.float32, torch.float64)
+                    and xsplit.cat_cat_sorted_pays(self.shape[0], self.shape[1], other.shape[1])):
+                # a table of several LDS tiles: rows grouped by this block's level (static twin of the pair), every
+                # tile reads only its own rows; a row restriction is a masked d
+                if rows is not None:
+                    dm = torch.zeros_like(d)
+                    r64 = rows.to(torch.int64)
+                    dm[r64] = d[r64]
+                    d = dm
+                res = xsplit.sandwich_cat_cat_sorted(self._sorted_pair(other), self.shape[1], other.shape[1], d)
+                return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_cat(self._dev(), other._dev(), self.shape[1],
                                           other.shape[1], d, rows, self.drop_first,
                                           other.drop_first, hot=min(self._hot_count(), other._hot_count()))
             return self._restrict(res, L_cols, R_cols)
         raise TypeError
+
+    def _sorted_pair(self, other):
+        """(ci_sorted, cj_sorted, perm, lptr) for tm_cat_cat_sandwich_sorted_*: this block's rows in level order
+        (the perm of _det_plan), both blocks' column indices in that order, the first position of every level.
+        Static per pair; cached by the partner's identity."""
+        cache = self.__dict__.setdefault("_sorted_pairs", {})
+        key = id(other)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not other:
+            perm = self._det_plan()[0]
+            p64 = perm.to(torch.int64)
+            ci_s = (self._dev()[p64] - int(self.drop_first)).to(torch.int32).contiguous()
+            cj = other._dev()[p64].to(torch.int32) - int(other.drop_first)
+            cj_s = torch.where((cj >= 0) & (cj < other.shape[1]), cj, torch.full_like(cj, -1)).contiguous()
+            cnt = torch.bincount(ci_s.to(torch.int64), minlength=self.shape[1]) if ci_s.numel() else \
+                torch.zeros(self.shape[1], dtype=torch.int64, device=ci_s.device)
+            lptr = torch.zeros(self.shape[1] + 1, dtype=torch.int64, device=ci_s.device)
+            torch.cumsum(cnt, dim=0, out=lptr[1:])
+            hit = cache[key] = (other, (ci_s, cj_s, perm, lptr.contiguous()))
+        return hit[1]
 
     def _hot_count(self) -> int:
         """Rows of the most frequent level (cached): an upper bound of what one cell of a

@@ -131,6 +131,52 @@ __global__ __launch_bounds__(256) void hist_global_kernel(
     }
 }
 
+// 2-D weighted histogram over rows GROUPED BY the level of categorical i (static per pair of categoricals: perm =
+// the rows in level order, ci_s / cj_s = the two column indices in that order, lptr = first position of every
+// level).  Part p owns the levels [p * ti, (p + 1) * ti) -- one LDS tile of the table -- and reads ONLY the
+// positions of those levels: one pass over the rows whatever the number of parts, against n_parts passes for
+// hist_lds_kernel<F, true> and one device-scope atomic per row (23 G/s) for hist_global_kernel.  Per row: 12
+// bytes of coalesced loads, one gather of the weight, one ds_add_f64.
+template <typename F>
+__global__ __launch_bounds__(1024) void hist_sorted_kernel(
+    const int32_t *__restrict__ ci_s, const int32_t *__restrict__ cj_s, const int32_t *__restrict__ perm,
+    const int64_t *__restrict__ lptr, const F *__restrict__ w, int i_ncol, int j_ncol, int ti,
+    F *__restrict__ ws, int64_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lds_acc_t *bins = reinterpret_cast<lds_acc_t *>(smem_raw);
+    const int part = blockIdx.y;
+    const int i0 = part * ti;
+    const int i1 = min(i0 + ti, i_ncol);
+    const int nbins = (i1 - i0) * j_ncol;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) bins[b] = 0.0;
+    __syncthreads();
+    const int64_t p0 = lptr[i0], p1 = lptr[i1];
+    const int64_t per = (p1 - p0 + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = p0 + (int64_t)blockIdx.x * per, t1 = min(t0 + per, p1);
+    const int B = blockDim.x;
+    int64_t t = t0 + threadIdx.x;
+    for (; t + 3 * (int64_t)B < t1; t += 4 * (int64_t)B) {          // four positions per lane in flight
+        int c[4], c2[4];
+        F x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = ci_s[t + u * B];
+            c2[u] = cj_s[t + u * B];
+            x[u] = w[perm[t + u * B]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c2[u] >= 0) atomic_add(&bins[(c[u] - i0) * j_ncol + c2[u]], (lds_acc_t)x[u]);
+    }
+    for (; t < t1; t += B) {
+        const int c2 = cj_s[t];
+        if (c2 >= 0) atomic_add(&bins[(ci_s[t] - i0) * j_ncol + c2], (lds_acc_t)w[perm[t]]);
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)part * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < nbins; b += blockDim.x) dst[b] = (F)bins[b];
+}
+
 constexpr size_t HIST_LDS_MAX = 128 * 1024;
 
 // Generic driver.  For !TWO: out[i_ncol] (accumulate or overwrite).  For TWO: out[i_ncol*j_ncol].
@@ -184,6 +230,43 @@ static int run_hist(const int32_t *ci, const int32_t *cj, const F *w, const int3
     TM_LAUNCH_CHECK();
     return launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, out, total, accumulate,
                                      st);
+}
+
+template <typename F>
+static int run_hist_sorted(const int32_t *ci_s, const int32_t *cj_s, const int32_t *perm, const int64_t *lptr,
+                           int64_t n_sorted, const F *w, int64_t i_ncol, int64_t j_ncol, F *out, hipStream_t st) {
+    const int64_t total = i_ncol * j_ncol;
+    if (total == 0) return TM_OK;
+    const size_t row_bytes = sizeof(lds_acc_t) * (size_t)j_ncol;
+    TM_REQUIRE(row_bytes <= HIST_LDS_MAX && total < (int64_t)INT32_MAX,
+               "cat x cat (level-sorted): one row of the table must fit the LDS tile");
+    if (n_sorted == 0) {
+        TM_HIP(hipMemsetAsync(out, 0, sizeof(F) * (size_t)total, st));
+        return TM_OK;
+    }
+    int64_t ti = std::min<int64_t>(i_ncol, (int64_t)(HIST_LDS_MAX / row_bytes));
+    const int64_t n_parts = ceil_div(i_ncol, ti);
+    ti = ceil_div(i_ncol, n_parts);
+    const int64_t stride = ti * j_ncol;
+    const size_t lds = (size_t)stride * sizeof(lds_acc_t);
+    const int threads = lds > 64 * 1024 ? 1024 : 512;
+    const int per_cu = lds > 64 * 1024 ? 1 : 2;
+    // workgroups per part: two rounds over the chip, at least ~4096 positions each
+    int64_t nblk = std::max<int64_t>(1, ceil_div(2 * NUM_CU * per_cu, n_parts));
+    nblk = std::min<int64_t>(nblk, std::max<int64_t>(1, n_sorted / n_parts / 4096));
+    void *wsv = nullptr;
+    int rc = get_workspace(sizeof(F) * (size_t)(n_parts * nblk * stride) + 256, &wsv, st);
+    if (rc) return rc;
+    F *ws = reinterpret_cast<F *>(wsv);
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_sorted_kernel<F>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    prof_begin(st);
+    hipLaunchKernelGGL((hist_sorted_kernel<F>), dim3((unsigned)nblk, (unsigned)n_parts), dim3(threads), lds, st,
+                       ci_s, cj_s, perm, lptr, w, (int)i_ncol, (int)j_ncol, (int)ti, ws, stride);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    return launch_reduce_partials<F>(ws, stride, (int)nblk, (int)n_parts, out, total, false, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1600,6 +1683,21 @@ int tm_cat_cat_sandwich_atomic_f64(const int32_t *i_codes, const int32_t *j_code
     return run_hist<double, true>(i_codes, j_codes, d, rows, rows ? n_rows : n, i_drop_first,
                                   j_drop_first, i_ncol, j_ncol, nullptr, out, false,
                                   as_stream(stream), 12);
+}
+
+int tm_cat_cat_sandwich_sorted_f32(const int32_t *ci_sorted, const int32_t *cj_sorted, const int32_t *perm,
+                                   const int64_t *lptr, int64_t n_sorted, const float *d, int64_t i_ncol,
+                                   int64_t j_ncol, float *out, void *stream) {
+    TM_CHECK_COMMON(n_sorted);
+    return run_hist_sorted<float>(ci_sorted, cj_sorted, perm, lptr, n_sorted, d, i_ncol, j_ncol, out,
+                                  as_stream(stream));
+}
+int tm_cat_cat_sandwich_sorted_f64(const int32_t *ci_sorted, const int32_t *cj_sorted, const int32_t *perm,
+                                   const int64_t *lptr, int64_t n_sorted, const double *d, int64_t i_ncol,
+                                   int64_t j_ncol, double *out, void *stream) {
+    TM_CHECK_COMMON(n_sorted);
+    return run_hist_sorted<double>(ci_sorted, cj_sorted, perm, lptr, n_sorted, d, i_ncol, j_ncol, out,
+                                   as_stream(stream));
 }
 
 int tm_cat_dense_sandwich_f32(const int32_t *codes, int64_t n, int64_t i_ncol, int drop_first,

@@ -39,6 +39,26 @@ def sandwich_cat_cat(i_indices, j_indices, i_ncol, j_ncol, d, rows, i_drop_first
     return res
 
 
+CAT_CAT_SORTED_MIN_ROWS = 200_000
+
+
+def cat_cat_sorted_pays(n, i_ncol, j_ncol, itemsize=8) -> bool:
+    """The level-sorted table kernel (tm_cat_cat_sandwich_sorted_*) instead of one device-scope atomic per row
+    (23 G/s) or one pass over the codes per LDS tile of the table: when the table needs several tiles, a row of it
+    fits one, and the rows pay for the static sorted twin (12 bytes per row)."""
+    return (n >= CAT_CAT_SORTED_MIN_ROWS and j_ncol * 8 <= 128 * 1024 and i_ncol * j_ncol * 8 > 128 * 1024
+            and i_ncol * j_ncol < 2**31 - 1)
+
+
+def sandwich_cat_cat_sorted(twin, i_ncol, j_ncol, d):
+    """twin = (ci_sorted, cj_sorted, perm, lptr) of the pair (CategoricalMatrix._sorted_pair)."""
+    ci_s, cj_s, perm, lptr = twin
+    res = D.out_buf((i_ncol, j_ncol), d.dtype)
+    call("tm_cat_cat_sandwich_sorted_" + D.fsuf(d), D.p(ci_s), D.p(cj_s), D.p(perm), D.p(lptr), int(perm.numel()),
+         D.p(d), i_ncol, j_ncol, D.p(res), D.stream_ptr())
+    return res
+
+
 def sandwich_cat_sparse(i_indices, i_ncol, d, S: CsrDev, rows, cols, drop_first=False):
     """The kernel behind CategoricalMatrix._cross_sparse (categorical_matrix.py:825-838), which in
     the reference is a scipy.sparse product."""

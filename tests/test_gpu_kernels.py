@@ -535,6 +535,61 @@ def test_cat_cat(ni, nj, drops):
     assert np.array_equal(mi._cross_sandwich(mj, ones, None), ref)  # counts: bit-exact
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ni,nj", [(1000, 1000), (40, 5000), (7000, 33)])
+def test_cat_cat_level_sorted(dtype, ni, nj):
+    """Tables of several LDS tiles take the level-sorted kernel (tm_cat_cat_sandwich_sorted_*, static twin of the
+    pair): skewed levels (one hot cell), missing codes on both sides, empty levels, drop_first, a row restriction,
+    column selections, counts bit-exact; the twin is reused across calls and not confused between partners."""
+    import tabmat_amd as tm
+    from tabmat_amd.ext import split as xsplit
+
+    rng = np.random.default_rng(ni * 3 + nj)
+    n = 260_000
+    assert xsplit.cat_cat_sorted_pays(n, ni - 1, nj)
+    ci = np.minimum((rng.pareto(1.0, n) * 3).astype(np.int64), ni - 1).astype(np.int32)      # level 0 is hot
+    cj = rng.integers(0, nj, n).astype(np.int32)
+    cj[ci == 0] = 1                                                                          # ... in ONE cell
+    ci[rng.random(n) < 0.03] = -1
+    cj[rng.random(n) < 0.03] = -1
+    ci[ci == 5] = 6                                                                          # an empty level
+    mi = tm.CategoricalMatrix(ci, categories=np.arange(ni), drop_first=True, dtype=dtype, cat_missing_method="zero")
+    mj = tm.CategoricalMatrix(cj, categories=np.arange(nj), drop_first=False, dtype=dtype, cat_missing_method="zero")
+    mk = tm.CategoricalMatrix((cj + 1) % nj, categories=np.arange(nj), dtype=dtype)          # another partner
+    d = rng.random(n).astype(dtype)
+
+    def ref_table(a, b, w, rows=None):
+        t = np.zeros((ni - 1, nj))
+        ok = (a >= 1) & (b >= 0)
+        if rows is not None:
+            m = np.zeros(n, dtype=bool)
+            m[rows] = True
+            ok &= m
+        np.add.at(t, (a[ok] - 1, b[ok]), w[ok].astype(np.float64))
+        return t
+
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    ref = ref_table(ci, cj, d)
+    got = mi._cross_sandwich(mj, d)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= tol * max(1.0, ref.max())
+    got2 = mi._cross_sandwich(mk, d)
+    ref2 = ref_table(ci, (cj + 1) % nj, d)
+    assert np.abs(got2 - ref2).max() <= tol * max(1.0, ref2.max())
+    assert np.abs(mi._cross_sandwich(mj, d) - ref).max() <= tol * max(1.0, ref.max())          # twin reused
+    rows = _rows_subset(rng, n)
+    refr = ref_table(ci, cj, d, rows)
+    lc = np.sort(rng.choice(ni - 1, size=min(20, ni - 1), replace=False)).astype(np.int32)
+    rc = np.sort(rng.choice(nj, size=min(25, nj), replace=False)).astype(np.int32)
+    gotr = mi._cross_sandwich(mj, d, rows, lc, rc)
+    assert np.abs(gotr - refr[lc][:, rc]).max() <= tol * max(1.0, refr.max())
+    ones = np.ones(n, dtype=dtype)
+    assert np.array_equal(mi._cross_sandwich(mj, ones), ref_table(ci, cj, ones))             # counts: exact
+    # the whole SplitMatrix product goes the same way
+    sp = tm.SplitMatrix([mi, mj])
+    S = sp.sandwich(d)
+    assert np.abs(S[: ni - 1, ni - 1:] - ref).max() <= tol * max(1.0, ref.max())
+
+
 @pytest.mark.parametrize("order", ["C", "F"])
 @pytest.mark.parametrize("ncat,k", [(5, 3), (256, 128), (1000, 40), (20_000, 16)])
 def test_cat_dense(order, ncat, k):
