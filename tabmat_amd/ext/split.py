@@ -39,15 +39,20 @@ def sandwich_cat_cat(i_indices, j_indices, i_ncol, j_ncol, d, rows, i_drop_first
     return res
 
 
-CAT_CAT_SORTED_MIN_ROWS = 200_000
+CAT_CAT_SORTED_MIN_ROWS = 500_000      # (below: 19 ps per row saved do not pay for a static twin of the pair)
 
 
 def cat_cat_sorted_pays(n, i_ncol, j_ncol, itemsize=8) -> bool:
     """The level-sorted table kernel (tm_cat_cat_sandwich_sorted_*) instead of one device-scope atomic per row
     (23 G/s) or one pass over the codes per LDS tile of the table: when the table needs several tiles, a row of it
     fits one, and the rows pay for the static sorted twin (12 bytes per row)."""
-    return (n >= CAT_CAT_SORTED_MIN_ROWS and j_ncol * 8 <= 128 * 1024 and i_ncol * j_ncol * 8 > 128 * 1024
-            and i_ncol * j_ncol < 2**31 - 1)
+    if not (n >= CAT_CAT_SORTED_MIN_ROWS and 0 < j_ncol * 8 <= 128 * 1024 and i_ncol * j_ncol < 2**31 - 1):
+        return False
+    # measured per row: the LDS-tiled kernel ~3 ps per PASS (16 coalesced bytes; one pass per tile of levels), global
+    # atomics 43 ps, this kernel 24 ps (12 coalesced bytes + a 64-byte sector for the gathered weight): it pays from
+    # eight tiles on (BASELINE configs[3]'s 256 x 96 table is two tiles and stays with the tiled kernel)
+    ti = (128 * 1024) // (8 * j_ncol)
+    return -(-i_ncol // ti) >= 8
 
 
 def sandwich_cat_cat_sorted(twin, i_ncol, j_ncol, d):

@@ -545,7 +545,7 @@ def test_cat_cat_level_sorted(dtype, ni, nj):
     from tabmat_amd.ext import split as xsplit
 
     rng = np.random.default_rng(ni * 3 + nj)
-    n = 260_000
+    n = 520_000
     assert xsplit.cat_cat_sorted_pays(n, ni - 1, nj)
     ci = np.minimum((rng.pareto(1.0, n) * 3).astype(np.int64), ni - 1).astype(np.int32)      # level 0 is hot
     cj = rng.integers(0, nj, n).astype(np.int32)
