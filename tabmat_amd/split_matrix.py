@@ -803,6 +803,35 @@ class SplitMatrix(MatrixBase):
                         res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
                         xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
                     done.add((min(i, w), max(i, w)))
+        # ---- categoricals with too many levels for the fused groups, against a NARROW dense block: the generic
+        #      LDS-tile kernel holds [all their levels][8 columns or fewer] at once, so one pass over the block
+        #      serves them all (the reference's design dense_cat: two 1000-level categoricals x 5 dense columns were
+        #      two passes of 0.08 ms)
+        big = [i for i in cat_ids if mats[i].shape[1] > self.FUSED_LEVELS]
+        if len(big) >= 2 and len(big) <= 16 and d.dtype == D.torch_dtype(self.dtype):
+            cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in big]
+            offs = np.concatenate([[0], np.cumsum([c[1] for c in cats])])
+            d_big = None
+            for w, mw in enumerate(mats):
+                if (empty[w] or not isinstance(mw, DenseMatrix) or mw.dtype != self.dtype
+                        or not xsplit.multi_cat_dense_tile_ok(cats, mw._dev_c())):
+                    continue
+                if d_big is None:
+                    d_big = d
+                    if rows is not None:
+                        d_big = torch.zeros_like(d)
+                        r64 = rows.to(torch.int64)
+                        d_big[r64] = d[r64]
+                stacked = xsplit.multi_cat_dense_sandwich(cats, d_big, mw._dev_c())
+                for ci, i in enumerate(big):
+                    res = stacked[int(offs[ci]):int(offs[ci + 1])]
+                    if (colsum is not None and colsum[w] is None and not mats[i].drop_first
+                            and not mats[i]._has_missings):
+                        cs = res.sum(dim=0)
+                        colsum[w] = cs if sub_d[w] is None else cs[sub_d[w].to(torch.int64)]
+                    res = CategoricalMatrix._restrict(res, sub_d[i], sub_d[w])
+                    xsplit.scatter_block(res.contiguous(), pos_d[i], pos_d[w], out, mirror=True)
+                    done.add((min(i, w), max(i, w)))
         # ---- all categorical x categorical tables that fit an LDS tile, and the categorical
         #      diagonals, in ONE pass over the codes (tm_multi_cat_pairs_*): a design with k
         #      categoricals has k (k - 1) / 2 of them, one launch each was ~30 us apiece

@@ -591,6 +591,45 @@ def test_cat_cat_level_sorted(dtype, ni, nj):
 
 
 @pytest.mark.parametrize("order", ["C", "F"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_many_level_categoricals_share_one_pass_over_a_narrow_dense_block(order, dtype, monkeypatch):
+    """Categoricals with more levels than the fused groups take (> 496) against a dense block of a few columns: ONE
+    launch of the LDS-tile kernel for all of them (the reference's design dense_cat), with a row restriction, a
+    column selection and a second, wide dense block that keeps its own path."""
+    import tabmat_amd as tm
+    from tabmat_amd import _lib
+
+    rng = np.random.default_rng(77)
+    n = 30_000
+    c1 = rng.integers(0, 600, n)
+    c2 = np.where(rng.random(n) < 0.05, -1, rng.integers(0, 700, n))
+    c3 = rng.integers(0, 12, n)
+    Xn = rng.standard_normal((n, 5)).astype(dtype)
+    Xn = np.asfortranarray(Xn) if order == "F" else Xn
+    Xw = rng.standard_normal((n, 40)).astype(dtype)
+    blocks = [tm.CategoricalMatrix(c1, categories=np.arange(600), dtype=dtype),
+              tm.DenseMatrix(Xn),
+              tm.CategoricalMatrix(c2, categories=np.arange(700), drop_first=True, dtype=dtype, cat_missing_method="zero"),
+              tm.CategoricalMatrix(c3, categories=np.arange(12), dtype=dtype),
+              tm.DenseMatrix(Xw)]
+    X = tm.SplitMatrix(blocks)
+    E = X.toarray().astype(np.float64)
+    d = rng.random(n).astype(dtype)
+    seen = []
+    real = _lib.call
+    monkeypatch.setattr("tabmat_amd.ext.split.call", lambda name, *a: (seen.append(name), real(name, *a))[1])
+    tol = F64_TOL if dtype == np.float64 else 2e-5
+    ref = E.T @ (E * d.astype(np.float64)[:, None])
+    assert nat_err(X.sandwich(d), ref) < tol
+    # the 600- and the 700-level block against the 5 columns: one fused launch
+    assert sum(s_.startswith("tm_multi_cat_dense_sandwich_") for s_ in seen) <= 3
+    rows = _rows_subset(rng, n)
+    cols = np.sort(rng.choice(E.shape[1], size=E.shape[1] // 2, replace=False))
+    refr = E[rows][:, cols].T @ (E[rows][:, cols] * d.astype(np.float64)[rows, None])
+    assert nat_err(X.sandwich(d, rows=rows, cols=cols), refr) < tol
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
 @pytest.mark.parametrize("ncat,k", [(5, 3), (256, 128), (1000, 40), (20_000, 16)])
 def test_cat_dense(order, ncat, k):
     import tabmat_amd as tm
