@@ -476,7 +476,7 @@ class CategoricalMatrix(MatrixBase):
                 if rows is not None:
                     dm = torch.zeros_like(d)
                     r64 = rows.to(torch.int64)
-                    dm[r64] = d[r64]
+                    dm.index_add_(0, r64, d[r64])          # (a repeated row counts once per occurrence)
                     d = dm
                 res = xsplit.sandwich_cat_cat_sorted(self._sorted_pair(other), self.shape[1], other.shape[1], d)
                 return self._restrict(res, L_cols, R_cols)

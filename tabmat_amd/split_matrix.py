@@ -821,7 +821,7 @@ class SplitMatrix(MatrixBase):
                     if rows is not None:
                         d_big = torch.zeros_like(d)
                         r64 = rows.to(torch.int64)
-                        d_big[r64] = d[r64]
+                        d_big.index_add_(0, r64, d[r64])   # (a repeated row counts once per occurrence)
                 stacked = xsplit.multi_cat_dense_sandwich(cats, d_big, mw._dev_c())
                 for ci, i in enumerate(big):
                     res = stacked[int(offs[ci]):int(offs[ci + 1])]
