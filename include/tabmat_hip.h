@@ -279,6 +279,18 @@ int tm_sparse_sandwich_blocks_f64(const double *cm_data, const int32_t *cm_indic
                                   const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
                                   void *stream);
 
+/* The same with the columns as ONE BYTE per entry: cm_col8[p] = column of chunk-major entry p inside its
+ * 128-column chunk (cm_indices[p] % tm_sparse_chunk_cols()).  The entry gathers of the kernel move a quarter of the
+ * index bytes. */
+int tm_sparse_sandwich_blocks_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                     int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                     const int32_t *wg_tab, int n_wg, int max_nb, const float *d, float *out,
+                                     void *stream);
+int tm_sparse_sandwich_blocks_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                     int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                     const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
+                                     void *stream);
+
 /* out[nA x nB] = A[rows,A_cols]^T diag(d) B[rows,B_cols]; A sparse (CSR, n x m), B dense (n x r).
  * Replaces _csr_dense{C,F}_sandwich (ext/sparse_helpers-tmpl.cpp:23-146) as bound by
  * csr_dense_sandwich (ext/sparse.pyx:211-260). */

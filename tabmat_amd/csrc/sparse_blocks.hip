@@ -50,7 +50,9 @@ __global__ void blocks_assemble_kernel(const F *__restrict__ tiles, int n_out, F
 constexpr int KB_FLAG_REP_A = 1 << 16;     // lane t takes A entry t & 3
 constexpr int KB_FLAG_REP_B = 1 << 17;     // lane t takes B entry t & 3
 
-template <typename F>
+// U8: `ind` points at BYTES, the column of an entry inside its 128-column chunk (a quarter of the index bytes the
+// entry gathers move).
+template <typename F, bool U8>
 __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int32_t *__restrict__ cptr,
     int64_t n, int64_t nnz1, const int4 *__restrict__ blocks, const int4 *__restrict__ wg_tab,
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
         const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[row_last + 1]) - baseB - 1, 0);
         const F *dataA = data + min((int64_t)baseA, nnz1), *dataB = data + min((int64_t)baseB, nnz1);
         const int32_t *indA = ind + min((int64_t)baseA, nnz1), *indB = ind + min((int64_t)baseB, nnz1);
+        const unsigned char *ind8 = reinterpret_cast<const unsigned char *>(ind);
+        const unsigned char *ind8A = ind8 + min((int64_t)baseA, nnz1), *ind8B = ind8 + min((int64_t)baseB, nnz1);
+        // (byte columns are chunk-relative: the tile origin is already taken off)
+        const int i0c = U8 ? 0 : i0, j0c = U8 ? 0 : j0;
         const unsigned nrow1 = (unsigned)max(n - 1, (int64_t)0);
         auto ldi = [](const int32_t *base, unsigned i) {
             return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (i << 2));
@@ -156,9 +162,9 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                 e.vb = ldf(dataB, min(iBw, spanB1));
                 return e;
 #endif
-                e.ca = ldi(indA, iA);
+                e.ca = U8 ? (int)ind8A[iA] : ldi(indA, iA);
                 e.va = ldf(dataA, iA);
-                e.cb = ldi(indB, iB);
+                e.cb = U8 ? (int)ind8B[iB] : ldi(indB, iB);
                 e.vb = ldf(dataB, iB);
                 return e;
             };
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                 // the pair steps run at a raised wave priority (ahead of the other waves' address arithmetic and
                 // gathers, which wait for memory anyway): 4.08 -> 4.02 ms (profiles/r4_k2b.txt)
                 __builtin_amdgcn_s_setprio(1);
-                const int colA = cur.ta < cur.nA ? cur.ca - i0 : -1;
-                const int colB = cur.tb < cur.nB ? cur.cb - j0 : -1;
+                const int colA = cur.ta < cur.nA ? cur.ca - i0c : -1;
+                const int colB = cur.tb < cur.nB ? cur.cb - j0c : -1;
                 const int la = (colA < 0 ? -8 : colA << SH) | offmask;
                 const int ba = (int)(((unsigned)colA << (7 + SH)) | ((colA & 15) << (3 + SH)));
                 const int kb = colB < 0 ? BIGKEY : colB << SH;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
     }
 }
 
-template <typename F>
+template <typename F, bool U8 = false>
 static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const int32_t *cptr, int64_t n,
                                       int64_t m, int64_t nnz, const int32_t *blocks, const int32_t *wg_tab,
                                       int n_wg, int max_nb, const F *d, F *out, hipStream_t st) {
@@ -255,7 +261,7 @@ static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const i
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     // tiles have different numbers of workgroups: unused partial slots must read as 0
     TM_HIP(hipMemsetAsync(ws, 0, ws_bytes, st));
-    auto kern = &sparse_sandwich_blocks_kernel<F>;
+    auto kern = &sparse_sandwich_blocks_kernel<F, U8>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
@@ -292,6 +298,24 @@ int tm_sparse_sandwich_blocks_f64(const double *cm_data, const int32_t *cm_indic
                                   void *stream) {
     return tmh::run_sparse_sandwich_blocks<double>(cm_data, cm_indices, cptr, n, m, nnz, blocks, wg_tab, n_wg,
                                                    max_nb, d, out, tmh::as_stream(stream));
+}
+
+// the same with the columns as one byte per entry: column inside the entry's 128-column chunk
+int tm_sparse_sandwich_blocks_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                     int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                     const int32_t *wg_tab, int n_wg, int max_nb, const float *d, float *out,
+                                     void *stream) {
+    return tmh::run_sparse_sandwich_blocks<float, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr, n, m,
+                                                        nnz, blocks, wg_tab, n_wg, max_nb, d, out,
+                                                        tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_blocks_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                     int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
+                                     const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
+                                     void *stream) {
+    return tmh::run_sparse_sandwich_blocks<double, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr, n, m,
+                                                         nnz, blocks, wg_tab, n_wg, max_nb, d, out,
+                                                         tmh::as_stream(stream));
 }
 
 }  // extern "C"

@@ -62,6 +62,17 @@ class CsrDev:
     def dtype(self):
         return self.data.dtype
 
+    def chunk_col8(self):
+        """uint8 [nnz]: the column of every chunk-major entry inside its column chunk (tm_sparse_sandwich_blocks_u8_*)."""
+        c8 = getattr(self, "_cm_col8", None)
+        if c8 is None:
+            from .._lib import lib
+
+            ch = int(lib().tm_sparse_chunk_cols())
+            _, cm_ind, _ = self.chunk_major()
+            c8 = self._cm_col8 = torch.remainder(cm_ind, ch).to(torch.uint8).contiguous()
+        return c8
+
     def chunk_major(self):
         """(cm_data, cm_indices, cptr int32 [NCH, n + 1]): the entries regrouped by column chunk,
         inside a chunk by row (see tm_sparse_sandwich_chunked_*).  Built once per block (ingest:

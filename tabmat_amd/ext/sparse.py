@@ -2,6 +2,8 @@
 a sparse block is kept on the device; see include/tabmat_hip.h."""
 from __future__ import annotations
 
+import os
+
 
 from .. import _device as D
 from .._lib import call
@@ -253,6 +255,9 @@ def blocks_sandwich_pays(A: CsrDev) -> bool:
     return est * 3 < torch.cuda.mem_get_info(A.data.device)[0] or getattr(A, "_pb", None) is not None
 
 
+K2B_U8 = os.environ.get("TABMAT_AMD_K2B_U8", "1") == "1"     # byte columns for the block-list kernel's gathers
+
+
 def sparse_sandwich_blocks(A: CsrDev, d):
     """ext/sparse.pyx:17-77, unrestricted, on the static block list (tm_sparse_sandwich_blocks_*)."""
     if A.m == 0 or A.n == 0:
@@ -261,6 +266,11 @@ def sparse_sandwich_blocks(A: CsrDev, d):
     D.same_float("sparse_sandwich_blocks", A.data, d)
     cm_data, cm_ind, cptr = A.chunk_major()
     blocks, wg_tab, max_nb = A.pair_blocks()
+    if K2B_U8:
+        call(f"tm_sparse_sandwich_blocks_u8_{D.fsuf(A.data)}", D.p(cm_data), D.p(A.chunk_col8()), D.p(cptr), A.n, A.m,
+             int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
+             D.p(out), D.stream_ptr())
+        return out
     call(f"tm_sparse_sandwich_blocks_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr), A.n, A.m,
          int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
          D.p(out), D.stream_ptr())
