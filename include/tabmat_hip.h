@@ -456,6 +456,22 @@ int tm_csr_matvec_f64(const double *csr_data, const int32_t *csr_indices,
                       const int32_t *rows, int64_t n_rows, const int32_t *cols, int64_t n_cols,
                       double *out, void *stream);
 
+/* The unrestricted form (all rows, all columns) on a 16-BIT twin of the column indices (blocks of at most 65536
+ * columns; csr_indices16[k] = (uint16_t)csr_indices[k]): 10 instead of 12 bytes per entry leave HBM.  The
+ * coefficient vector is staged in LDS: needs sizeof(F) * (m + 4096) <= 64 KB. */
+int tm_csr_matvec_u16_f32(const float *csr_data, const uint16_t *csr_indices16, const int64_t *csr_indptr,
+                          int64_t n, int64_t m, const float *v, float *out, void *stream);
+int tm_csr_matvec_u16_f64(const double *csr_data, const uint16_t *csr_indices16, const int64_t *csr_indptr,
+                          int64_t n, int64_t m, const double *v, double *out, void *stream);
+
+/* out[j] += sum_i v[i] * X[i, j] (all rows, all columns) on the same 16-bit twin; values and 16-bit columns must
+ * start at entries of the same parity (both freshly allocated arrays do); accumulators in LDS:
+ * 8 * (m + 1) + sizeof(F) * 4096 <= 128 KB. */
+int tm_csr_rmatvec_u16_f32(const float *csr_data, const uint16_t *csr_indices16, const int64_t *csr_indptr,
+                           int64_t n, int64_t m, const float *v, float *out, void *stream);
+int tm_csr_rmatvec_u16_f64(const double *csr_data, const uint16_t *csr_indices16, const int64_t *csr_indptr,
+                           int64_t n, int64_t m, const double *v, double *out, void *stream);
+
 /* out[Cj] += sum_{i in rows} X[i, cols[Cj]] * v[i]      (v length n; out length n_cols).
  * Replaces csc_rmatvec_unrestricted / csc_rmatvec (ext/sparse.pyx:142-199).  The reference
  * walks CSC columns; on the GPU the CSR twin is streamed row by row (the order rows are

@@ -110,32 +110,51 @@ constexpr int CSR_EPL = CSR_CAP / 64;   // entries per lane and tile
 // registers ONE TILE AHEAD of the tile being worked on, and the row pointers / vector entries of a chunk one chunk
 // ahead.  A tile starts at an even entry (vector alignment): the entry in front of a chunk's first one, if any, is
 // fetched with it and ignored.
-template <typename F>
+// (the column pairs stay as loaded -- int32 pairs or one packed word of two uint16 -- and are taken apart where they
+// are used: unpacking at load time made the compiler wait for every index load in turn)
+template <typename F, typename IDX = int32_t>
 struct CsrTile {
     F x[CSR_EPL];
     int32_t j[CSR_EPL];
+    __device__ __forceinline__ void set_pair(int k, int32_t a, int32_t b) { j[2 * k] = a; j[2 * k + 1] = b; }
+    __device__ __forceinline__ void load_pair(int k, const int32_t *p) {
+        typedef int32_t i2 __attribute__((ext_vector_type(2)));
+        const i2 v = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(p));
+        j[2 * k] = v[0];
+        j[2 * k + 1] = v[1];
+    }
+    __device__ __forceinline__ int32_t col(int i) const { return j[i]; }
+};
+template <typename F>
+struct CsrTile<F, uint16_t> {
+    F x[CSR_EPL];
+    uint32_t jw[CSR_EPL / 2];
+    __device__ __forceinline__ void set_pair(int k, int32_t a, int32_t b) { jw[k] = (uint32_t)a | ((uint32_t)b << 16); }
+    __device__ __forceinline__ void load_pair(int k, const uint16_t *p) {
+        jw[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+    }
+    __device__ __forceinline__ int32_t col(int i) const {
+        return (i & 1) ? (int32_t)(jw[i >> 1] >> 16) : (int32_t)(jw[i >> 1] & 0xffffu);
+    }
 };
 
 // entries [c0, c0 + cnt) of the stream (data + c0 16- / 8-byte aligned, cnt <= CSR_CAP; nnz = entries in the arrays):
 // lane holds e = 2 lane + 128 k + {0, 1}.  Pairs are fetched whole; a pair whose second entry lies behind the tile
 // is fetched anyway (the consumers ignore slots >= cnt) unless it would leave the arrays -- only the first tile
 // of an odd-aligned view (c0 = -1) and the last tile of the arrays can, and they take the entry-by-entry path.
-template <typename F>
-__device__ __forceinline__ void csr_tile_load(const F *__restrict__ data, const int32_t *__restrict__ ind, int64_t c0,
-                                              int cnt, int64_t nnz, int lane, CsrTile<F> &t) {
+template <typename F, typename IDX>
+__device__ __forceinline__ void csr_tile_load(const F *__restrict__ data, const IDX *__restrict__ ind, int64_t c0,
+                                              int cnt, int64_t nnz, int lane, CsrTile<F, IDX> &t) {
     typedef F f2 __attribute__((ext_vector_type(2)));
-    typedef int32_t i2 __attribute__((ext_vector_type(2)));
     const F *dp = data + c0 + 2 * lane;
-    const int32_t *ip = ind + c0 + 2 * lane;
+    const IDX *ip = ind + c0 + 2 * lane;
     if (cnt == CSR_CAP && c0 >= 0) {
 #pragma unroll
         for (int k = 0; k < CSR_EPL / 2; ++k) {
             const f2 xv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(dp + 128 * k));
-            const i2 jv = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(ip + 128 * k));
+            t.load_pair(k, ip + 128 * k);
             t.x[2 * k] = xv[0];
             t.x[2 * k + 1] = xv[1];
-            t.j[2 * k] = jv[0];
-            t.j[2 * k + 1] = jv[1];
         }
         return;
     }
@@ -145,15 +164,13 @@ __device__ __forceinline__ void csr_tile_load(const F *__restrict__ data, const 
 #pragma unroll
         for (int k = 0; k < CSR_EPL / 2; ++k) {
             f2 xv = f2{F(0), F(0)};
-            i2 jv = i2{0, 0};
+            t.set_pair(k, 0, 0);
             if (2 * lane + 128 * k < cnt) {
                 xv = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(dp + 128 * k));
-                jv = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(ip + 128 * k));
+                t.load_pair(k, ip + 128 * k);
             }
             t.x[2 * k] = xv[0];
             t.x[2 * k + 1] = xv[1];
-            t.j[2 * k] = jv[0];
-            t.j[2 * k + 1] = jv[1];
         }
         return;
     }
@@ -164,16 +181,15 @@ __device__ __forceinline__ void csr_tile_load(const F *__restrict__ data, const 
         int32_t j0 = 0, j1 = 0;
         if (e < cnt && c0 + e >= 0) {
             x0 = dp[128 * k];
-            j0 = ip[128 * k];
+            j0 = (int32_t)ip[128 * k];
         }
         if (e + 1 < cnt) {
             x1 = dp[128 * k + 1];
-            j1 = ip[128 * k + 1];
+            j1 = (int32_t)ip[128 * k + 1];
         }
         t.x[2 * k] = x0;
         t.x[2 * k + 1] = x1;
-        t.j[2 * k] = j0;
-        t.j[2 * k + 1] = j1;
+        t.set_pair(k, j0, j1);
     }
 }
 
@@ -187,8 +203,8 @@ __device__ __forceinline__ int64_t csr_uniform(int64_t v, int src) {
 // The tile walk shared by both kernels.  chunk range [cb, ce) of this wave; per chunk c lane <-> row c * 64 + lane
 // with its entry range [rlo, rhi); `Per` = per-row payload fetched with the pointers (rmatvec: v[row]).
 // body(tile, c0, cnt, rlo, rhi, first, payload) works on one tile; end_chunk(row, payload) closes a chunk.
-template <typename F, typename Per, typename LoadPer, typename Body, typename EndChunk>
-__device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, const int32_t *__restrict__ ind,
+template <typename F, typename Per, typename IDX, typename LoadPer, typename Body, typename EndChunk>
+__device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, const IDX *__restrict__ ind,
                                                 const int64_t *__restrict__ ptr, int64_t n, int64_t cb, int64_t ce,
                                                 int lane, LoadPer load_per, Body body, EndChunk end_chunk) {
     if (cb >= ce) return;
@@ -208,10 +224,10 @@ __device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, cons
     if (c + 1 < ce) load_ptrs(c + 1, rloN, rhiN, perN);
     int64_t p0 = csr_uniform(rlo, 0), p1 = csr_uniform(rhi, 63);
     int64_t c0 = p0 - ((p0 + off) & 1);
-    CsrTile<F> A, B;
+    CsrTile<F, IDX> A, B;
     csr_tile_load(data, ind, c0, (int)min((int64_t)CSR_CAP, p1 - c0), nnz, lane, A);
     // one step: request the tile after (c, c0) into `nxt`, work on `cur`; false when `cur` was the last one
-    auto step = [&](CsrTile<F> &cur, CsrTile<F> &nxt) -> bool {
+    auto step = [&](CsrTile<F, IDX> &cur, CsrTile<F, IDX> &nxt) -> bool {
         const bool same = c0 + CSR_CAP < p1;           // the chunk goes on in the next tile
         const bool more = same || c + 1 < ce;
         int64_t c0n = c0 + CSR_CAP, p0n = p0, p1n = p1;
@@ -251,9 +267,11 @@ __device__ __forceinline__ void csr_stream_walk(const F *__restrict__ data, cons
 // the HBM peak -- because this kernel lives on the LDS pipe (16 random gathers of v + the stores and segment reads of
 // the products per 1024 entries), not on its loads; an 8-lanes-per-row form without LDS staging took 0.87 ms
 // (profiles/r5_matvec.txt).
-template <typename F>
+// IDX: int32 column indices, or uint16 (a twin of the index array for blocks of at most 65536 columns: 10 instead
+// of 12 bytes per entry leave HBM)
+template <typename F, typename IDX = int32_t>
 __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
-    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ data, const IDX *__restrict__ ind, const int64_t *__restrict__ ptr,
     const F *__restrict__ v, int64_t n, int m, F *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     F *vl = reinterpret_cast<F *>(smem_raw);                       // [m]
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
             const int cnt = (int)min((int64_t)CSR_CAP, p1 - c0);
 #pragma unroll 4
             for (int e = lane; e < cnt; e += 64)
-                prod[e] = __builtin_nontemporal_load(data + c0 + e) * vl[__builtin_nontemporal_load(ind + c0 + e)];
+                prod[e] = __builtin_nontemporal_load(data + c0 + e) * vl[(int)__builtin_nontemporal_load(ind + c0 + e)];
             __builtin_amdgcn_wave_barrier();
             const int lo = (int)(max(rlo, c0) - c0);
             const int hi = (int)(min(rhi, c0 + CSR_CAP) - c0);
@@ -286,9 +304,9 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_matvec_stream_kernel(
     }
 }
 
-template <typename F>
+template <typename F, typename IDX = int32_t>
 __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
-    const F *__restrict__ data, const int32_t *__restrict__ ind, const int64_t *__restrict__ ptr,
+    const F *__restrict__ data, const IDX *__restrict__ ind, const int64_t *__restrict__ ptr,
     const F *__restrict__ v, int64_t n, int m, int64_t chunks_per_wave, F *__restrict__ ws,
     int square) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -302,9 +320,9 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
     const int64_t cb = ((int64_t)blockIdx.x * CSR_WAVES + wave) * chunks_per_wave;
     const int64_t ce = min(cb + chunks_per_wave, nchunk);
     typedef F f2 __attribute__((ext_vector_type(2)));
-    csr_stream_walk<F, F>(
+    csr_stream_walk<F, F, IDX>(
         data, ind, ptr, n, cb, ce, lane, [&](int64_t row) { return row < n ? v[row] : F(0); },
-        [&](const CsrTile<F> &t, int64_t c0, int cnt, int64_t rlo, int64_t rhi, int first, F vr) {
+        [&](const CsrTile<F, IDX> &t, int64_t c0, int cnt, int64_t rlo, int64_t rhi, int first, F vr) {
             // lane <-> row: v[row] over the row's part of the tile, then lane <-> entry
             const int lo = (int)(max(rlo, c0) - c0);
             const int hi = (int)(min(rhi, c0 + cnt) - c0);
@@ -317,11 +335,11 @@ __global__ __launch_bounds__(CSR_WAVES * 64) void csr_rmatvec_stream_kernel(
                 // (slots in front of the chunk's first entry and behind the tile's last were not written: skipped)
                 if (e >= first && e < cnt) {
                     const F x = t.x[2 * k];
-                    atomic_add(&bins[t.j[2 * k]], (lds_acc_t)((square ? x * x : x) * vv[0]));
+                    atomic_add(&bins[t.col(2 * k)], (lds_acc_t)((square ? x * x : x) * vv[0]));
                 }
                 if (e + 1 >= first && e + 1 < cnt) {
                     const F x = t.x[2 * k + 1];
-                    atomic_add(&bins[t.j[2 * k + 1]], (lds_acc_t)((square ? x * x : x) * vv[1]));
+                    atomic_add(&bins[t.col(2 * k + 1)], (lds_acc_t)((square ? x * x : x) * vv[1]));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -946,6 +964,26 @@ static inline bool csr_stream_aligned(const F *data, const int32_t *ind) {
 }
 
 template <typename F>
+static int run_csr_matvec_u16(const F *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                              const F *v, F *out, hipStream_t st) {
+    if (n == 0 || m == 0) return TM_OK;
+    TM_REQUIRE(m <= 65536 && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024,
+               "csr_matvec (16-bit columns): the coefficient vector must fit the LDS beside the staging buffers");
+    const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
+    auto kern = &csr_matvec_stream_kernel<F, uint16_t>;
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t nchunk = ceil_div(n, CSR_RPW);
+    const int64_t nblk = std::min<int64_t>(ceil_div(nchunk, CSR_WAVES), NUM_CU * 4);
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind16, ptr, v, n, (int)m, out);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    return TM_OK;
+}
+
+template <typename F>
 static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
                           int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
                           const int32_t *cols, int64_t n_cols, F *out, hipStream_t st) {
@@ -954,7 +992,7 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
     if (cols && n_cols == 0) return TM_OK;
     if (!rows && !cols && sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP) <= 64 * 1024) {
         const size_t lds = sizeof(F) * (size_t)(m + CSR_WAVES * CSR_CAP);
-        auto kern = &csr_matvec_stream_kernel<F>;
+        auto kern = &csr_matvec_stream_kernel<F, int32_t>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -987,6 +1025,36 @@ static int run_csr_matvec(const F *data, const int32_t *ind, const int64_t *ptr,
 }
 
 template <typename F>
+static int run_csr_rmatvec_u16(const F *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                               const F *v, F *out, hipStream_t st, int square) {
+    if (n == 0 || m == 0) return TM_OK;
+    const uintptr_t dpa = reinterpret_cast<uintptr_t>(data), ipa = reinterpret_cast<uintptr_t>(ind16);
+    TM_REQUIRE(m <= 65536 && sizeof(lds_acc_t) * (size_t)(m + 1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= SP_LDS_MAX,
+               "csr_rmatvec (16-bit columns): the accumulators must fit the LDS");
+    TM_REQUIRE(dpa % sizeof(F) == 0 && ipa % 2 == 0 && ((dpa / sizeof(F)) & 1) == ((ipa / 2) & 1),
+               "csr_rmatvec (16-bit columns): values and columns must start at entries of the same parity");
+    const size_t lds = sizeof(lds_acc_t) * (size_t)((m + 1) & ~(int64_t)1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
+    auto kern = &csr_rmatvec_stream_kernel<F, uint16_t>;
+    if (lds > 48 * 1024)
+        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t nchunk = ceil_div(n, CSR_RPW);
+    const int64_t nwave = std::min<int64_t>(nchunk, (int64_t)NUM_CU * 4 * CSR_WAVES);
+    const int64_t cpw = ceil_div(nchunk, nwave);
+    const int64_t nblk = ceil_div(ceil_div(nchunk, cpw), CSR_WAVES);
+    void *wsv = nullptr;
+    int rc = get_workspace(sizeof(F) * (size_t)(nblk * m) + 256, &wsv, st);
+    if (rc) return rc;
+    F *ws = reinterpret_cast<F *>(wsv);
+    prof_begin(st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CSR_WAVES * 64), lds, st, data, ind16, ptr, v, n, (int)m, cpw,
+                       ws, square);
+    prof_end(st);
+    TM_LAUNCH_CHECK();
+    return launch_reduce_partials<F>(ws, m, (int)nblk, 1, out, m, true, st);
+}
+
+template <typename F>
 static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr, int64_t n,
                            int64_t m, const F *v, const int32_t *rows, int64_t n_rows,
                            const int32_t *cols, int64_t n_cols, F *out, hipStream_t st,
@@ -998,7 +1066,7 @@ static int run_csr_rmatvec(const F *data, const int32_t *ind, const int64_t *ptr
         sizeof(lds_acc_t) * (size_t)(m + 1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP) <= SP_LDS_MAX &&
         csr_stream_aligned(data, ind)) {
         const size_t lds = sizeof(lds_acc_t) * (size_t)((m + 1) & ~(int64_t)1) + sizeof(F) * (size_t)(CSR_WAVES * CSR_CAP);
-        auto kern = &csr_rmatvec_stream_kernel<F>;
+        auto kern = &csr_rmatvec_stream_kernel<F, int32_t>;
         if (lds > 48 * 1024)
             TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1284,6 +1352,30 @@ extern "C" {
         return RUN<F>(data, ind, ptr, n, m, v, rows, n_rows, cols, n_cols, out,                 \
                       as_stream(stream));                                                       \
     }
+
+// out[i] += sum_k data[k] * v[ind16[k]] over row i (all rows, all columns), the column indices as uint16
+int tm_csr_matvec_u16_f32(const float *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                          const float *v, float *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_csr_matvec_u16<float>(data, ind16, ptr, n, m, v, out, as_stream(stream));
+}
+int tm_csr_matvec_u16_f64(const double *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                          const double *v, double *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_csr_matvec_u16<double>(data, ind16, ptr, n, m, v, out, as_stream(stream));
+}
+
+// out[j] += sum_i v[i] * X[i, j] (all rows, all columns) on the 16-bit column twin
+int tm_csr_rmatvec_u16_f32(const float *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                           const float *v, float *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_csr_rmatvec_u16<float>(data, ind16, ptr, n, m, v, out, as_stream(stream), 0);
+}
+int tm_csr_rmatvec_u16_f64(const double *data, const uint16_t *ind16, const int64_t *ptr, int64_t n, int64_t m,
+                           const double *v, double *out, void *stream) {
+    TM_REQUIRE(n >= 0 && m >= 0, "negative shape");
+    return run_csr_rmatvec_u16<double>(data, ind16, ptr, n, m, v, out, as_stream(stream), 0);
+}
 
 TM_CSR_MV_ENTRY(tm_csr_matvec_f32, float, run_csr_matvec)
 TM_CSR_MV_ENTRY(tm_csr_matvec_f64, double, run_csr_matvec)

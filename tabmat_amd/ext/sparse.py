@@ -41,6 +41,19 @@ def csr_dense_sandwich(A: CsrDev, B: DenseDev, d, rows, A_cols, B_cols):
     return out
 
 
+CSR_U16 = os.environ.get("TABMAT_AMD_CSR_U16", "1") == "1"   # 16-bit column twin for the unrestricted matvec kernels
+CSR_U16_MIN_NNZ = 1_000_000
+
+
+def _u16_ok(X: CsrDev, lds_bytes) -> bool:
+    """The 16-bit column twin pays (and the kernel's LDS budget holds): a block of at most 65536 columns with enough
+    entries that 2 of 12 bytes per entry matter; not a row-sliced view of odd parity (the pair loads need the values
+    and the columns to start at entries of the same parity)."""
+    isz = X.data.element_size()
+    return (CSR_U16 and 0 < X.m <= 65536 and int(X.data.numel()) >= CSR_U16_MIN_NNZ and lds_bytes
+            and (X.data.data_ptr() // isz) % 2 == 0)
+
+
 def csr_matvec(X: CsrDev, v, rows, cols, out=None):
     """ext/sparse.pyx:79-140 (csr_matvec_unrestricted with rows = cols = None)."""
     n_rows = X.n if rows is None else D.nlen(rows)
@@ -49,6 +62,10 @@ def csr_matvec(X: CsrDev, v, rows, cols, out=None):
     if n_rows == 0 or (cols is not None and D.nlen(cols) == 0):
         return out
     D.same_float("csr_matvec", X.data, v, out)
+    if rows is None and cols is None and _u16_ok(X, X.data.element_size() * (X.m + 4096) <= 64 * 1024):
+        call(f"tm_csr_matvec_u16_{D.fsuf(X.data)}", D.p(X.data), D.p(X.indices16()), D.p(X.indptr), X.n, X.m, D.p(v),
+             D.p(out), D.stream_ptr())
+        return out
     call(f"tm_csr_matvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
          D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out
@@ -63,6 +80,10 @@ def csc_rmatvec(X: CsrDev, v, rows, cols, out=None):
     if n_cols == 0 or (rows is not None and D.nlen(rows) == 0):
         return out
     D.same_float("csc_rmatvec", X.data, v, out)
+    if rows is None and cols is None and _u16_ok(X, 8 * (X.m + 1) + X.data.element_size() * 4096 <= 128 * 1024):
+        call(f"tm_csr_rmatvec_u16_{D.fsuf(X.data)}", D.p(X.data), D.p(X.indices16()), D.p(X.indptr), X.n, X.m, D.p(v),
+             D.p(out), D.stream_ptr())
+        return out
     call(f"tm_csr_rmatvec_{D.fsuf(X.data)}", *_csr_args(X), D.p(v), D.p(rows), D.nlen(rows),
          D.p(cols), D.nlen(cols), D.p(out), D.stream_ptr())
     return out

@@ -451,6 +451,41 @@ def test_categorical_matvec_quads_and_fresh_output(dtype, drop_first, missing):
         assert np.array_equal(mat.matvec(v, cols=np.array([], dtype=np.int64)), np.zeros(n, dtype=dtype))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,dens", [(60_000, 600, 0.05), (300_001, 37, 0.12), (40_000, 3000, 0.01)])
+def test_sparse_matvec_16_bit_column_twin(dtype, n, m, dens, monkeypatch):
+    """Blocks of a million entries and more stream a 16-bit twin of their column indices in the unrestricted matvec /
+    transpose_matvec (tm_csr_{matvec,rmatvec}_u16_*): the same numbers as the int32 kernels (matvec bit for bit),
+    accumulation into out, the restricted forms untouched."""
+    import tabmat_amd as tm
+    from tabmat_amd import _lib
+    from tabmat_amd.ext import sparse as xs
+
+    rng = np.random.default_rng(n + m)
+    S = sps.random(n, m, density=dens, format="csc", random_state=rng).astype(dtype)
+    assert S.nnz >= xs.CSR_U16_MIN_NNZ
+    v, w = rng.standard_normal(m).astype(dtype), rng.standard_normal(n).astype(dtype)
+    seen = []
+    real = _lib.call
+    monkeypatch.setattr("tabmat_amd.ext.sparse.call", lambda name, *a: (seen.append(name), real(name, *a))[1])
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(xs, "CSR_U16", flag)
+        mat = tm.SparseMatrix(S)
+        out = np.full(n, 0.5, dtype=dtype)
+        res[flag] = (mat.matvec(v), mat.transpose_matvec(w), mat.matvec(v, out=out).copy(),
+                     mat.matvec(v, cols=np.arange(0, m, 2)), mat.transpose_matvec(w, rows=np.arange(0, n, 3)))
+    assert any(s_.startswith("tm_csr_matvec_u16_") for s_ in seen) and any(s_.startswith("tm_csr_rmatvec_u16_") for s_ in seen)
+    tol = F64_TOL if dtype == np.float64 else 1e-4
+    S64 = S.astype(np.float64)
+    ref_mv, ref_t = S64 @ v.astype(np.float64), S64.T @ w.astype(np.float64)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][2], res[False][2])
+    assert np.abs(res[True][0] - ref_mv).max() / max(1.0, np.abs(ref_mv).max()) < tol
+    assert np.abs(res[True][1] - ref_t).max() / max(1.0, np.abs(ref_t).max()) < tol
+    assert np.array_equal(res[True][3], res[False][3])
+    assert np.abs(res[True][4] - res[False][4]).max() / max(1.0, np.abs(ref_t).max()) < tol
+
+
 # ------------------------------------------------------------------ K4 categorical family
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("ncat", [3, 1000, 10_000, 58_059])
