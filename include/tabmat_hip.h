@@ -256,6 +256,13 @@ int tm_sparse_sandwich_pairs_f32(const int32_t *cm_rec, const int32_t *cptr, int
 int tm_sparse_sandwich_pairs_f64(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                  const double *d, double *out, void *stream);
 
+/* The same on PACKED records: {value, row << 7 | column inside the 128-column chunk} -- 12 bytes per entry for f64
+ * (three words), 8 for f32 -- for blocks of fewer than 2^25 rows; the array must be readable 4 bytes beyond its end. */
+int tm_sparse_sandwich_pairs_pk_f32(const int32_t *cm_rec_pk, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                    const float *d, float *out, void *stream);
+int tm_sparse_sandwich_pairs_pk_f64(const int32_t *cm_rec_pk, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                    const double *d, double *out, void *stream);
+
 /* The same product on a static BLOCK LIST (csrc/sparse_blocks.hip): every (row, tile) of the
  * chunk-major twin is cut, once per matrix, into blocks of at most 8 x 8 entries -- block (a, b)
  * pairs entries 8a .. 8a+7 of the row's list in chunk I with entries 8b .. 8b+7 of its list in chunk

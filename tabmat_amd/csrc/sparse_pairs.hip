@@ -53,10 +53,28 @@ __global__ void pairs_assemble_kernel(const F *__restrict__ tiles, int n_out, F 
     out[(int64_t)i * n_out + j] = tiles[(int64_t)part * KP_TS * KP_TS + (hi % KP_TS) * KP_TS + (lo % KP_TS)];
 }
 
-template <typename F>
+// PK: packed records -- {value, row << 7 | column inside the chunk}: 12 bytes for f64, 8 for f32 (blocks of fewer than
+// 2^25 rows) -- instead of the 16-byte ones.
+template <typename F, bool PK>
 __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
-    const kp_rec_t *__restrict__ rec, const int32_t *__restrict__ cptr, int64_t n, const F *__restrict__ d,
+    const void *__restrict__ rec_v, const int32_t *__restrict__ cptr, int64_t n, const F *__restrict__ d,
     int n_slots, F *__restrict__ ws) {
+    const kp_rec_t *__restrict__ rec = reinterpret_cast<const kp_rec_t *>(rec_v);
+    constexpr int RB = PK ? (int)sizeof(F) + 4 : 16;                 // bytes per record
+    // a record as four words {value lo, value hi (f32: unused), column, row}, whatever the stored form
+    auto fetch = [&](int p) -> kp_rec_t {
+        if constexpr (!PK) {
+            return rec[p];
+        } else if constexpr (sizeof(F) == 8) {
+            typedef int32_t i3 __attribute__((ext_vector_type(3), aligned(4)));
+            const i3 t = *reinterpret_cast<const i3 *>(reinterpret_cast<const char *>(rec_v) + (int64_t)p * RB);
+            return kp_rec_t{t[0], t[1], (int)((unsigned)t[2] & 127u), (int)((unsigned)t[2] >> 7)};
+        } else {
+            typedef int32_t i2 __attribute__((ext_vector_type(2)));
+            const i2 t = *reinterpret_cast<const i2 *>(reinterpret_cast<const char *>(rec_v) + (int64_t)p * RB);
+            return kp_rec_t{t[0], (int)((unsigned)t[1] & 127u), (int)((unsigned)t[1] >> 7), 0};
+        }
+    };
     // rec[p] = {value (f64: low word, high word; f32: bits), column, row} of chunk-major entry p (f32: {value,
     // column, row, 0})
     constexpr int TS = KP_TS;
@@ -70,7 +88,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
     while (I * (I + 1) / 2 > part) --I;
     const int J = part - I * (I + 1) / 2;
     const bool diag = I == J;
-    const int i0 = I * TS, j0 = J * TS;
+    const int i0 = PK ? 0 : I * TS, j0 = PK ? 0 : J * TS;     // (packed records carry chunk-relative columns)
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
@@ -97,7 +115,10 @@ __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
     auto load_ent = [&](int p, int pend) {
         Ent e;
         e.on = p < pend;
-        const kp_rec_t r = __builtin_nontemporal_load(rec + (e.on ? p : max(pend - 1, 0)));
+        const int pp = e.on ? p : max(pend - 1, 0);
+        kp_rec_t r;
+        if constexpr (PK) r = fetch(pp);
+        else r = __builtin_nontemporal_load(rec + pp);
         e.col = rec_col(r);
         e.val = rec_val(r);
         e.row = rec_row(r);
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
         // (clamped to the list's last entry: unconditional loads, no wait inside a lane branch)
         const int last = l.lo + max(l.k - 1, 0);
 #pragma unroll
-        for (int t = 0; t < T0; ++t) q.r[t] = rec[min(l.lo + t, last)];
+        for (int t = 0; t < T0; ++t) q.r[t] = fetch(min(l.lo + t, last));
         return q;
     };
     auto run = [&](const Lst &l, const Pre &q) {
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
         int t = T0;
         while (__builtin_amdgcn_ballot_w64(t < l.k) != 0) {
             if (t < l.k) {
-                const kp_rec_t r = rec[l.lo + t];
+                const kp_rec_t r = fetch(l.lo + t);
                 atomic_add(&tile[l.ca + rec_col(r)], (lds_acc_t)(l.w * rec_val(r)));
             }
             ++t;
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(KP_WAVES * 64) void sparse_sandwich_pairs_kernel(
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) dst[b] = (F)tile[b];
 }
 
-template <typename F>
+template <typename F, bool PK = false>
 static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                      const F *d, F *out, hipStream_t st) {
     if (m == 0) return TM_OK;
@@ -209,13 +230,13 @@ static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, in
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = n_slots > 1 ? reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes) : tmp;
-    auto kern = &sparse_sandwich_pairs_kernel<F>;
+    auto kern = &sparse_sandwich_pairs_kernel<F, PK>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int waves = (int)std::min<int64_t>(KP_WAVES, std::max<int64_t>(1, tune("k2p_waves", KP_WAVES)));
     prof_begin(st);
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_parts * n_slots)), dim3(waves * 64), lds, st,
-                       reinterpret_cast<const kp_rec_t *>(rec), cptr, n, d, n_slots, ws);
+                       reinterpret_cast<const void *>(rec), cptr, n, d, n_slots, ws);
     prof_end(st);
     TM_LAUNCH_CHECK();
     if (n_slots > 1) {
@@ -239,6 +260,19 @@ int tm_sparse_sandwich_pairs_f32(const int32_t *cm_rec, const int32_t *cptr, int
 int tm_sparse_sandwich_pairs_f64(const int32_t *cm_rec, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
                                  const double *d, double *out, void *stream) {
     return tmh::run_sparse_sandwich_pairs<double>(cm_rec, cptr, n, m, nnz, d, out, tmh::as_stream(stream));
+}
+
+// packed records: {value, row << 7 | column inside the chunk} -- 12 bytes (f64) / 8 bytes (f32) per entry, n < 2^25;
+// the record array must be readable 4 bytes beyond its last record
+int tm_sparse_sandwich_pairs_pk_f32(const int32_t *cm_rec_pk, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                    const float *d, float *out, void *stream) {
+    if (n >= (1ll << 25)) { tmh::set_error("packed pair records need fewer than 2^25 rows"); return TM_EUNSUPPORTED; }
+    return tmh::run_sparse_sandwich_pairs<float, true>(cm_rec_pk, cptr, n, m, nnz, d, out, tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_pairs_pk_f64(const int32_t *cm_rec_pk, const int32_t *cptr, int64_t n, int64_t m, int64_t nnz,
+                                    const double *d, double *out, void *stream) {
+    if (n >= (1ll << 25)) { tmh::set_error("packed pair records need fewer than 2^25 rows"); return TM_EUNSUPPORTED; }
+    return tmh::run_sparse_sandwich_pairs<double, true>(cm_rec_pk, cptr, n, m, nnz, d, out, tmh::as_stream(stream));
 }
 
 }  // extern "C"

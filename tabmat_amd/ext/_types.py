@@ -151,6 +151,43 @@ class CsrDev:
             self._cm_rec = cr
         return cr
 
+    def chunk_records_packed(self):
+        """int32 [nnz * W + 4] (W = 3 for f64, 2 for f32): packed records {value, row << 7 | column inside the chunk}
+        for tm_sparse_sandwich_pairs_pk_* (n < 2^25), or None."""
+        cr = getattr(self, "_cm_rec_pk", False)
+        if cr is False:
+            cr = None
+            if self.n < 2**25:
+                from .._lib import lib
+
+                ch = int(lib().tm_sparse_chunk_cols())
+                cm_data, cm_ind, cptr = self.chunk_major()
+                dev = cptr.device
+                nnz = int(cm_data.numel())
+                f64 = cm_data.dtype == torch.float64
+                W = 3 if f64 else 2
+                buf = torch.zeros(nnz * W + 4, dtype=torch.int32, device=dev)
+                rec = buf[:nnz * W].view(nnz, W)
+                if f64:
+                    words = cm_data.view(torch.int32).view(nnz, 2)
+                    rec[:, 0] = words[:, 0]
+                    rec[:, 1] = words[:, 1]
+                else:
+                    rec[:, 0] = cm_data.view(torch.int32)
+                ar = torch.arange(self.n, device=dev, dtype=torch.int64)
+                pos = 0
+                for c in range(int(cptr.shape[0])):
+                    k = int(cptr[c, -1].item()) - int(cptr[c, 0].item())
+                    if k:
+                        cnt = (cptr[c, 1:] - cptr[c, :-1]).to(torch.int64)
+                        rows = torch.repeat_interleave(ar, cnt, output_size=k)
+                        word = (rows << 7) | torch.remainder(cm_ind[pos:pos + k].to(torch.int64), ch)
+                        rec[pos:pos + k, W - 1] = torch.where(word >= 2**31, word - 2**32, word).to(torch.int32)
+                    pos += k
+                cr = buf
+            self._cm_rec_pk = cr
+        return cr
+
     def pair_blocks(self, n_wg: int = 0, nw: int = 16, cyclic=None):
         """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of

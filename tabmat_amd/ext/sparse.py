@@ -306,6 +306,11 @@ def sparse_sandwich_pairs(A: CsrDev, d):
     out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_pairs", A.data, d)
     _, _, cptr = A.chunk_major()
+    if K2_PAIRS_PACKED and A.n < 2**25:
+        rec = A.chunk_records_packed()
+        call(f"tm_sparse_sandwich_pairs_pk_{D.fsuf(A.data)}", D.p(rec), D.p(cptr), A.n, A.m, int(A.data.numel()), D.p(d),
+             D.p(out), D.stream_ptr())
+        return out
     rec = A.chunk_records()
     call(f"tm_sparse_sandwich_pairs_{D.fsuf(A.data)}", D.p(rec), D.p(cptr), A.n, A.m, int(rec.shape[0]), D.p(d),
          D.p(out), D.stream_ptr())
@@ -359,6 +364,7 @@ def direct_sandwich_pays(A: CsrDev) -> bool:
 
 # the pair-stream form of the unrestricted sparse self sandwich (csrc/sparse_pairs.hip): "auto" / "0" / "1"
 K2_PAIRS = "auto"
+K2_PAIRS_PACKED = os.environ.get("TABMAT_AMD_K2_PAIRS_PACKED", "1") == "1"    # packed 12- / 8-byte records (n < 2^25)
 K2_PAIRS_MAX_M = 16384      # tm_sparse_sandwich_pairs_*: at most 128 column chunks
 
 
@@ -383,7 +389,9 @@ def pairs_sandwich_pays(A: CsrDev) -> bool:
     pairs = n * per_row * (per_row + 2.0) / 2.0
     # (beyond 768 tiles every tile is one workgroup writing its tile once: ~0.1 us each, measured on the reference's
     # 'sparse_wide' design 40k x 10k @ 1 %: 1.63 ms, and on 40k x 16k @ 0.5 %: 2.71 ms)
-    t_pairs = (nnz * (nch + 1) / 2.0 * 2.3e-12 * min(6.0, max(1.0, (1.6 / k) ** 0.8)) + pairs * 2.7e-12
+    # (packed 12-byte records, n < 2^25: both per-entry terms x 0.75 -- 2.83 -> 2.12, 7.23 -> 5.54, 2.99 -> 2.18 ms)
+    pk = 0.75 if (K2_PAIRS_PACKED and n < 2**25) else 1.0
+    t_pairs = (nnz * (nch + 1) / 2.0 * 2.3e-12 * pk * min(6.0, max(1.0, (1.6 / k) ** 0.8)) + pairs * 2.7e-12 * pk
                + min(parts, 768) * 0.8e-6 + max(0.0, parts - 768) * 0.1e-6)
     t_direct = pairs / 21e9
     if nch > 32:

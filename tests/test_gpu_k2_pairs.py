@@ -24,8 +24,19 @@ def _pairs(S, d, dtype=np.float64):
     from tabmat_amd.ext import sparse as xs
 
     sm = tm.SparseMatrix(S.astype(dtype))
-    out = xs.sparse_sandwich_pairs(sm._dev(), torch.from_numpy(d.astype(dtype)).cuda())
-    return out.cpu().numpy()
+    dd = torch.from_numpy(d.astype(dtype)).cuda()
+    # both record forms: packed {value, row << 7 | column in chunk} (12 / 8 bytes, the default) and 16-byte records
+    outs = {}
+    keep = xs.K2_PAIRS_PACKED
+    try:
+        for pk in (False, True):
+            xs.K2_PAIRS_PACKED = pk
+            outs[pk] = xs.sparse_sandwich_pairs(sm._dev(), dd).cpu().numpy()
+    finally:
+        xs.K2_PAIRS_PACKED = keep
+    scale = max(1.0, float(np.abs(outs[False]).max())) if np.isfinite(outs[False]).all() else 1.0
+    assert np.allclose(outs[True], outs[False], rtol=0, atol=(1e-12 if dtype == np.float64 else 1e-5) * scale, equal_nan=True)
+    return outs[True]
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
