@@ -18,13 +18,16 @@ for m, dens in cases:
     sm = synth.sparse_block(n, m, dens, torch.float64, 1003)
     d = torch.rand(n, dtype=torch.float64, device="cuda")
     A = sm._dev()
+    auto = xs.pairs_sandwich_pays(A)
+    xs.K2_PAIRS = "0"                  # what the dispatch takes without the pair-stream kernel
     ref = sm._sandwich_dev(d, None, None)
     t_cur = t(lambda: sm._sandwich_dev(d, None, None))
+    xs.K2_PAIRS = "auto"
     got = xs.sparse_sandwich_pairs(A, d)
     dg = torch.sqrt(torch.diagonal(ref).abs()); den = torch.outer(dg, dg).clamp_min(1e-300)
     err = float(((got - ref).abs() / den).max())
     t_new = t(lambda: xs.sparse_sandwich_pairs(A, d))
     nnz = A.data.numel()
-    print(f"m={m:5d} dens={dens:.5f} nnz/row={nnz / n:5.1f}  current {t_cur:7.3f} ms   pairs {t_new:7.3f} ms   nat.err {err:.1e}", flush=True)
+    print(f"m={m:5d} dens={dens:.5f} nnz/row={nnz / n:5.1f}  without {t_cur:7.3f} ms   pairs {t_new:7.3f} ms   model picks pairs: {auto}   nat.err {err:.1e}", flush=True)
     del sm, A, ref, got
     torch.cuda.empty_cache()

@@ -380,7 +380,7 @@ def pairs_sandwich_pays(A: CsrDev) -> bool:
     if K2_PAIRS != "auto":
         return K2_PAIRS == "1" and A.m <= K2_PAIRS_MAX_M and 0 < int(A.data.numel()) < 2**31
     nnz, n, m = int(A.data.numel()), A.n, A.m
-    if n == 0 or nnz == 0 or m <= 1024 or m > K2_PAIRS_MAX_M or nnz >= 2**31:
+    if n == 0 or nnz == 0 or m <= 512 or m > K2_PAIRS_MAX_M or nnz >= 2**31:
         return False
     nch = (m + 127) // 128
     parts = nch * (nch + 1) / 2
@@ -397,7 +397,8 @@ def pairs_sandwich_pays(A: CsrDev) -> bool:
     if nch > 32:
         t_tiled = n * parts * 0.3e-9      # only the generic tiled kernel is left (direct_sandwich_pays)
     else:
-        t_tiled = pairs * 1.15e-12 if k > 4.5 else n * parts * 20e-12
+        # (chunked kernel at 1024 columns, 2M rows: 1.24 ms @ 1.25 %, 1.82 ms @ 2.5 % -- pair stream 0.56 / 1.59)
+        t_tiled = pairs * 1.15e-12 if k > 4.5 else n * parts * 17e-12 + pairs * 0.8e-12
     # (a 10 % margin: 4096 columns @ 0.2 % over 2M rows is 2.9-3.0 ms here against 3.57 ms direct, modelled 3.34 / 3.98)
     return t_pairs < 0.9 * min(t_direct, t_tiled)
 

@@ -517,6 +517,8 @@ def test_pairs_cost_model_picks_the_regimes_it_was_measured_in():
     assert xs.pairs_sandwich_pays(Fake(n, 4096, 0.00625))
     assert xs.pairs_sandwich_pays(Fake(n, 4096, 0.002))             # 2.9-3.0 ms against 3.57 ms direct
     assert not xs.pairs_sandwich_pays(Fake(n, 512, 0.05))
+    assert xs.pairs_sandwich_pays(Fake(n, 1024, 0.0125))            # 0.56 ms against 1.24 ms chunked
+    assert not xs.pairs_sandwich_pays(Fake(n, 1024, 0.05))          # 6.3 ms against 2.8 ms on the block list
     assert not xs.pairs_sandwich_pays(Fake(n, 2048, 0.05))
     assert not xs.pairs_sandwich_pays(Fake(n, 8192, 0.0005))
     # the reference's own 'sparse_wide' design (benchmark/generate_matrices.py): pair stream 1.63 ms, direct 9.7 ms;
