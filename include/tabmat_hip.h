@@ -839,6 +839,19 @@ int tm_sparse_sandwich_chunked_rows_f32(const float *cm_data, const int32_t *cm_
 int tm_sparse_sandwich_chunked_rows_f64(const double *cm_data, const int32_t *cm_indices,
                                         const int32_t *row_ranges, int64_t n_sel, int64_t m,
                                         int64_t nnz, const double *d_sel, double *out, void *stream);
+
+/* Both forms with the columns as ONE BYTE per chunk-major entry (cm_col8[p] = cm_indices[p] % 128, the column inside
+ * the entry's chunk): the entry gathers of the kernel move a quarter of the index bytes. */
+int tm_sparse_sandwich_chunked_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr, int64_t n,
+                                      int64_t m, int64_t nnz, const float *d, float *out, void *stream);
+int tm_sparse_sandwich_chunked_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr, int64_t n,
+                                      int64_t m, int64_t nnz, const double *d, double *out, void *stream);
+int tm_sparse_sandwich_chunked_rows_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *row_ranges,
+                                           int64_t n_sel, int64_t m, int64_t nnz, const float *d_sel, float *out,
+                                           void *stream);
+int tm_sparse_sandwich_chunked_rows_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *row_ranges,
+                                           int64_t n_sel, int64_t m, int64_t nnz, const double *d_sel, double *out,
+                                           void *stream);
 /* The same product for WIDE, VERY SPARSE blocks (fewer than one nonzero per row and 128-column
  * chunk): plain CSR in, one L2 atomic per pair into a double accumulator, cost proportional to the
  * number of pairs instead of rows x tiles (csrc/sparse_direct.hip).  All rows (a row restriction is

@@ -623,7 +623,9 @@ __device__ __forceinline__ float k2_bcast(float v, float x4) {
 // row and 128-column chunk (5 % density); a block with 1-2 nonzeros per row and chunk (wide and
 // sparse: 2048 columns at 1.25 %) would fill 3 % of the lanes of its 8 ds_adds per 8 rows -- with
 // S = 2 the same pairs take 2 ds_adds per 32 rows.
-template <typename F, int TS, int S, int NW = K2_WAVES>
+// U8: `ind` points at BYTES, the column of an entry inside its 128-column chunk (as in sparse_blocks.hip: the entry
+// gathers are charged for the bytes they move).
+template <typename F, int TS, int S, int NW = K2_WAVES, bool U8 = false>
 __global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind,
     const int32_t *__restrict__ cptr, int nch, const F *__restrict__ d, int64_t n,
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
     while ((I + 1) * (I + 2) / 2 <= part) ++I;
     while (I * (I + 1) / 2 > part) --I;
     const int J = part - I * (I + 1) / 2;
-    const int i0 = I * TS, j0 = J * TS;
+    const int i0 = U8 ? 0 : I * TS, j0 = U8 ? 0 : J * TS;       // (byte columns are chunk-relative)
     for (int b = threadIdx.x; b < TS * TS; b += blockDim.x) tile[b] = 0.0;
     __syncthreads();
 
@@ -703,6 +705,8 @@ __global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
     const unsigned spanB1 = (unsigned)max(__builtin_amdgcn_readfirstlane(cpB[last]) - baseB - 1, 0);
     const F *dataA = data + min((int64_t)baseA, nnz1), *dataB = data + min((int64_t)baseB, nnz1);
     const int32_t *indA = ind + min((int64_t)baseA, nnz1), *indB = ind + min((int64_t)baseB, nnz1);
+    const unsigned char *ind8A = reinterpret_cast<const unsigned char *>(ind) + min((int64_t)baseA, nnz1);
+    const unsigned char *ind8B = reinterpret_cast<const unsigned char *>(ind) + min((int64_t)baseB, nnz1);
     // The whole pipeline is instantiated twice: DIAG (I == J: one list per row, loaded once, pairs
     // b <= a) and off-diagonal (two lists); the choice is workgroup-uniform and made once, outside
     // the load pipeline (a branch inside it would bring the conservative s_waitcnt back).
@@ -745,16 +749,16 @@ __global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
             return *reinterpret_cast<const F *>(reinterpret_cast<const char *>(base) +
                                                 (i * (unsigned)sizeof(F)));
         };
-        e.ca = ldi(indA, iA);
+        e.ca = U8 ? (int)ind8A[iA] : ldi(indA, iA);
         e.va = ldf(dataA, iA);
-        e.ca2 = ldi(indA, iA2);
+        e.ca2 = U8 ? (int)ind8A[iA2] : ldi(indA, iA2);
         e.va2 = ldf(dataA, iA2);
         if constexpr (!DIAG) {
             const unsigned iB = min(rB + min((unsigned)lt, lB), spanB1);
             const unsigned iB2 = min(rB + min((unsigned)lt + (unsigned)S, lB), spanB1);
-            e.cb = ldi(indB, iB);
+            e.cb = U8 ? (int)ind8B[iB] : ldi(indB, iB);
             e.vb = ldf(dataB, iB);
-            e.cb2 = ldi(indB, iB2);
+            e.cb2 = U8 ? (int)ind8B[iB2] : ldi(indB, iB2);
             e.vb2 = ldf(dataB, iB2);
         } else {
             // the B side of a diagonal tile is read from the A fields in process() (no copies
@@ -878,14 +882,14 @@ __global__ __launch_bounds__(NW * 64) void sparse_sandwich_chunked_kernel(
                     int ca = 0;
                     F va = F(0);
                     if (a < nAr) {
-                        ca = ind[pAr + a] - i0;
+                        ca = (U8 ? (int)reinterpret_cast<const unsigned char *>(ind)[pAr + a] : ind[pAr + a]) - i0;
                         va = data[pAr + a] * dr;
                     }
                     // (pairs with a < 2 S and b < 2 S were formed above)
                     for (int b0 = (a0 + 8 <= 2 * S ? (2 * S) / 8 * 8 : 0); b0 < nBr; b0 += 8) {
                         const int b = b0 + pb;
                         if (a < nAr && b < nBr && (a >= 2 * S || b >= 2 * S)) {
-                            const int cb = ind[pBr + b] - j0;
+                            const int cb = (U8 ? (int)reinterpret_cast<const unsigned char *>(ind)[pBr + b] : ind[pBr + b]) - j0;
                             const F vb = data[pBr + b];
                             if (!DIAG || cb <= ca)
                                 atomic_add(&tile[ca * TS + (cb ^ ((ca & 15) << 3))], (lds_acc_t)(va * vb));
@@ -1262,7 +1266,7 @@ static int run_sparse_sandwich(const F *data, const int32_t *ind, const int64_t 
     return TM_OK;
 }
 
-template <typename F>
+template <typename F, bool U8 = false>
 static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const int32_t *cptr,
                                        int64_t n, int64_t m, int64_t nnz, const F *d, F *out,
                                        hipStream_t st, int pairs = 0) {
@@ -1310,11 +1314,11 @@ static int run_sparse_sandwich_chunked(const F *data, const int32_t *ind, const 
     // waves per workgroup: 16 when the kernel has the CU to itself; 8 / 12 leave registers for a
     // co-resident MFMA kernel on the same CU (tm_tune_set("k2_waves", ...), S = 8 only)
     const int nw = slots == 8 ? (int)tune("k2_waves", K2_WAVES) : K2_WAVES;
-    auto kern = slots == 8   ? (nw == 8    ? &sparse_sandwich_chunked_kernel<F, TS, 8, 8>
-                                : nw == 12 ? &sparse_sandwich_chunked_kernel<F, TS, 8, 12>
-                                           : &sparse_sandwich_chunked_kernel<F, TS, 8>)
-                : slots == 4 ? &sparse_sandwich_chunked_kernel<F, TS, 4>
-                             : &sparse_sandwich_chunked_kernel<F, TS, 2>;
+    auto kern = slots == 8   ? (nw == 8    ? &sparse_sandwich_chunked_kernel<F, TS, 8, 8, U8>
+                                : nw == 12 ? &sparse_sandwich_chunked_kernel<F, TS, 8, 12, U8>
+                                           : &sparse_sandwich_chunked_kernel<F, TS, 8, K2_WAVES, U8>)
+                : slots == 4 ? &sparse_sandwich_chunked_kernel<F, TS, 4, K2_WAVES, U8>
+                             : &sparse_sandwich_chunked_kernel<F, TS, 2, K2_WAVES, U8>;
     const int threads = (slots == 8 && (nw == 8 || nw == 12) ? nw : K2_WAVES) * 64;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2332,6 +2336,30 @@ int tm_sparse_sandwich_chunked_f64(const double *csr_data, const int32_t *csr_in
                                    const double *d, double *out, void *stream) {
     return tmh::run_sparse_sandwich_chunked<double>(csr_data, csr_indices, cptr, n, m, nnz, d, out,
                                                     tmh::as_stream(stream));
+}
+
+// the same two forms with the columns as one byte per chunk-major entry (column inside its 128-column chunk)
+int tm_sparse_sandwich_chunked_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr, int64_t n,
+                                      int64_t m, int64_t nnz, const float *d, float *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<float, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr, n, m,
+                                                         nnz, d, out, tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_chunked_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr, int64_t n,
+                                      int64_t m, int64_t nnz, const double *d, double *out, void *stream) {
+    return tmh::run_sparse_sandwich_chunked<double, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr, n, m,
+                                                          nnz, d, out, tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_chunked_rows_u8_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *row_ranges,
+                                           int64_t n_sel, int64_t m, int64_t nnz, const float *d_sel, float *out,
+                                           void *stream) {
+    return tmh::run_sparse_sandwich_chunked<float, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), row_ranges,
+                                                         n_sel, m, nnz, d_sel, out, tmh::as_stream(stream), 1);
+}
+int tm_sparse_sandwich_chunked_rows_u8_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *row_ranges,
+                                           int64_t n_sel, int64_t m, int64_t nnz, const double *d_sel, double *out,
+                                           void *stream) {
+    return tmh::run_sparse_sandwich_chunked<double, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), row_ranges,
+                                                          n_sel, m, nnz, d_sel, out, tmh::as_stream(stream), 1);
 }
 
 int tm_sparse_sandwich_chunked_rows_f32(const float *cm_data, const int32_t *cm_indices,

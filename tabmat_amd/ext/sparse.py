@@ -225,7 +225,8 @@ def sparse_sandwich_rows(A: CsrDev, d, rows):
         return out
     D.same_float("sparse_sandwich_rows", A.data, d)
     cm_data, cm_ind, ranges, r32, d_sel = _row_table(A, rows, d, True)
-    call(f"tm_sparse_sandwich_chunked_rows_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(ranges),
+    call(f"tm_sparse_sandwich_chunked_rows_{'u8_' if K2B_U8 else ''}{D.fsuf(A.data)}", D.p(cm_data),
+         D.p(A.chunk_col8() if K2B_U8 else cm_ind), D.p(ranges),
          int(r32.numel()), A.m, int(cm_data.numel()), D.p(d_sel), D.p(out), D.stream_ptr())
     return out
 
@@ -251,7 +252,8 @@ def sparse_sandwich_chunked(A: CsrDev, d):
     out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_chunked", A.data, d)
     cm_data, cm_ind, cptr = A.chunk_major()
-    call(f"tm_sparse_sandwich_chunked_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr),
+    call(f"tm_sparse_sandwich_chunked_{'u8_' if K2B_U8 else ''}{D.fsuf(A.data)}", D.p(cm_data),
+         D.p(A.chunk_col8() if K2B_U8 else cm_ind), D.p(cptr),
          A.n, A.m, int(cm_data.numel()), D.p(d), D.p(out), D.stream_ptr())
     return out
 
