@@ -35,6 +35,17 @@ def test_blocks_sandwich_vs_oracle(n, m, dens, dtype):
     assert np.array_equal(got, got.T)
     other = D.to_host(xs.sparse_sandwich_chunked(A, D.to_dev(d)))
     assert rel_err(got, other) < (1e-12 if dtype == np.float64 else 1e-4)
+    # byte columns (the default, tm_sparse_sandwich_{blocks,chunked}_u8_*) against the int32 columns: the same pairs,
+    # only the order of the LDS atomics differs
+    assert xs.K2B_U8
+    try:
+        xs.K2B_U8 = False
+        got32 = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
+        other32 = D.to_host(xs.sparse_sandwich_chunked(A, D.to_dev(d)))
+    finally:
+        xs.K2B_U8 = True
+    assert rel_err(got, got32) < (1e-12 if dtype == np.float64 else 1e-4)
+    assert rel_err(other, other32) < (1e-12 if dtype == np.float64 else 1e-4)
 
 
 @pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"), reason="the fixed-order sparse self sandwich is selected instead")
