@@ -99,6 +99,26 @@ def nlen(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else int(t.numel())
 
 
+def masked_d(d: torch.Tensor, rows: Optional[torch.Tensor], as_set: bool = False) -> torch.Tensor:
+    """A row restriction as a masked weight vector for the kernels that make one full pass: rows outside
+    `rows` get d = 0.  What a REPEATED row id means follows the reference product by product, and every
+    masked-d path goes through here so that the masked pass and the row-list kernel of one product agree:
+      as_set=False  a row that occurs k times counts k times (index_add_): the reference's `for k in rows` loops
+                    (dense_helpers-tmpl.cpp:224, sparse_helpers-tmpl.cpp:67-131, ext/categorical.pyx,
+                    ext/split.pyx) and its X[rows] indexing (categorical_matrix.py:825-838);
+      as_set=True   it counts once (assignment): the sparse SELF sandwich, whose reference turns `rows` into a
+                    uint8 mask (ext/sparse.pyx:46-48)."""
+    if rows is None:
+        return d
+    dm = torch.zeros_like(d)
+    r64 = rows.to(torch.int64)
+    if as_set:
+        dm[r64] = d[r64]
+    else:
+        dm.index_add_(0, r64, d[r64])
+    return dm
+
+
 def to_host(t: torch.Tensor) -> np.ndarray:
     return t.detach().cpu().numpy()
 

@@ -426,11 +426,7 @@ class CategoricalMatrix(MatrixBase):
                 # the one-hot slab
                 from .ext import sparse as xs
 
-                if rows is not None:
-                    dm = torch.zeros_like(d)
-                    r64 = rows.to(torch.int64)
-                    dm[r64] = d[r64]
-                    d = dm
+                d = D.masked_d(d, rows)
                 cats = [(self._dev(), self.shape[1], self.drop_first)]
                 if (other.dtype == self.dtype and d.dtype == other._dev_c().buf.dtype
                         and xsplit.multi_cat_dense_wide_ok(cats, other._dev_c())):
@@ -458,11 +454,7 @@ class CategoricalMatrix(MatrixBase):
                     and d.dtype == S.data.dtype and S.data.numel() > 0):
                 # the [levels][columns] tile would take several passes over the rows: level-sorted
                 # kernel instead (masked d for a row restriction, sub-selection of the result)
-                if rows is not None:
-                    dm = torch.zeros_like(d)
-                    r64 = rows.to(torch.int64)
-                    dm[r64] = d[r64]
-                    d = dm
+                d = D.masked_d(d, rows)
                 res = xsplit.cat_sparse_sandwich_sorted(self._det_plan(), self.shape[1], d, S)
                 return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_sparse(self._dev(), self.shape[1], d, S, rows,
@@ -473,11 +465,7 @@ class CategoricalMatrix(MatrixBase):
                     and xsplit.cat_cat_sorted_pays(self.shape[0], self.shape[1], other.shape[1])):
                 # a table of several LDS tiles: rows grouped by this block's level (static twin of the pair), every
                 # tile reads only its own rows; a row restriction is a masked d
-                if rows is not None:
-                    dm = torch.zeros_like(d)
-                    r64 = rows.to(torch.int64)
-                    dm.index_add_(0, r64, d[r64])          # (a repeated row counts once per occurrence)
-                    d = dm
+                d = D.masked_d(d, rows)
                 res = xsplit.sandwich_cat_cat_sorted(self._sorted_pair(other), self.shape[1], other.shape[1], d)
                 return self._restrict(res, L_cols, R_cols)
             res = xsplit.sandwich_cat_cat(self._dev(), other._dev(), self.shape[1],

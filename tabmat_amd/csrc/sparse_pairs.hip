@@ -213,7 +213,10 @@ static int run_sparse_sandwich_pairs(const int32_t *rec, const int32_t *cptr, in
         return TM_OK;
     }
     constexpr int TS = KP_TS;
-    TM_REQUIRE(nnz < (1ll << 31) && n < (1ll << 31) - 1, "sparse block too large for 32-bit entry positions");
+    // entry positions are 32-bit ints and the stream walk looks 3 strides of KP_WAVES * 64 entries ahead of the
+    // segment's end (load_ent: p + 3 * stride): the margin keeps that sum below 2^31
+    TM_REQUIRE(nnz < (1ll << 31) - 4ll * KP_WAVES * 64 && n < (1ll << 31) - 1,
+               "sparse block too large for 32-bit entry positions");
     const int nchunk = (int)ceil_div(m, TS);
     TM_REQUIRE(nchunk <= 128, "at most 16384 columns (the tile partials are kept per workgroup)");
     const int n_parts = nchunk * (nchunk + 1) / 2;

@@ -277,12 +277,9 @@ class DenseMatrix(MatrixBase):
                 key = None if center is None else "centered"
                 if rows is not None:
                     # excluded rows get d = 0 (the block is finite: checked once in _i8_colmax), one full pass;
-                    # index_add_: a row id that occurs twice counts twice, as in the reference's row loop
+                    # a row id that occurs twice counts twice (D.masked_d), as in the reference's row loop
                     # (dense_helpers-tmpl.cpp:224) and in the row-list kernels below the threshold
-                    dm = torch.zeros_like(d)
-                    r64 = rows.to(torch.int64)
-                    dm.index_add_(0, r64, d[r64])
-                    d = dm
+                    d = D.masked_d(d, rows)
                     key = "masked" if center is None else "masked-centered"
                 if self.shape[1] > 128:
                     return xd.dense_sandwich_i8_wide(self._dev_c(), d, cmax, center=center)

@@ -131,7 +131,8 @@ class CsrDev:
             dev = cptr.device
             nnz = int(cm_data.numel())
             ar = torch.arange(self.n, device=dev, dtype=torch.int32)
-            cr = torch.zeros((nnz, 4), dtype=torch.int32, device=dev)
+            # (one record of tail padding, as the packed form has: the kernel's clamped look-ahead may name entry nnz)
+            cr = torch.zeros((nnz + 1, 4), dtype=torch.int32, device=dev)[:nnz]
             f64 = cm_data.dtype == torch.float64
             if f64:
                 words = cm_data.view(torch.int32).view(nnz, 2)

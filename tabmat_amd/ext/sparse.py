@@ -368,6 +368,7 @@ def direct_sandwich_pays(A: CsrDev) -> bool:
 K2_PAIRS = "auto"
 K2_PAIRS_PACKED = os.environ.get("TABMAT_AMD_K2_PAIRS_PACKED", "1") == "1"    # packed 12- / 8-byte records (n < 2^25)
 K2_PAIRS_MAX_M = 16384      # tm_sparse_sandwich_pairs_*: at most 128 column chunks
+K2_PAIRS_MAX_NNZ = 2**31 - 4 * 16 * 64   # 32-bit entry positions + the kernel's look-ahead of 3 strides (KP_WAVES * 64)
 
 
 def pairs_sandwich_pays(A: CsrDev) -> bool:
@@ -380,9 +381,9 @@ def pairs_sandwich_pays(A: CsrDev) -> bool:
                                span rows without entries: x (1.6 / k)^0.8 for k entries per row and chunk, at
                                most x 6) + 2.7 ps per pair + ~0.8 us per tile (LDS tile set-up and partials)."""
     if K2_PAIRS != "auto":
-        return K2_PAIRS == "1" and A.m <= K2_PAIRS_MAX_M and 0 < int(A.data.numel()) < 2**31
+        return K2_PAIRS == "1" and A.m <= K2_PAIRS_MAX_M and 0 < int(A.data.numel()) < K2_PAIRS_MAX_NNZ
     nnz, n, m = int(A.data.numel()), A.n, A.m
-    if n == 0 or nnz == 0 or m <= 512 or m > K2_PAIRS_MAX_M or nnz >= 2**31:
+    if n == 0 or nnz == 0 or m <= 512 or m > K2_PAIRS_MAX_M or nnz >= K2_PAIRS_MAX_NNZ:
         return False
     nch = (m + 127) // 128
     parts = nch * (nch + 1) / 2

@@ -485,7 +485,8 @@ def multi_cat_sparse_sandwich_rows(cats, d, A, rows):
     """The fused categorical x sparse cross terms over a short row list: cost proportional to
     len(rows) (the reference works on self[rows], categorical_matrix.py:825-838).  A: CsrDev (its
     chunk-major twin and the row table of the row-list K2 are used); rows: int32 device tensor of
-    unique row ids; d: the full-length weight vector."""
+    row ids (a repeated id counts per occurrence, as X[rows] does in the reference); d: the full-length weight
+    vector."""
     from . import sparse as xs
 
     total = sum(int(c[1]) for c in cats)
@@ -494,7 +495,7 @@ def multi_cat_sparse_sandwich_rows(cats, d, A, rows):
     res = D.out_buf((total, A.m), A.data.dtype)
     codes, ncols, drop, n = _cat_args(cats)
     D.same_float("multi_cat_sparse_sandwich_rows", A.data, d)
-    cm_data, cm_ind, ranges, r32, d_sel = xs._row_table(A, rows, d, True)
+    cm_data, cm_ind, ranges, r32, d_sel = xs._row_table(A, rows, d, False)
     call(f"tm_multi_cat_sparse_sandwich_rows_{D.fsuf(A.data)}", codes, ncols, drop, n, D.p(cm_data),
          D.p(cm_ind), D.p(ranges), D.p(r32), int(r32.numel()), A.m, D.p(d_sel), D.p(res), D.stream_ptr())
     return res

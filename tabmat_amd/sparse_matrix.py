@@ -352,11 +352,7 @@ class SparseMatrix(MatrixBase):
             # wide block: the pair-stream kernel (cost follows the entries and pairs of a row, csrc/sparse_pairs.hip);
             # a long row list is a masked d (the kernel never touches the entries of a row with d == 0); short
             # ones keep the row-list kernels below
-            if rows is not None:
-                dm = torch.zeros_like(d)
-                r64 = rows.to(torch.int64)
-                dm.index_add_(0, r64, d[r64])
-                d = dm
+            d = D.masked_d(d, rows, as_set=True)    # (ext/sparse.pyx:46-48: a row mask)
             res = xs.sparse_sandwich_pairs(A, d)
             if cols is not None:
                 c64 = cols.to(torch.int64)
@@ -367,11 +363,7 @@ class SparseMatrix(MatrixBase):
             pays = self._direct_pays = xs.direct_sandwich_pays(A)
         if pays:
             # wide and very sparse: cost per pair instead of per (row, tile)
-            if rows is not None:
-                dm = torch.zeros_like(d)
-                r64 = rows.to(torch.int64)
-                dm[r64] = d[r64]
-                d = dm
+            d = D.masked_d(d, rows, as_set=True)    # (ext/sparse.pyx:46-48: a row mask)
             res = xs.sparse_sandwich_direct(A, d)
             if cols is not None:
                 c64 = cols.to(torch.int64)
@@ -387,11 +379,7 @@ class SparseMatrix(MatrixBase):
                 return res
             # fast path: unrestricted chunk-pointer kernel; row restriction = masked d,
             # column restriction = sub-selection of the small result
-            if rows is not None:
-                dm = torch.zeros_like(d)
-                r64 = rows.to(torch.int64)
-                dm[r64] = d[r64]
-                d = dm
+            d = D.masked_d(d, rows, as_set=True)    # (ext/sparse.pyx:46-48: a row mask)
             bl = getattr(self, "_blocks_pay", None)
             if bl is None:
                 bl = self._blocks_pay = xs.blocks_sandwich_pays(A)
@@ -432,12 +420,17 @@ class SparseMatrix(MatrixBase):
             return None
         n, m = self.shape
         A = self._dev()
-        if rows is not None:
-            dm = torch.zeros_like(d)
-            r64 = rows.to(torch.int64)
-            dm.index_add_(0, r64, d[r64])           # (a repeated row id counts once per occurrence)
-            d = dm
-        sel = torch.arange(m, dtype=torch.int64, device=d.device) if cols is None else cols.to(torch.int64)
+        d = D.masked_d(d, rows, as_set=True)    # (ext/sparse.pyx:46-48: a row mask)
+        inv = None
+        if cols is None:
+            sel = torch.arange(m, dtype=torch.int64, device=d.device)
+        else:
+            # a column id may occur twice (normalize_index allows it, as the reference does): the product is
+            # computed over the DISTINCT columns -- `colmap` below holds one slot per column id -- and the
+            # repeats are expanded from the small result
+            sel, inv = torch.unique(cols.to(torch.int64), return_inverse=True)
+            if int(sel.numel()) == int(inv.numel()) and bool((sel == cols.to(torch.int64)).all()):
+                inv = None
         k = int(sel.numel())
         out = torch.empty((m, k), dtype=d.dtype, device=d.device)
         W = 128
@@ -453,7 +446,10 @@ class SparseMatrix(MatrixBase):
             del T
         out = out if cols is None else out[sel]
         low = torch.tril(out)
-        return low + torch.tril(out, -1).T
+        full = low + torch.tril(out, -1).T
+        if inv is not None:
+            full = full.index_select(0, inv).index_select(1, inv)
+        return full
 
     def sandwich(self, d, rows=None, cols=None):
         """sparse_matrix.py:175-185."""
@@ -492,11 +488,7 @@ class SparseMatrix(MatrixBase):
                     rows is None or self._values_finite()):
                 # fast path: unrestricted slab kernel; a row restriction is a masked d (excluded
                 # rows contribute exactly 0), column restrictions select from the small result
-                if rows is not None:
-                    dm = torch.zeros_like(d)
-                    r64 = rows.to(torch.int64)
-                    dm[r64] = d[r64]
-                    d = dm
+                d = D.masked_d(d, rows)
                 if (A.data.numel() <= SORTED_K3_NNZ_PER_ROW * self.shape[0] and self.shape[1] >= 1024
                         and xs.ell_supported(Bd)):      # (to_device applies the same test before building twins)
                     # a few nonzeros per row in a wide block: column by column on the CSC form

@@ -548,7 +548,9 @@ class SplitMatrix(MatrixBase):
                 dsum = (d[a:b] if r is None else d[a:b][r.to(torch.int64)]).sum(dtype=torch.float64)
                 _, sub_p, _ = self._sandwich_plan(cols_host)
                 for i in sub_cen.cs_centered:
-                    if cs[i] is not None:
+                    # (a block the narrow path marked without a centre of its own -- sparse columns, dense
+                    # blocks whose centres are all zero -- has centre 0: its centred sum IS the raw sum)
+                    if cs[i] is not None and sub_cen.get(i) is not None:
                         cv = sub_cen.get(i).to(torch.float64)
                         if sub_p[i] is not None:
                             cv = cv[sub_p[i].to(torch.int64)]
@@ -700,14 +702,15 @@ class SplitMatrix(MatrixBase):
                     colsum[b] = cs_tmp[0][t0:t0 + s]
                     if sub_cen is not None and 0 in sub_cen.cs_centered:
                         center.cs_centered.add(b)
+            # the categoricals' X'd falls out of the product whether or not anything is centred
+            for k, i in enumerate(nar["cat"]):
+                if cs_tmp[1 + k] is not None and i in nar["cat_sub"]:
+                    colsum[i] = cs_tmp[1 + k][nar["cat_sub"][i]]
         if center is not None:
             # every entry between two columns of T came out of T's centred self term
             g = torch.full_like(nar["sel"], -1, dtype=torch.int32)
             g[nar["sel"] < nar["w_pad"]] = _Centering.NARROW_GROUP
             center.groups = g
-            for k, i in enumerate(nar["cat"]):
-                if cs_tmp[1 + k] is not None and i in nar["cat_sub"]:
-                    colsum[i] = cs_tmp[1 + k][nar["cat_sub"][i]]
         sel = nar["sel"]
         return full.index_select(0, sel).index_select(1, sel)
 
@@ -769,11 +772,7 @@ class SplitMatrix(MatrixBase):
         budget = (128 * 1024) // 8       # LDS tiles are made of doubles for float32 data too
         groups = self._cat_groups(cat_ids)
         if groups:
-            d_eff = d
-            if rows is not None:   # row restriction = masked d (excluded rows contribute 0)
-                d_eff = torch.zeros_like(d)
-                r64 = rows.to(torch.int64)
-                d_eff[r64] = d[r64]
+            d_eff = D.masked_d(d, rows)   # row restriction = masked d (excluded rows contribute 0)
         for grp in groups:
             cats = [(mats[i]._dev(), mats[i].shape[1], mats[i].drop_first) for i in grp]
             total = sum(c[1] for c in cats)
@@ -817,11 +816,7 @@ class SplitMatrix(MatrixBase):
                         or not xsplit.multi_cat_dense_tile_ok(cats, mw._dev_c())):
                     continue
                 if d_big is None:
-                    d_big = d
-                    if rows is not None:
-                        d_big = torch.zeros_like(d)
-                        r64 = rows.to(torch.int64)
-                        d_big.index_add_(0, r64, d[r64])   # (a repeated row counts once per occurrence)
+                    d_big = D.masked_d(d, rows)
                 stacked = xsplit.multi_cat_dense_sandwich(cats, d_big, mw._dev_c())
                 for ci, i in enumerate(big):
                     res = stacked[int(offs[ci]):int(offs[ci + 1])]

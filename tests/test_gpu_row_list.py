@@ -183,10 +183,39 @@ def test_cat_sparse_row_list_kernel(frac, kind, m, dtype):
     cats = [(D.to_dev(c), L - int(dr), dr) for c, L, dr in zip(codes, levels, drops)]
     sm = tm.SparseMatrix(S)
     got = D.to_host(xsplit.multi_cat_sparse_sandwich_rows(cats, D.to_dev(d), sm._dev(), D.idx_dev(rows)))
-    uniq = np.unique(rows)                                 # a repeated row counts once (a row SET)
+    # a repeated row counts per occurrence, as X[rows] does in the reference (categorical_matrix.py:825-838)
     want = np.vstack([orc.sandwich_cat_sparse(c, L - int(dr), d.astype(np.float64), sps.csr_matrix(S).astype(np.float64),
-                                              uniq.astype(np.int32), None, None, dr)
+                                              rows.astype(np.int32), None, None, dr)
                       for c, L, dr in zip(codes, levels, drops)])
     tol = 1e-10 if dtype == np.float64 else 3e-4
     assert got.shape == want.shape
     assert np.abs(got - want).max() / max(np.abs(want).max(), 1e-300) < tol
+
+
+@pytest.mark.parametrize("frac", [0.7, 0.3, 0.04])
+def test_repeated_row_ids_follow_the_reference_product_by_product(frac):
+    """a row id that occurs twice.  The reference is not uniform here and the products follow it one by
+    one, on the masked-d pass (long lists) and on the row-list kernels (short lists) alike: the sparse SELF sandwich
+    turns `rows` into a mask (ext/sparse.pyx:46-48: once), every other product loops over the list or indexes
+    X[rows] (twice).  The oracle restates exactly those loops."""
+    from oracle import oracle as orc
+
+    n = 30_000
+    specs, idx = cs.mixed_specs(n, 24, 140, (9, 30), seed=5)
+    mat = to_tm_split(specs, idx)
+    blocks = [cs.to_oracle_block(s) for s in specs]
+    rng = np.random.default_rng(int(frac * 100))
+    d = rng.random(n)
+    rows = rng.choice(n, int(n * frac), replace=False)
+    rows = np.concatenate([rows, rows[: len(rows) // 3], rows[:7]])       # some twice, seven of them three times
+    got = mat.sandwich(d, rows=rows)
+    want = orc.split_sandwich(blocks, idx, d, rows, None)
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    # block by block: the sparse self term counts a repeated row once, the dense one per occurrence
+    sm, dm = mat.matrices[1], mat.matrices[0]
+    S, B = specs[1][1].tocsr(), specs[0][1]
+    uniq = np.unique(rows)
+    want_s = (S[uniq].T @ sps.diags(d[uniq]) @ S[uniq]).toarray()
+    assert np.abs(sm.sandwich(d, rows=rows) - want_s).max() <= 1e-10 * np.abs(want_s).max()
+    want_d = B[rows].T @ (d[rows, None] * B[rows])
+    assert np.abs(dm.sandwich(d, rows=rows) - want_d).max() <= 1e-10 * np.abs(want_d).max()

@@ -67,3 +67,31 @@ def test_sparse_matrix_in_row_parts(monkeypatch):
     Sr = S.tocsr()[rows]
     want = (Sr.T @ sps.diags(d[rows]) @ Sr).toarray()
     assert np.abs(sm.sandwich(d, rows=rows) - want).max() <= 1e-10 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n_sel", [30, 70, 100])
+def test_standardized_sandwich_in_row_parts_with_a_narrow_column_selection(monkeypatch, n_sel):
+    """the row-parts path with a narrow `cols=` selection that mixes dense and sparse columns.
+    The narrow path marks EVERY block of the selection as centred (sparse columns and all-zero centres have centre
+    0); the parts' column sums must take those as they are instead of asking for a centre vector."""
+    import tabmat_amd as tm
+    import tabmat_amd.sparse_matrix as spm
+
+    monkeypatch.setattr(spm, "PART_NNZ", 20_000)
+    specs, idx = cs.mixed_specs(9000, 64, 120, (12,), seed=4)
+    X = to_tm_split(specs, idx)
+    assert X._parts() is not None and len(X._parts()) >= 2
+    E = np.hstack([cs.spec_toarray(s) for s in specs])
+    order = np.argsort(np.concatenate(idx))         # E's columns in block order -> matrix column order
+    E = E[:, order]
+    rng = np.random.default_rng(n_sel)
+    p = E.shape[1]
+    shift, mult = rng.standard_normal(p) * 3.0, rng.random(p) + 0.5
+    S = tm.StandardizedMatrix(X, shift, mult)
+    d = rng.random(9000)
+    noncat = np.concatenate([idx[0], idx[1]])
+    cols = np.sort(np.concatenate([rng.choice(noncat, n_sel, replace=False), idx[2][:5]]))
+    Es = (E * mult + shift)[:, cols]
+    want = Es.T @ (d[:, None] * Es)
+    got = S.sandwich(d, cols=cols)
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()

@@ -264,7 +264,15 @@ def test_deterministic_sparse_self_sandwich(dtype, monkeypatch):
     got_rc = sm.sandwich(d, rows, cols)
     assert np.abs(got_rc - want_rc).max() / np.abs(want_rc).max() < tol
     assert np.array_equal(got_rc, sm.sandwich(d, rows, cols))
+    # a column id twice inside one 128-column window, unsorted: the product of X[:, cols], as the
+    # LDS-atomic path gives it -- the repeats are expanded from the product over the distinct columns
+    cols_dup = np.concatenate([cols[:20][::-1], cols[5:12], cols[30:]]).astype(np.int32)
+    Sd = S.tocsr()[rows][:, cols_dup].astype(np.float64)
+    want_dup = (Sd.T.multiply(d[rows].astype(np.float64))).dot(Sd).toarray()
+    got_dup = sm.sandwich(d, rows, cols_dup)
+    assert np.abs(got_dup - want_dup).max() / np.abs(want_dup).max() < tol
     monkeypatch.setattr(cmod, "DETERMINISTIC", False)
+    assert np.abs(sm.sandwich(d, rows, cols_dup) - want_dup).max() / np.abs(want_dup).max() < tol
     c = sm.sandwich(d)
     assert np.abs(a - c).max() / np.abs(want).max() < tol
 
