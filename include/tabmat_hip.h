@@ -692,6 +692,21 @@ int tm_multi_cat_sparse_sandwich_rows_f64(const void *const *h_codes, const int6
                                           const int32_t *row_ranges, const int32_t *rows,
                                           int64_t n_sel, int64_t m, const double *d_sel, double *out,
                                           void *stream);
+/* The same with the columns of the chunk-major entries as ONE BYTE each (cm_col8: the column inside its 128-column
+ * chunk, the array tm_sparse_sandwich_blocks_u8_* streams): since round 6 the host side keeps no int32 copy of the
+ * chunk-major columns (-1.0 GB at BASELINE configs[3]). */
+int tm_multi_cat_sparse_sandwich_rows_u8_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                             const int32_t *h_drop_first, int n_cats,
+                                             const float *cm_data, const uint8_t *cm_col8,
+                                             const int32_t *row_ranges, const int32_t *rows,
+                                             int64_t n_sel, int64_t m, const float *d_sel, float *out,
+                                             void *stream);
+int tm_multi_cat_sparse_sandwich_rows_u8_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                             const int32_t *h_drop_first, int n_cats,
+                                             const double *cm_data, const uint8_t *cm_col8,
+                                             const int32_t *row_ranges, const int32_t *rows,
+                                             int64_t n_sel, int64_t m, const double *d_sel, double *out,
+                                             void *stream);
 /* The same fused categorical x sparse cross terms on the ENTRY twin of the sparse block (round 4; layout at
  * tm_csr_dense_sandwich_ent_*): no slab-form twin is needed for a block whose sparse x dense term runs on the entry
  * kernel.  mk = 16 * groups kernel columns; out [sum(n_cols)][mk] in kernel column order (the caller applies the
@@ -870,6 +885,16 @@ int tm_csr_dense_sandwich_rows_f64(const double *cm_data, const int32_t *cm_indi
                                    const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
                                    const double *d_sel, int64_t n, int64_t m, const double *B, int64_t r,
                                    int order_f, double *out, void *stream);
+/* (byte columns inside the 128-column chunk instead of int32 block columns: see tm_multi_cat_sparse_sandwich_rows_u8_*;
+ * reference loop: ext/sparse_helpers-tmpl.cpp:67-131) */
+int tm_csr_dense_sandwich_rows_u8_f32(const float *cm_data, const uint8_t *cm_col8,
+                                      const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                      const float *d_sel, int64_t n, int64_t m, const float *B, int64_t r,
+                                      int order_f, float *out, void *stream);
+int tm_csr_dense_sandwich_rows_u8_f64(const double *cm_data, const uint8_t *cm_col8,
+                                      const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                      const double *d_sel, int64_t n, int64_t m, const double *B, int64_t r,
+                                      int order_f, double *out, void *stream);
 
 /* =====================================================================================
  * Deterministic categorical transpose_matvec / sandwich diagonal (ext/categorical.pyx:23-42 with

@@ -1216,9 +1216,10 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
 // (the table the row-list K2 uses), part = one 32-column group of a 128-column chunk, tile
 // [total levels][33] of doubles in LDS.  8 lanes per selected row walk its list in the group's
 // chunk and keep the entries of the group; codes and d are read once per row.
-template <typename F>
+// (IX = uint8_t: the columns as bytes inside their 128-column chunk, round 6)
+template <typename F, typename IX>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_rows_kernel(
-    CatSet cs, const F *__restrict__ cm_data, const int32_t *__restrict__ cm_ind,
+    CatSet cs, const F *__restrict__ cm_data, const IX *__restrict__ cm_ind,
     const int32_t *__restrict__ ranges, const int32_t *__restrict__ rows, const F *__restrict__ d_sel,
     int64_t n_sel, int64_t rows_per_block, F *__restrict__ ws, int64_t stride) {
     constexpr int GC = 32;                       // columns per group
@@ -1253,7 +1254,7 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_rows_kernel(
             }
         }
         for (int e = e0 + lt; e < e1; e += 8) {
-            const int col = cm_ind[e] - g * GC;
+            const int col = (int)cm_ind[e] - (sizeof(IX) == 1 ? (g & 3) : g) * GC;
             if (col < 0 || col >= GC) continue;
             const lds_acc_t x = (lds_acc_t)(dk * cm_data[e]);
 #pragma unroll
@@ -1422,10 +1423,10 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
     return TM_OK;
 }
 
-template <typename F>
+template <typename F, typename IX>
 static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *h_ncols,
                                      const int32_t *h_drop, int n_cats, const F *cm_data,
-                                     const int32_t *cm_ind, const int32_t *ranges, const int32_t *rows,
+                                     const IX *cm_ind, const int32_t *ranges, const int32_t *rows,
                                      int64_t n_sel, int64_t m, const F *d_sel, F *out, hipStream_t st);
 
 template <typename F>
@@ -1828,10 +1829,10 @@ int tm_multi_cat_sparse_sandwich_slab_f64(const void *const *h_codes, const int6
 }  // extern "C"
 
 namespace tmh {
-template <typename F>
+template <typename F, typename IX>
 static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *h_ncols,
                                      const int32_t *h_drop, int n_cats, const F *cm_data,
-                                     const int32_t *cm_ind, const int32_t *ranges, const int32_t *rows,
+                                     const IX *cm_ind, const int32_t *ranges, const int32_t *rows,
                                      int64_t n_sel, int64_t m, const F *d_sel, F *out, hipStream_t st) {
     CatSet cs;
     int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
@@ -1860,7 +1861,7 @@ static int run_multi_cat_sparse_rows(const void *const *h_codes, const int64_t *
     if (rc) return rc;
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
-    auto kern = &multi_cat_sparse_rows_kernel<F>;
+    auto kern = &multi_cat_sparse_rows_kernel<F, IX>;
     if (lds > 48 * 1024)
         TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1885,7 +1886,7 @@ int tm_multi_cat_sparse_sandwich_rows_f32(const void *const *h_codes, const int6
                                           const int32_t *row_ranges, const int32_t *rows,
                                           int64_t n_sel, int64_t m, const float *d_sel, float *out,
                                           void *stream) {
-    return tmh::run_multi_cat_sparse_rows<float>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+    return tmh::run_multi_cat_sparse_rows<float, int32_t>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
                                                  cm_indices, row_ranges, rows, n_sel, m, d_sel, out,
                                                  tmh::as_stream(stream));
 }
@@ -1895,9 +1896,28 @@ int tm_multi_cat_sparse_sandwich_rows_f64(const void *const *h_codes, const int6
                                           const int32_t *row_ranges, const int32_t *rows,
                                           int64_t n_sel, int64_t m, const double *d_sel, double *out,
                                           void *stream) {
-    return tmh::run_multi_cat_sparse_rows<double>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+    return tmh::run_multi_cat_sparse_rows<double, int32_t>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
                                                   cm_indices, row_ranges, rows, n_sel, m, d_sel, out,
                                                   tmh::as_stream(stream));
 }
+int tm_multi_cat_sparse_sandwich_rows_u8_f32(const void *const *h_codes, const int64_t *h_ncols,
+                                             const int32_t *h_drop_first, int n_cats,
+                                             const float *cm_data, const uint8_t *cm_col8,
+                                             const int32_t *row_ranges, const int32_t *rows,
+                                             int64_t n_sel, int64_t m, const float *d_sel, float *out,
+                                             void *stream) {
+    return tmh::run_multi_cat_sparse_rows<float, uint8_t>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+                                                          cm_col8, row_ranges, rows, n_sel, m, d_sel, out,
+                                                          tmh::as_stream(stream));
+}
+int tm_multi_cat_sparse_sandwich_rows_u8_f64(const void *const *h_codes, const int64_t *h_ncols,
+                                             const int32_t *h_drop_first, int n_cats,
+                                             const double *cm_data, const uint8_t *cm_col8,
+                                             const int32_t *row_ranges, const int32_t *rows,
+                                             int64_t n_sel, int64_t m, const double *d_sel, double *out,
+                                             void *stream) {
+    return tmh::run_multi_cat_sparse_rows<double, uint8_t>(h_codes, h_ncols, h_drop_first, n_cats, cm_data,
+                                                           cm_col8, row_ranges, rows, n_sel, m, d_sel, out,
+                                                           tmh::as_stream(stream));
+}
 }  // extern "C"
-

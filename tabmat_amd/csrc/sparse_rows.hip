@@ -16,9 +16,11 @@ constexpr int RK_TS = 128;          // sparse columns per chunk = LDS tile rows
 constexpr int RK_W = 128;           // dense columns per part
 constexpr int RK_WAVES = 16;
 
-template <typename F>
+// IX = int32_t: column indices of the whole block; IX = uint8_t: the column inside the 128-column chunk (the byte
+// twin K2b streams -- round 6: the int32 chunk-major columns are no longer kept in HBM)
+template <typename F, typename IX>
 __global__ __launch_bounds__(RK_WAVES * 64) void csr_dense_rows_kernel(
-    const F *__restrict__ data, const int32_t *__restrict__ ind, const int32_t *__restrict__ ranges,
+    const F *__restrict__ data, const IX *__restrict__ ind, const int32_t *__restrict__ ranges,
     int64_t n_sel, const int32_t *__restrict__ rows, const F *__restrict__ d_sel,
     const F *__restrict__ B, int64_t ldb, int order_f, int64_t n, int nB, int64_t rows_per_block,
     F *__restrict__ ws) {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(RK_WAVES * 64) void csr_dense_rows_kernel(
     auto scatter_row = [&](int e0, int ne, F dk, F x0, F x1) {
         for (int base = 0; base < ne; base += 64) {          // > 64 entries of a row in one chunk: rare
             const int cnt = min(ne - base, 64);
-            const int ci = lane < cnt ? ind[e0 + base + lane] - chunk * RK_TS : 0;
+            const int ci = lane < cnt ? (int)ind[e0 + base + lane] - (sizeof(IX) == 1 ? 0 : chunk * RK_TS) : 0;
             const F cv = lane < cnt ? data[e0 + base + lane] * dk : F(0);
             for (int e = 0; e < cnt; ++e) {
                 const int col = __builtin_amdgcn_readlane(ci, e);
@@ -93,8 +95,8 @@ __global__ void rows_untile_kernel(const F *__restrict__ tmp, int64_t m, int64_t
     out[e] = tmp[(((i / RK_TS) * nz + j / RK_W) * RK_TS + i % RK_TS) * RK_W + j % RK_W];
 }
 
-template <typename F>
-static int run_csr_dense_rows(const F *data, const int32_t *ind, const int32_t *ranges, int64_t n_sel,
+template <typename F, typename IX>
+static int run_csr_dense_rows(const F *data, const IX *ind, const int32_t *ranges, int64_t n_sel,
                               const int32_t *rows, const F *d_sel, int64_t n, int64_t m, const F *B,
                               int64_t nB, int order_f, F *out, hipStream_t st) {
     const int64_t total = m * nB;
@@ -118,7 +120,7 @@ static int run_csr_dense_rows(const F *data, const int32_t *ind, const int32_t *
     F *tmp = reinterpret_cast<F *>(wsv);
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     const size_t lds = sizeof(lds_acc_t) * (size_t)stride;
-    auto kern = &csr_dense_rows_kernel<F>;
+    auto kern = &csr_dense_rows_kernel<F, IX>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
@@ -143,15 +145,29 @@ int tm_csr_dense_sandwich_rows_f32(const float *cm_data, const int32_t *cm_indic
                                    const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
                                    const float *d_sel, int64_t n, int64_t m, const float *B, int64_t r,
                                    int order_f, float *out, void *stream) {
-    return tmh::run_csr_dense_rows<float>(cm_data, cm_indices, row_ranges, n_sel, rows, d_sel, n, m, B, r,
+    return tmh::run_csr_dense_rows<float, int32_t>(cm_data, cm_indices, row_ranges, n_sel, rows, d_sel, n, m, B, r,
                                           order_f, out, tmh::as_stream(stream));
 }
 int tm_csr_dense_sandwich_rows_f64(const double *cm_data, const int32_t *cm_indices,
                                    const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
                                    const double *d_sel, int64_t n, int64_t m, const double *B, int64_t r,
                                    int order_f, double *out, void *stream) {
-    return tmh::run_csr_dense_rows<double>(cm_data, cm_indices, row_ranges, n_sel, rows, d_sel, n, m, B, r,
+    return tmh::run_csr_dense_rows<double, int32_t>(cm_data, cm_indices, row_ranges, n_sel, rows, d_sel, n, m, B, r,
                                            order_f, out, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_rows_u8_f32(const float *cm_data, const uint8_t *cm_col8,
+                                      const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                      const float *d_sel, int64_t n, int64_t m, const float *B, int64_t r,
+                                      int order_f, float *out, void *stream) {
+    return tmh::run_csr_dense_rows<float, uint8_t>(cm_data, cm_col8, row_ranges, n_sel, rows, d_sel, n, m, B, r,
+                                                   order_f, out, tmh::as_stream(stream));
+}
+int tm_csr_dense_sandwich_rows_u8_f64(const double *cm_data, const uint8_t *cm_col8,
+                                      const int32_t *row_ranges, int64_t n_sel, const int32_t *rows,
+                                      const double *d_sel, int64_t n, int64_t m, const double *B, int64_t r,
+                                      int order_f, double *out, void *stream) {
+    return tmh::run_csr_dense_rows<double, uint8_t>(cm_data, cm_col8, row_ranges, n_sel, rows, d_sel, n, m, B, r,
+                                                    order_f, out, tmh::as_stream(stream));
 }
 
 }  // extern "C"

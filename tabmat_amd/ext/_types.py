@@ -1,6 +1,7 @@
 """Device-resident block storage handed to the ext functions."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -47,67 +48,129 @@ class DenseDev:
         return self.buf if self.order_f == 0 else self.buf.T
 
 
-@dataclass
+# Column indices of the CSR twin: int32 as uploaded, or -- once to_device() has built the twins (compact_indices) and
+# the block has at most 65 536 columns -- ONLY the 16-bit copy the unrestricted matvec / transpose_matvec kernels
+# stream (1.0 GB less at BASELINE configs[3]).  The generic / restricted entry points and the twin
+# builders read `.indices`, which then widens into ONE library-wide scratch tensor (the latest widening of any block;
+# released by the next one or by release_index_scratch()).
+COMPACT_CSR_INDICES = os.environ.get("TABMAT_AMD_COMPACT_CSR", "1") != "0"
+_WIDE = {"owner": None, "tensor": None}
+
+
+def release_index_scratch() -> None:
+    _WIDE["owner"] = _WIDE["tensor"] = None
+
+
 class CsrDev:
     """CSR twin of a sparse block in HBM (sparse_matrix.py:133-143): int32 column indices,
     int64 indptr (ext/sparse.pyx:13-15 accepts int32 or int64; narrowed/widened on upload)."""
 
-    data: torch.Tensor
-    indices: torch.Tensor
-    indptr: torch.Tensor
-    n: int
-    m: int
+    def __init__(self, data, indices, indptr, n, m):
+        self.data = data
+        self._ind32 = indices
+        self._ind16 = None
+        self.indptr = indptr
+        self.n = int(n)
+        self.m = int(m)
 
     @property
     def dtype(self):
         return self.data.dtype
 
+    @property
+    def indices(self) -> torch.Tensor:
+        """int32 column indices (widened from the 16-bit twin into the shared scratch once compacted)."""
+        if self._ind32 is not None:
+            return self._ind32
+        if _WIDE["owner"] is not self or _WIDE["tensor"] is None:
+            _WIDE["owner"] = _WIDE["tensor"] = None           # (free the previous block's scratch first)
+            _WIDE["tensor"] = self._ind16.to(torch.int32).bitwise_and_(0xFFFF)
+            _WIDE["owner"] = self
+        return _WIDE["tensor"]
+
     def indices16(self):
         """uint16 twin of the column indices (bit pattern in an int16 tensor) for the unrestricted matvec /
         transpose_matvec stream kernels (tm_csr_{matvec,rmatvec}_u16_*): 10 instead of 12 bytes per entry."""
-        i16 = getattr(self, "_ind16", None)
+        i16 = self._ind16
         if i16 is None:
             assert self.m <= 65536
-            w = self.indices.to(torch.int32)
+            w = self._ind32
             i16 = self._ind16 = torch.where(w >= 32768, w - 65536, w).to(torch.int16).contiguous()
         return i16
 
-    def chunk_col8(self):
-        """uint8 [nnz]: the column of every chunk-major entry inside its column chunk (tm_sparse_sandwich_blocks_u8_*)."""
-        c8 = getattr(self, "_cm_col8", None)
-        if c8 is None:
-            from .._lib import lib
+    def compact_indices(self) -> bool:
+        """Keep only the 16-bit column indices (blocks of at most 65 536 columns).  Called by
+        SparseMatrix.to_device() after the twins are built."""
+        if (COMPACT_CSR_INDICES and self._ind32 is not None and self.m <= 65536
+                and self._ind32.numel() > 0):
+            self.indices16()
+            self._ind32 = None
+            return True
+        return False
 
-            ch = int(lib().tm_sparse_chunk_cols())
-            _, cm_ind, _ = self.chunk_major()
-            c8 = self._cm_col8 = torch.remainder(cm_ind, ch).to(torch.uint8).contiguous()
-        return c8
+    def nbytes(self) -> int:
+        """HBM bytes of the CSR arrays and of every twin built so far."""
+        seen, tot = set(), 0
+
+        def add(t):
+            nonlocal tot
+            if isinstance(t, torch.Tensor):
+                if t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    tot += t.numel() * t.element_size()
+            elif isinstance(t, (tuple, list)):
+                for x in t:
+                    add(x)
+
+        for v in self.__dict__.values():
+            add(v)
+        return tot
+
+    def chunk_col8(self):
+        """uint8 [nnz]: the column of every chunk-major entry inside its column chunk (tm_sparse_sandwich_blocks_u8_*,
+        the row-list kernels)."""
+        return self.chunk_major()[1]
+
+    def chunk_cols32(self):
+        """int32 [nnz] block columns of the chunk-major entries -- NOT kept since round 6 (the byte columns serve every
+        kernel): rebuilt on request for the int32 entry points (K2B_U8 = False, the record twins' builders)."""
+        _, c8, cptr = self.chunk_major()
+        from .._lib import lib
+
+        ch = int(lib().tm_sparse_chunk_cols())
+        nch = int(cptr.shape[0])
+        sizes = (cptr[:, -1] - cptr[:, 0]).to(torch.int64)
+        base = torch.repeat_interleave(torch.arange(nch, device=c8.device, dtype=torch.int32) * ch, sizes,
+                                       output_size=int(c8.numel()))
+        return base.add_(c8.to(torch.int32))
 
     def chunk_major(self):
-        """(cm_data, cm_indices, cptr int32 [NCH, n + 1]): the entries regrouped by column chunk,
-        inside a chunk by row (see tm_sparse_sandwich_chunked_*).  Built once per block (ingest:
-        one device key sort), cached."""
+        """(cm_data, cm_col8 uint8, cptr int32 [NCH, n + 1]): the entries regrouped by column chunk,
+        inside a chunk by row (see tm_sparse_sandwich_chunked_*); cm_col8 = the column INSIDE the chunk.
+        Built once per block (ingest: one device key sort), cached."""
         cm = getattr(self, "_cm", None)
         if cm is None:
             from .._lib import lib
 
             ch = int(lib().tm_sparse_chunk_cols())
+            assert ch <= 256
             nch = max(1, (self.m + ch - 1) // ch)
             nnz = int(self.data.numel())
             if nnz >= 2**31:
                 raise ValueError("chunk pointers need nnz < 2^31")
             dev = self.data.device
+            ind = self.indices
             counts = self.indptr[1:] - self.indptr[:-1]
             rows = torch.repeat_interleave(torch.arange(self.n, device=dev, dtype=torch.int64), counts)
-            chunk = torch.div(self.indices, ch, rounding_mode="floor")
+            chunk = torch.div(ind, ch, rounding_mode="floor")
             # CSR is row-major with ascending columns: a STABLE sort by the chunk number alone is
             # the (chunk, row, column) order -- an 8- or 16-bit radix sort instead of a 64-bit one
             small = chunk.to(torch.uint8 if nch <= 255 else torch.int16 if nch < 2**15 else torch.int32)
             perm = torch.sort(small, stable=True).indices
             del small
             cm_data = self.data[perm].contiguous()
-            cm_ind = self.indices[perm].contiguous()
-            del perm
+            cm_col8 = torch.remainder(ind, ch).to(torch.uint8)[perm].contiguous()
+            del perm, ind
             key = chunk.to(torch.int64) * self.n + rows
             del rows, chunk
             per = torch.bincount(key, minlength=nch * self.n) if nnz else \
@@ -116,7 +179,7 @@ class CsrDev:
             start = (torch.cumsum(per, dim=0) - per).view(nch, self.n)
             ends = torch.cat([start[1:, 0], torch.tensor([nnz], device=dev, dtype=torch.int64)])
             cptr = torch.cat([start, ends[:, None]], dim=1).to(torch.int32).contiguous()
-            cm = (cm_data, cm_ind, cptr)
+            cm = (cm_data, cm_col8, cptr)
             self._cm = cm
         return cm
 
@@ -127,7 +190,8 @@ class CsrDev:
         column by column: a 2-D gather of more than 2^32 bytes came back scrambled on this stack.)"""
         cr = getattr(self, "_cm_rec", None)
         if cr is None:
-            cm_data, cm_ind, cptr = self.chunk_major()
+            cm_data, _, cptr = self.chunk_major()
+            cm_ind = self.chunk_cols32()
             dev = cptr.device
             nnz = int(cm_data.numel())
             ar = torch.arange(self.n, device=dev, dtype=torch.int32)
@@ -162,7 +226,7 @@ class CsrDev:
                 from .._lib import lib
 
                 ch = int(lib().tm_sparse_chunk_cols())
-                cm_data, cm_ind, cptr = self.chunk_major()
+                cm_data, cm_c8, cptr = self.chunk_major()
                 dev = cptr.device
                 nnz = int(cm_data.numel())
                 f64 = cm_data.dtype == torch.float64
@@ -182,7 +246,7 @@ class CsrDev:
                     if k:
                         cnt = (cptr[c, 1:] - cptr[c, :-1]).to(torch.int64)
                         rows = torch.repeat_interleave(ar, cnt, output_size=k)
-                        word = (rows << 7) | torch.remainder(cm_ind[pos:pos + k].to(torch.int64), ch)
+                        word = (rows << 7) | cm_c8[pos:pos + k].to(torch.int64)
                         rec[pos:pos + k, W - 1] = torch.where(word >= 2**31, word - 2**32, word).to(torch.int32)
                     pos += k
                 cr = buf
@@ -288,13 +352,22 @@ class CsrDev:
                     key = wg * 2 + (~full).to(torch.int64)
                     order = torch.sort(key, stable=True).indices          # row order kept inside a class
                     cnts = torch.bincount(key, minlength=nb_p * 2).view(nb_p, 2)
+                    desc = desc[order]
+                    # first / last row of every workgroup: the stable sort keeps the (ascending) row order inside a
+                    # (workgroup, class) segment, so they are the rows at the segments' ends -- 2 nb_p reads.  (Round
+                    # 5 asked scatter_reduce_ for them: millions of rows contending for nb_p addresses, 200 ms per
+                    # tile, 2.2 of the 2.4 s this twin took to build at BASELINE configs[3].)
+                    seg_end = torch.cumsum(cnts.reshape(-1), 0)
+                    seg_lo = (seg_end - cnts.reshape(-1)).clamp_(max=c - 1)
+                    seg_hi = (seg_end - 1).clamp_(min=0)
+                    srow = desc[:, 2].to(torch.int64)
                     big = torch.iinfo(torch.int64).max
-                    rows_h = torch.full((nb_p,), big, dtype=torch.int64, device=dev).scatter_reduce_(
-                        0, wg, row, "amin").cpu().numpy()
-                    rows_l = torch.zeros(nb_p, dtype=torch.int64, device=dev).scatter_reduce_(
-                        0, wg, row, "amax").cpu().numpy()
+                    some = cnts > 0
+                    rows_h = torch.where(some, srow[seg_lo].view(nb_p, 2), big).amin(dim=1).cpu().numpy()
+                    rows_l = torch.where(some, srow[seg_hi].view(nb_p, 2), 0).amax(dim=1).cpu().numpy()
                     cnts = cnts.cpu().numpy()
-                    descs.append(desc[order])
+                    descs.append(desc)
+                    del srow
                     lo = off
                     for sgl in range(nb_p):
                         nf, nh = int(cnts[sgl][0]), int(cnts[sgl][1])

@@ -187,7 +187,7 @@ def csr_dense_sandwich_ent(A: SlabEnt, B: DenseDev, d, want_colsum=False):
 
 
 def _row_table(A: CsrDev, rows, d, as_set: bool):
-    """(cm_data, cm_ind, ranges int32 [n_chunks, n_sel, 2], rows_sorted int32, d_sel): the
+    """(cm_data, cm_col8, ranges int32 [n_chunks, n_sel, 2], rows_sorted int32, d_sel): the
     {start, end} of every selected row in every column chunk, rows ascending (the sums do not
     depend on the order).  as_set: a repeated row counts once -- the reference's sparse_sandwich
     turns `rows` into a mask (ext/sparse.pyx:46-48) while its csr_dense_sandwich loops over the
@@ -196,7 +196,7 @@ def _row_table(A: CsrDev, rows, d, as_set: bool):
 
     import torch
 
-    cm_data, cm_ind, cptr = A.chunk_major()
+    cm_data, cm_c8, cptr = A.chunk_major()
     # the table depends on `rows` only: the self sandwich and the cross term of one call share it
     # (keyed on the tensor AND its version counter: a caller that refills a static index buffer in
     # place must not get the ranges of the old contents)
@@ -214,7 +214,7 @@ def _row_table(A: CsrDev, rows, d, as_set: bool):
         rr = torch.unique_consecutive(r64) if key else r64
         tabs[key] = (rr, torch.stack([cptr[:, rr], cptr[:, rr + 1]], dim=2).contiguous())
     rr, ranges = tabs[key]
-    return cm_data, cm_ind, ranges, rr.to(torch.int32).contiguous(), d[rr].contiguous()
+    return cm_data, cm_c8, ranges, rr.to(torch.int32).contiguous(), d[rr].contiguous()
 
 
 def sparse_sandwich_rows(A: CsrDev, d, rows):
@@ -224,9 +224,10 @@ def sparse_sandwich_rows(A: CsrDev, d, rows):
     if A.m == 0 or D.nlen(rows) == 0 or A.data.numel() == 0:
         return out
     D.same_float("sparse_sandwich_rows", A.data, d)
-    cm_data, cm_ind, ranges, r32, d_sel = _row_table(A, rows, d, True)
+    cm_data, cm_c8, ranges, r32, d_sel = _row_table(A, rows, d, True)
+    cols = cm_c8 if K2B_U8 else A.chunk_cols32()        # (int32 columns: rebuilt per call, the A/B switch only)
     call(f"tm_sparse_sandwich_chunked_rows_{'u8_' if K2B_U8 else ''}{D.fsuf(A.data)}", D.p(cm_data),
-         D.p(A.chunk_col8() if K2B_U8 else cm_ind), D.p(ranges),
+         D.p(cols), D.p(ranges),
          int(r32.numel()), A.m, int(cm_data.numel()), D.p(d_sel), D.p(out), D.stream_ptr())
     return out
 
@@ -238,8 +239,8 @@ def csr_dense_sandwich_rows(A: CsrDev, B: DenseDev, d, rows):
     if A.m == 0 or B.m == 0 or D.nlen(rows) == 0 or A.data.numel() == 0:
         return out
     D.same_float("csr_dense_sandwich_rows", A.data, B.buf, d)
-    cm_data, cm_ind, ranges, r32, d_sel = _row_table(A, rows, d, False)
-    call(f"tm_csr_dense_sandwich_rows_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(ranges),
+    cm_data, cm_c8, ranges, r32, d_sel = _row_table(A, rows, d, False)
+    call(f"tm_csr_dense_sandwich_rows_u8_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_c8), D.p(ranges),
          int(r32.numel()), D.p(r32), D.p(d_sel), A.n, A.m, D.p(B.buf), B.m, B.order_f, D.p(out),
          D.stream_ptr())
     return out
@@ -251,9 +252,10 @@ def sparse_sandwich_chunked(A: CsrDev, d):
         return D.zeros((A.m, A.m), A.dtype)
     out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_chunked", A.data, d)
-    cm_data, cm_ind, cptr = A.chunk_major()
+    cm_data, cm_c8, cptr = A.chunk_major()
+    cols = cm_c8 if K2B_U8 else A.chunk_cols32()
     call(f"tm_sparse_sandwich_chunked_{'u8_' if K2B_U8 else ''}{D.fsuf(A.data)}", D.p(cm_data),
-         D.p(A.chunk_col8() if K2B_U8 else cm_ind), D.p(cptr),
+         D.p(cols), D.p(cptr),
          A.n, A.m, int(cm_data.numel()), D.p(d), D.p(out), D.stream_ptr())
     return out
 
@@ -287,13 +289,14 @@ def sparse_sandwich_blocks(A: CsrDev, d):
         return D.zeros((A.m, A.m), A.dtype)
     out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_blocks", A.data, d)
-    cm_data, cm_ind, cptr = A.chunk_major()
+    cm_data, cm_c8, cptr = A.chunk_major()
     blocks, wg_tab, max_nb = A.pair_blocks()
     if K2B_U8:
-        call(f"tm_sparse_sandwich_blocks_u8_{D.fsuf(A.data)}", D.p(cm_data), D.p(A.chunk_col8()), D.p(cptr), A.n, A.m,
+        call(f"tm_sparse_sandwich_blocks_u8_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_c8), D.p(cptr), A.n, A.m,
              int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
              D.p(out), D.stream_ptr())
         return out
+    cm_ind = A.chunk_cols32()
     call(f"tm_sparse_sandwich_blocks_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_ind), D.p(cptr), A.n, A.m,
          int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
          D.p(out), D.stream_ptr())

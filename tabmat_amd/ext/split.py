@@ -495,7 +495,7 @@ def multi_cat_sparse_sandwich_rows(cats, d, A, rows):
     res = D.out_buf((total, A.m), A.data.dtype)
     codes, ncols, drop, n = _cat_args(cats)
     D.same_float("multi_cat_sparse_sandwich_rows", A.data, d)
-    cm_data, cm_ind, ranges, r32, d_sel = xs._row_table(A, rows, d, False)
-    call(f"tm_multi_cat_sparse_sandwich_rows_{D.fsuf(A.data)}", codes, ncols, drop, n, D.p(cm_data),
-         D.p(cm_ind), D.p(ranges), D.p(r32), int(r32.numel()), A.m, D.p(d_sel), D.p(res), D.stream_ptr())
+    cm_data, cm_c8, ranges, r32, d_sel = xs._row_table(A, rows, d, False)
+    call(f"tm_multi_cat_sparse_sandwich_rows_u8_{D.fsuf(A.data)}", codes, ncols, drop, n, D.p(cm_data),
+         D.p(cm_c8), D.p(ranges), D.p(r32), int(r32.numel()), A.m, D.p(d_sel), D.p(res), D.stream_ptr())
     return res

@@ -187,6 +187,9 @@ class SparseMatrix(MatrixBase):
                 self._ell(wide=dense_width > 64)
         if ent is None:
             self._slab()       # (categorical x sparse runs on the entry twin when there is one)
+        # the twins are built: from here on the hot kernels read them, the 16-bit column twin (unrestricted matvec /
+        # transpose_matvec) or nothing of the CSR columns at all -- the int32 column array goes (ext/_types.py)
+        self._dev().compact_indices()
         return self
 
     @property

@@ -195,10 +195,25 @@ def test_chunk_major_twin_round_trip():
         assert c == 0 or cptr[c, 0] == cptr[c - 1, n]          # chunks follow each other
         for k in range(n):
             lo, hi = cptr[c, k], cptr[c, k + 1]
-            cols = ind[lo:hi]
-            assert np.all(cols // ch == c) and np.all(np.diff(cols) > 0)
+            assert ind.dtype == np.uint8            # round 6: the column INSIDE the chunk, one byte per entry
+            cols = c * ch + ind[lo:hi].astype(np.int64)
+            assert np.all(cols < m) and np.all(np.diff(cols) > 0)
             B[k, cols] += data[lo:hi]
     np.testing.assert_array_equal(B, A.toarray())
+    # the int32 block columns are rebuilt on request (A/B switch, record twins), not kept
+    c32 = csr.chunk_cols32().numpy()
+    assert c32.dtype == np.int32
+    for c in range(nch):
+        seg = slice(cptr[c, 0], cptr[c, n])
+        np.testing.assert_array_equal(c32[seg], c * ch + ind[seg].astype(np.int32))
+    # 16-bit CSR columns after compaction; `.indices` widens them again (shared scratch)
+    assert csr.compact_indices() and csr._ind32 is None
+    np.testing.assert_array_equal(csr.indices.numpy(), A.indices.astype(np.int32))
+    wide = CsrDev(torch.from_numpy(A.data), torch.from_numpy((A.indices.astype(np.int64) * 200).astype(np.int32)),
+                  torch.from_numpy(A.indptr.astype(np.int64)), n, m * 200)
+    wide.compact_indices()
+    np.testing.assert_array_equal(wide.indices.numpy(), (A.indices.astype(np.int64) * 200).astype(np.int32))
+    np.testing.assert_array_equal(csr.indices.numpy(), A.indices.astype(np.int32))     # (scratch changed hands)
 
 
 def test_slab_stream_round_trip():
@@ -458,7 +473,8 @@ def test_pair_block_list_covers_every_pair_once(seed, m, dens):
     A.sort_indices()
     csr = CsrDev(torch.from_numpy(A.data.copy()), torch.from_numpy(A.indices.astype(np.int32)),
                  torch.from_numpy(A.indptr.astype(np.int64)), n, m)
-    cm_data, cm_ind, cptr = csr.chunk_major()
+    cm_data, _, cptr = csr.chunk_major()
+    cm_ind = csr.chunk_cols32()           # block columns (the twin itself keeps one byte per entry)
     blocks, wg_tab, max_nb = csr.pair_blocks(n_wg=24)
     cm_data, cm_ind, blocks, wg_tab = cm_data.numpy(), cm_ind.numpy(), blocks.numpy(), wg_tab.numpy()
     assert (cptr.numpy()[:, 1:] - cptr.numpy()[:, :-1]).max() > 8
