@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, rows_mode="spread"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,6 +41,8 @@ def _worker(rank, world, port, q):
         d = rng.random(n)
         w = rng.standard_normal(n)
         rows_g = np.sort(rng.choice(n, 600, replace=False))
+        if rows_mode == "low":            # every selected row in the first three shards of eight: the others get none
+            rows_g = np.sort(rng.choice(3 * (n // 8), 200, replace=False))
         full = orc.split_sandwich(blocks, idx, d)
         full_rows = orc.split_sandwich(blocks, idx, d, rows_g)
         full_tmv = orc.split_transpose_matvec(blocks, idx, w)
@@ -105,3 +107,25 @@ def test_row_sharded_sandwich_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def test_row_sharded_sandwich_gloo_world8_uneven_rows_and_empty_row_lists():
+    """The shape of the 8-GPU job (BASELINE configs[4]) on CPU: eight ranks, n = 1001 rows (not divisible by 8:
+    one rank gets an extra row), and a `rows=` list that leaves five of the eight shards without a single selected
+    row -- their partial is all zeros and still takes part in the all-reduce (a rank that skipped the collective
+    would hang the job)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "low")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    bounds = sorted(b for _, _, b in res)
+    assert bounds[0][0] == 0 and bounds[-1][1] == 1001
+    assert sorted(h - l for l, h in bounds) == [125] * 7 + [126]

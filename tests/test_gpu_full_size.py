@@ -136,6 +136,37 @@ def test_cfg4_split_sandwich_10M():
     assert nat_err(sub.cpu().numpy(), ref) < 1e-10
 
 
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_cfg1_dense_f64_100k_x_64(order):
+    """BASELINE configs[0] at its exact workload (X = default_rng(0).standard_normal((100_000, 64)),
+    float64, d = rng.random(n)): DenseMatrix.sandwich against the oracle's restatement of the reference loop
+    (dense_helpers-tmpl.cpp:198-417; the reference's own test of this path is tests/test_fast_sandwich.py:51-98) at
+    FULL size -- the oracle needs milliseconds for it.  (64 columns are below the int8-sliced syrk's 65-column floor:
+    this block runs on the float64 MFMA syrk whatever set_strict_f64 says.)  Both memory orders, with and without
+    rows / cols; also the two matrix-vector products of the block."""
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(0)
+    n, k = 100_000, 64
+    X = rng.standard_normal((n, k))
+    d = rng.random(n)
+    Xo = np.asfortranarray(X) if order == "F" else X
+    dm = tm.DenseMatrix(Xo)
+    orc = _orc()
+    want = orc.dense_sandwich(X, d, None, None)
+    got = dm.sandwich(d)
+    assert got.dtype == np.float64 and got.shape == (k, k)
+    assert nat_err(got, want) < 1e-10 and rel_err(got, want) < 1e-10
+    rows = np.sort(rng.choice(n, 40_000, replace=False)).astype(np.int32)
+    cols = np.sort(rng.choice(k, 41, replace=False)).astype(np.int32)
+    for r, c in ((rows, None), (None, cols), (rows[:900], cols)):
+        w = orc.dense_sandwich(X, d, r, c)
+        assert nat_err(dm.sandwich(d, rows=r, cols=c), w) < 1e-10
+    v = rng.standard_normal(k)
+    assert rel_err(dm.matvec(v), X @ v) < 1e-12
+    assert rel_err(dm.transpose_matvec(d), X.T @ d) < 1e-12
+
+
 def test_cfg2_dense_f32_10M_x_256():
     """BASELINE configs[1]: DenseMatrix.sandwich float32, 10M x 256 (MFMA row-weighted syrk)."""
     from tabmat_amd import synth
