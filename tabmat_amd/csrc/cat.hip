@@ -1210,6 +1210,148 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
         dst[b] = (F)tile[(b / GC) * TSTR + (b % GC)];
 }
 
+// The same on the entry twin with the per-row operands STAGED (round 6).  The kernel above is bound
+// by its dependent loads: stream -> {d, codes} of the slot's row (no gathers at all 0.60 ms against 1.02,
+// profiles/r4_catsparse.txt).  A (group, slab) block only names rows of ITS 64-row slab, and a wave walks the slabs of
+// its range in order, so what a slot needs of its row is known without looking at the stream: the wave loads d and the
+// code word(s) of the slab's 64 rows lane <-> row (two coalesced loads), EN_CS_D slabs ahead together with the block's
+// stream, parks them in 768 bytes of per-wave LDS when the slab's turn comes, and every slot reads its row's pair from
+// there -- no load depends on another load.  One step of 64 slots per block (a block of more than 64 slots: further
+// steps straight from memory; 3 % of the blocks at BASELINE configs[3]).  PK: the packed code word of
+// tm_multi_cat_pack_codes (NC <= 3), else NC code words per row.
+#ifndef EN_CS_D
+#define EN_CS_D 4
+#endif
+template <typename F, int NC, bool PK>
+__global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
+    const unsigned *__restrict__ bstart, int n_groups, int64_t n, int64_t n_slabs, int64_t slabs_per_block,
+    F *__restrict__ ws, int64_t stride, const unsigned *__restrict__ packed, int tile_bytes) {
+    constexpr int GC = 32, TSTR = GC + 1;
+    constexpr int NCW = PK ? 1 : NC;                      // staged code words per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lds_acc_t *tile = reinterpret_cast<lds_acc_t *>(smem_raw);  // [total][33]
+    const int nel = cs.total * TSTR;
+    for (int b = threadIdx.x; b < nel; b += blockDim.x) tile[b] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwave = blockDim.x >> 6;
+    F *sd = reinterpret_cast<F *>(smem_raw + tile_bytes) + wave * 64;                                      // d of the slab's rows
+    int *sc = reinterpret_cast<int *>(smem_raw + tile_bytes + (size_t)nwave * 64 * sizeof(F)) + wave * 64 * NCW;
+    const int h = wave & 1;                               // which of the pair's two groups
+    const int g = 2 * blockIdx.y + h;
+    const int nwh = (nwave + 1 - h) / 2;                  // waves on this group
+    const int wi = wave >> 1;
+    const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
+    const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
+    if (g < n_groups && s1 > s0) {
+        const int64_t spw = (s1 - s0 + nwh - 1) / nwh;
+        const int64_t sa = min(s0 + (int64_t)wi * spw, s1), sb = min(sa + spw, s1);
+        const unsigned *brow = bstart + (int64_t)g * (n_slabs + 1);
+        // Every load of the walk is UNCONDITIONAL (clamped addresses, results masked afterwards): the compiler can only
+        // count its waits (s_waitcnt vmcnt(N) for the requests of EN_CS_D slabs ago, the newer ones stay in flight)
+        // over loads it knows were issued -- a first version with the loads behind `if (slot < slots of the block)`
+        // waited with vmcnt(0) in front of every slab, one memory round trip per slab: 1.27 ms against 0.94 for the
+        // gather kernel.  Three stages, EN_CS_D slabs apart: block bounds (two broadcast loads) -> stream + the rows'
+        // operands -> scatter.
+        struct Bnd { unsigned b0, b1; };
+        struct Pre { F v; unsigned m; F dd; int c[NCW]; unsigned b0; int nsl; };
+        // (the bounds through VECTOR loads at a lane-invariant address the compiler cannot see through: scalar loads
+        // share their counter with the LDS atomics, every use would wait for those too)
+        int vz = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+#endif
+        auto request_bounds = [&](int64_t s, Bnd &q) {
+            const int64_t sc_ = min(s, sb - 1) + vz;
+            q.b0 = brow[sc_];
+            q.b1 = brow[sc_ + 1];
+        };
+        auto request = [&](int64_t s, const Bnd &q, Pre &p) {
+            const bool live = s < sb;
+            const unsigned qb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b0);
+            const unsigned qb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b1);
+            p.b0 = qb0;
+            p.nsl = live ? (int)(qb1 - qb0) * 16 : 0;
+            const bool ok = lane < p.nsl;
+            const int64_t e = (int64_t)qb0 * 16 + (ok ? lane : 0);            // (slot b0 * 16 exists: slack behind the stream)
+            const F v = __builtin_nontemporal_load(vals + e);
+            p.m = __builtin_nontemporal_load(meta + e);
+            p.v = ok ? v : F(0);
+            const int64_t row_ = min(s, sb - 1) * 64 + lane;
+            const int64_t row = min(row_, n - 1);              // (ragged last slab: no slot names a row beyond n - 1)
+            p.dd = d[row];
+            if constexpr (PK) {
+                p.c[0] = (int)packed[row];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) p.c[c] = cs.codes[c][row] - cs.drop[c];
+            }
+        };
+        auto process = [&](Pre &p) {
+            if (p.nsl == 0) return;
+            sd[lane] = p.dd;
+#pragma unroll
+            for (int c = 0; c < NCW; ++c) sc[c * 64 + lane] = p.c[c];
+            __builtin_amdgcn_wave_barrier();
+            F v = p.v;
+            unsigned m = p.m;
+            for (int off = 0; off < p.nsl; off += 64) {
+                if (off > 0) {                 // a block of more than 64 slots: the rest straight from memory
+                    const bool ok = off + lane < p.nsl;
+                    const int64_t e = (int64_t)p.b0 * 16 + off + (ok ? lane : 0);
+                    v = ok ? vals[e] : F(0);
+                    m = meta[e];
+                }
+                const int r6 = (int)((m >> 4) & 63u);
+                const int col = 16 * h + (int)(m & 15u);
+                const F dk = sd[r6];
+                // rows masked out by d == 0 (and padding slots: value 0) contribute exactly nothing
+                const F x = (dk != F(0) && v != F(0)) ? dk * v : F(0);
+                if (x != F(0)) {
+                    if constexpr (PK) {
+                        const unsigned pk = (unsigned)sc[r6];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const int f = (int)((pk >> (10 * c)) & 1023u);
+                            if (f != 1023) atomic_add(&tile[f * TSTR + col], (lds_acc_t)x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const int cc = sc[c * 64 + r6];
+                            if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * TSTR + col], (lds_acc_t)x);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        constexpr int DEPTH = EN_CS_D;             // slabs in flight per wave and stage
+        Pre p[DEPTH];
+        Bnd q[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) request_bounds(sa + j, q[j]);
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            request(sa + j, q[j], p[j]);
+            request_bounds(sa + DEPTH + j, q[j]);
+        }
+        for (int64_t s = sa; s < sb; s += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                process(p[j]);
+                request(s + DEPTH + j, q[j], p[j]);
+                request_bounds(s + 2 * DEPTH + j, q[j]);
+            }
+        }
+    }
+    __syncthreads();
+    F *dst = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    for (int b = threadIdx.x; b < cs.total * GC; b += blockDim.x)
+        dst[b] = (F)tile[(b / GC) * TSTR + (b % GC)];
+}
+
 // Row-list form of the fused categorical x sparse cross terms (the reference's cost for `rows=` is
 // proportional to len(rows): categorical_matrix.py:825-838 works on self[rows]): the selected rows'
 // entry lists come from the chunk-major twin through a {start, end} table [chunk][selected row]
@@ -1573,15 +1715,46 @@ static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h
                 : n_cats == 6 ? &multi_cat_sparse_ent_kernel<F, 6>
                 : n_cats == 7 ? &multi_cat_sparse_ent_kernel<F, 7>
                               : &multi_cat_sparse_ent_kernel<F, 8>;
-    if (lds > 48 * 1024)
-        TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    prof_begin(st);
     TM_REQUIRE(packed == nullptr || (n_cats <= 3 && cs.total < 1023), "packed codes: at most 3 categoricals, 1022 levels");
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds, st, cs, d, vals, meta,
-                       bstart, n_groups, n_slabs, spb, ws, stride, packed);
-    prof_end(st);
-    TM_LAUNCH_CHECK();
+    // staged form (round 6): d and the code word(s) of a slab's rows parked in per-wave LDS next to the tile
+    const int ncw = packed != nullptr ? 1 : n_cats;
+    const size_t lds_staged = lds + (size_t)nw * 64 * (sizeof(F) + 4 * (size_t)ncw);
+    if (tune("catsparse_staged", 1) != 0 && lds_staged <= 156 * 1024) {
+        using KS = void (*)(CatSet, const F *, const F *, const unsigned *, const unsigned *, int, int64_t, int64_t,
+                            int64_t, F *, int64_t, const unsigned *, int);
+        KS ks = nullptr;
+        if (packed != nullptr) {
+            ks = n_cats == 1 ? &multi_cat_sparse_ent_staged_kernel<F, 1, true>
+                 : n_cats == 2 ? &multi_cat_sparse_ent_staged_kernel<F, 2, true>
+                               : &multi_cat_sparse_ent_staged_kernel<F, 3, true>;
+        } else {
+            ks = n_cats == 1   ? &multi_cat_sparse_ent_staged_kernel<F, 1, false>
+                 : n_cats == 2 ? &multi_cat_sparse_ent_staged_kernel<F, 2, false>
+                 : n_cats == 3 ? &multi_cat_sparse_ent_staged_kernel<F, 3, false>
+                 : n_cats == 4 ? &multi_cat_sparse_ent_staged_kernel<F, 4, false>
+                 : n_cats == 5 ? &multi_cat_sparse_ent_staged_kernel<F, 5, false>
+                 : n_cats == 6 ? &multi_cat_sparse_ent_staged_kernel<F, 6, false>
+                 : n_cats == 7 ? &multi_cat_sparse_ent_staged_kernel<F, 7, false>
+                               : &multi_cat_sparse_ent_staged_kernel<F, 8, false>;
+        }
+        if (lds_staged > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ks),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        prof_begin(st);
+        hipLaunchKernelGGL(ks, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds_staged, st, cs, d, vals,
+                           meta, bstart, n_groups, n, n_slabs, spb, ws, stride, packed, (int)lds);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+    } else {
+        if (lds > 48 * 1024)
+            TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_begin(st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds, st, cs, d, vals, meta,
+                           bstart, n_groups, n_slabs, spb, ws, stride, packed);
+        prof_end(st);
+        TM_LAUNCH_CHECK();
+    }
     rc = launch_reduce_partials<F>(ws, stride, (int)nblk, n_pairs, tmp, (int64_t)n_pairs * stride, false, st);
     if (rc) return rc;
     // tmp [pair][total][32] -> out[total][mk]

@@ -51,14 +51,14 @@ class DenseDev:
 # Column indices of the CSR twin: int32 as uploaded, or -- once to_device() has built the twins (compact_indices) and
 # the block has at most 65 536 columns -- ONLY the 16-bit copy the unrestricted matvec / transpose_matvec kernels
 # stream (1.0 GB less at BASELINE configs[3]).  The generic / restricted entry points and the twin
-# builders read `.indices`, which then widens into ONE library-wide scratch tensor (the latest widening of any block;
-# released by the next one or by release_index_scratch()).
+# builders read `.indices`, which then widens into a library-wide scratch tensor (the two most recent widenings are
+# kept; released by later ones or by release_index_scratch()).
 COMPACT_CSR_INDICES = os.environ.get("TABMAT_AMD_COMPACT_CSR", "1") != "0"
-_WIDE = {"owner": None, "tensor": None}
+_WIDE = []          # [(weak reference to the owner CsrDev, int32 tensor)], most recent last; at most two (a call may name two blocks)
 
 
 def release_index_scratch() -> None:
-    _WIDE["owner"] = _WIDE["tensor"] = None
+    del _WIDE[:]
 
 
 class CsrDev:
@@ -82,11 +82,18 @@ class CsrDev:
         """int32 column indices (widened from the 16-bit twin into the shared scratch once compacted)."""
         if self._ind32 is not None:
             return self._ind32
-        if _WIDE["owner"] is not self or _WIDE["tensor"] is None:
-            _WIDE["owner"] = _WIDE["tensor"] = None           # (free the previous block's scratch first)
-            _WIDE["tensor"] = self._ind16.to(torch.int32).bitwise_and_(0xFFFF)
-            _WIDE["owner"] = self
-        return _WIDE["tensor"]
+        import weakref
+
+        _WIDE[:] = [(o, t) for o, t in _WIDE if o() is not None]      # (scratch of blocks that are gone)
+        for k, (owner, t) in enumerate(_WIDE):
+            if owner() is self:
+                _WIDE.append(_WIDE.pop(k))
+                return t
+        while len(_WIDE) >= 2:
+            _WIDE.pop(0)                                       # (free the oldest scratch before allocating)
+        t = self._ind16.to(torch.int32).bitwise_and_(0xFFFF)
+        _WIDE.append((weakref.ref(self), t))
+        return t
 
     def indices16(self):
         """uint16 twin of the column indices (bit pattern in an int16 tensor) for the unrestricted matvec /

@@ -312,19 +312,38 @@ def test_deterministic_mode_builds_its_own_twin_for_a_very_sparse_block(monkeypa
         sm.sandwich(d)
 
 
+@pytest.fixture
+def _catsparse_kernel(request):
+    """Both kernels behind tm_multi_cat_sparse_sandwich_ent*: "staged" (round 6: d and the code words of a slab's rows
+    parked in per-wave LDS; the default wherever the LDS holds tile + staging) and "gather" (round 4 / 5: per-slot
+    gathers; the fallback)."""
+    from tabmat_amd import _lib
+
+    _lib.call("tm_tune_set", b"catsparse_staged", 1 if request.param == "staged" else 0)
+    yield request.param
+    _lib.call("tm_tune_set", b"catsparse_staged", 1)
+
+
 @gpu
+@pytest.mark.parametrize("_catsparse_kernel", ["staged", "gather"], indirect=True)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,levels", [(9000, 100, (7, 5)), (20_011, 512, (256, 96, 32)), (70, 16, (3,)),
-                                        (30_000, 40, (40, 30, 20, 10, 5, 4, 3, 2))])
-def test_cat_sparse_cross_terms_on_the_entry_twin(n, m, levels, dtype):
+                                        (30_000, 40, (40, 30, 20, 10, 5, 4, 3, 2)), (64 * 300 + 1, 48, (11, 6, 2))])
+def test_cat_sparse_cross_terms_on_the_entry_twin(n, m, levels, dtype, _catsparse_kernel):
     """tm_multi_cat_sparse_sandwich_ent_*: all categorical x sparse blocks of a SplitMatrix from one pass over the
     entry twin, against the oracle's sandwich_cat_sparse (the reference: scipy.sparse product,
-    categorical_matrix.py:825-838); drop_first, missing codes, zero weights."""
+    categorical_matrix.py:825-838); drop_first, missing codes, zero weights; a last slab of ONE row; dense columns
+    whose blocks hold more than 64 slots (the staged kernel's second step)."""
     from oracle import oracle as orc
     from tabmat_amd.ext import split as xsplit
 
     rng = np.random.default_rng(n + m)
     S = sps.random(n, m, density=0.06, format="csr", random_state=rng, dtype=np.float64)
+    if m >= 40:              # five nearly full columns: their groups' blocks hold well over 64 slots per slab
+        extra = sps.random(n, m, density=1.0, format="csr", random_state=rng, dtype=np.float64).multiply(
+            sps.csr_matrix(np.isin(np.arange(m), [1, 2, 17, 18, 33]).astype(np.float64))).tocsr()
+        keep = sps.csr_matrix((rng.random(n) < 0.85).astype(np.float64)[:, None])
+        S = (S + extra.multiply(keep)).tocsr()
     S.data = rng.standard_normal(S.data.shape[0])
     S = S.astype(dtype)
     S.sort_indices()
