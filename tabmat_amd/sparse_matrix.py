@@ -189,7 +189,9 @@ class SparseMatrix(MatrixBase):
             self._slab()       # (categorical x sparse runs on the entry twin when there is one)
         # the twins are built: from here on the hot kernels read them, the 16-bit column twin (unrestricted matvec /
         # transpose_matvec) or nothing of the CSR columns at all -- the int32 column array goes (ext/_types.py)
-        self._dev().compact_indices()
+        # (only where the unrestricted matvec kernels stream the 16-bit twin anyway: large blocks, TABMAT_AMD_CSR_U16)
+        if xs.CSR_U16 and int(self._dev().data.numel()) >= xs.CSR_U16_MIN_NNZ:
+            self._dev().compact_indices()
         return self
 
     @property
