@@ -204,6 +204,24 @@ class CategoricalMatrix(MatrixBase):
     def toarray(self) -> np.ndarray:
         return self.tocsr().toarray()
 
+    @property
+    def cat(self):
+        """The data as a pandas.Categorical (categorical_matrix.py:434-449; deprecated there, kept for callers that
+        still unpack it)."""
+        import warnings
+
+        warnings.warn("This property will be removed in the next major release.", category=DeprecationWarning)
+        try:
+            import pandas as pd
+        except ImportError as e:          # pragma: no cover
+            raise ModuleNotFoundError("The `cat` property is provided for backward compatibility and "
+                                      "requires pandas to be installed.") from e
+        return pd.Categorical.from_codes(self.indices, categories=self.categories)
+
+    def unpack(self):
+        """categorical_matrix.py:719-721."""
+        return self.cat
+
     def astype(self, dtype, order="K", casting="unsafe", copy=True):
         """categorical_matrix.py:723-726: only the nominal dtype changes."""
         self.dtype = np.dtype(dtype)

@@ -292,6 +292,40 @@ class StandardizedMatrix:
     def astype(self, dtype, order="K", casting="unsafe", copy=True):
         return type(self)(self.mat.astype(dtype, casting=casting, copy=copy), self.shift, self.mult)
 
+    def multiply(self, other):
+        """Element-wise multiplication with a vector of length n (standardized_mat.py:255-262): always a
+        DenseMatrix, as in the reference (host-side convenience, not a hot-path product)."""
+        from .dense_matrix import DenseMatrix
+
+        return DenseMatrix(self.toarray()).multiply(other)
+
+    def __repr__(self):
+        return (f"StandardizedMat. Mat: {type(self.mat)} of shape {self.mat.shape}.\n"
+                f"        Shift: {self.shift}\n        Mult: {self.mult}\n        ")
+
+    # ---- names: those of the wrapped matrix (standardized_mat.py:311-378)
+    def get_names(self, type="column", missing_prefix=None, indices=None):
+        return self.mat.get_names(type, missing_prefix, indices)
+
+    def set_names(self, names, type="column"):
+        self.mat.set_names(names, type)
+
+    @property
+    def column_names(self):
+        return self.get_names(type="column")
+
+    @column_names.setter
+    def column_names(self, names):
+        self.set_names(names, type="column")
+
+    @property
+    def term_names(self):
+        return self.get_names(type="term")
+
+    @term_names.setter
+    def term_names(self, names):
+        self.set_names(names, type="term")
+
     def __getitem__(self, item):
         if isinstance(item, tuple):
             row, col = item

@@ -542,3 +542,49 @@ def test_pairs_cost_model_picks_the_regimes_it_was_measured_in():
     assert xs.pairs_sandwich_pays(Fake(40_000, 10_000, 0.01))
     assert not xs.pairs_sandwich_pays(Fake(400_000, 10_000, 0.001))
     assert not xs.pairs_sandwich_pays(Fake(40_000, 20_000, 0.01))          # beyond 128 column chunks
+
+
+def test_api_members_of_the_reference_classes_exist():
+    """Every public method / property the reference's six classes define (matrix_base.py, dense_matrix.py,
+    sparse_matrix.py, categorical_matrix.py, split_matrix.py, standardized_mat.py) exists here under the same name --
+    the list below was taken from the reference's class bodies; the hot-path ones are tested against the oracle
+    elsewhere, this pins the drop-in surface (round 6 added StandardizedMatrix.multiply / names / __repr__ and
+    CategoricalMatrix.cat / unpack)."""
+    import tabmat_amd as tm
+
+    common = ["matvec", "transpose_matvec", "sandwich", "standardize", "toarray", "astype", "getcol", "multiply",
+              "get_names", "set_names", "column_names", "term_names", "A", "__matmul__", "__rmatmul__",
+              "_get_col_means", "_get_col_stds"]
+    for cls in (tm.DenseMatrix, tm.SparseMatrix, tm.CategoricalMatrix, tm.SplitMatrix):
+        for name in common + ([] if cls is tm.SplitMatrix else ["_cross_sandwich"]):    # (split_matrix.py has none)
+            assert hasattr(cls, name), (cls.__name__, name)
+    for name in ("recover_orig", "tocsr", "to_sparse_matrix", "cat", "unpack", "drop_first", "categories"):
+        assert hasattr(tm.CategoricalMatrix, name) or name in ("drop_first", "categories"), name
+    for name in ("matvec", "transpose_matvec", "sandwich", "unstandardize", "getcol", "toarray", "A", "astype",
+                 "multiply", "get_names", "set_names", "column_names", "term_names", "__getitem__", "__matmul__",
+                 "__rmatmul__", "__repr__"):
+        assert hasattr(tm.StandardizedMatrix, name), name
+
+
+def test_standardized_names_multiply_and_categorical_unpack_on_the_host():
+    import warnings
+
+    import tabmat_amd as tm
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((7, 3))
+    dm = tm.DenseMatrix(X, column_names=["a", "b", "c"])
+    shift, mult = rng.standard_normal(3), rng.random(3) + 0.5
+    S = tm.StandardizedMatrix(dm, shift, mult)
+    assert S.column_names == ["a", "b", "c"] and S.get_names("term") == dm.get_names("term")
+    S.column_names = ["x", "y", "z"]
+    assert dm.column_names == ["x", "y", "z"]
+    w = rng.random(7)
+    np.testing.assert_allclose(S.multiply(w).toarray(), (X * mult + shift) * w[:, None])
+    assert "StandardizedMat" in repr(S)
+    codes = np.array([2, 0, 1, 1, 2])
+    cm = tm.CategoricalMatrix(codes, categories=np.array(["u", "v", "w"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        cat = cm.unpack()
+    assert list(cat) == ["w", "u", "v", "v", "w"]
