@@ -42,7 +42,7 @@ def csr_dense_sandwich(A: CsrDev, B: DenseDev, d, rows, A_cols, B_cols):
 
 
 CSR_U16 = os.environ.get("TABMAT_AMD_CSR_U16", "1") == "1"   # 16-bit column twin for the unrestricted matvec kernels
-CSR_U16_MIN_NNZ = 1_000_000
+CSR_U16_MIN_NNZ = int(os.environ.get("TABMAT_AMD_CSR_U16_MIN_NNZ", "1000000"))   # (0: every block, for tests)
 
 
 def _u16_ok(X: CsrDev, lds_bytes) -> bool:
