@@ -16,3 +16,10 @@ free, total = torch.cuda.mem_get_info()
 print(f"{n} rows: sandwich {ms:.1f} ms = {13.52e9 * n / 10e6 / ms / 1e6:.0f} GB/s effective; HBM in use {(total - free) / 1e9:.0f} GB")
 S = X._sandwich_dev(d, None, None)
 print("symmetric:", bool(torch.allclose(S, S.T, rtol=1e-12, atol=0)), " finite:", bool(torch.isfinite(S).all()))
+# round 6: ingest time / resident bytes at this size, and S u = X' (d * (X u)) from independent kernels
+torch.cuda.empty_cache()
+print(f"resident (live allocations) {torch.cuda.memory_allocated() / 1e9:.1f} GB for {13.51 * n / 10e6:.1f} GB of data")
+u = torch.randn(X.shape[1], dtype=torch.float64, device="cuda")
+lhs = S @ u
+rhs = X.transpose_matvec(d * X.matvec(u))
+print(f"|S u - X'(d * X u)| / |S u| = {float((lhs - rhs).abs().max() / lhs.abs().max()):.2e}")
