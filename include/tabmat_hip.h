@@ -297,6 +297,17 @@ int tm_sparse_sandwich_blocks_u8_f64(const double *cm_data, const uint8_t *cm_co
                                      int64_t n, int64_t m, int64_t nnz, const int32_t *blocks,
                                      const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
                                      void *stream);
+/* Byte columns AND 12-byte block descriptors (round 6): blocks12 [B][3] = {first A entry, first B entry,
+ * row | (nA - 1) << 24 | (nB - 1) << 27 | short-A flag << 30 | short-B flag << 31}; blocks of fewer than 2^24 rows.
+ * Same kernel, a quarter less descriptor storage (the reference loop: ext/sparse.pyx:55-74). */
+int tm_sparse_sandwich_blocks_p12_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                      int64_t n, int64_t m, int64_t nnz, const int32_t *blocks12,
+                                      const int32_t *wg_tab, int n_wg, int max_nb, const float *d, float *out,
+                                      void *stream);
+int tm_sparse_sandwich_blocks_p12_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                      int64_t n, int64_t m, int64_t nnz, const int32_t *blocks12,
+                                      const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
+                                      void *stream);
 
 /* out[nA x nB] = A[rows,A_cols]^T diag(d) B[rows,B_cols]; A sparse (CSR, n x m), B dense (n x r).
  * Replaces _csr_dense{C,F}_sandwich (ext/sparse_helpers-tmpl.cpp:23-146) as bound by

@@ -52,10 +52,13 @@ constexpr int KB_FLAG_REP_B = 1 << 17;     // lane t takes B entry t & 3
 
 // U8: `ind` points at BYTES, the column of an entry inside its 128-column chunk (a quarter of the index bytes the
 // entry gathers move).
-template <typename F, bool U8>
+// D12 (round 6): 12-byte descriptors {first A entry, first B entry, row | nA - 1 << 24 | nB - 1 << 27 | flags << 30}
+// for blocks of fewer than 2^24 rows (0.56 GB less at BASELINE configs[3]; the descriptors are read coalesced and
+// once: same time as the 16-byte form, profiles/r5_k2b.txt).
+template <typename F, bool U8, bool D12 = false>
 __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
     const F *__restrict__ data, const int32_t *__restrict__ ind, const int32_t *__restrict__ cptr,
-    int64_t n, int64_t nnz1, const int4 *__restrict__ blocks, const int4 *__restrict__ wg_tab,
+    int64_t n, int64_t nnz1, const int32_t *__restrict__ blocks, const int4 *__restrict__ wg_tab,
     const F *__restrict__ d, int max_nb, F *__restrict__ ws, WgLogBuf *__restrict__ wglog) {
     constexpr int TS = KB_TS;
     const unsigned long long t_begin = wg_log_begin(wglog);
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
             constexpr int offmask = DIAG ? 0 : 0x70000000;
             const int nseg = s1 - s0;
             if (nseg <= 0) return;
-            const int4 *blk = blocks + s0;
+            constexpr int DW = D12 ? 3 : 4;                 // words per descriptor
+            const int32_t *blk = blocks + (int64_t)s0 * DW;
             struct Dsc { int4 q; bool valid; };
             struct Grp { int nA, nB, ta, tb; F d, va, vb; int ca, cb; };
             auto load_desc = [&](int g) {
@@ -138,7 +142,15 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
                 const int k = g + lr;
                 r.valid = k < nseg;
                 const unsigned kc = (unsigned)min(k, nseg - 1);
-                r.q = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(blk) + (kc << 4));
+                if constexpr (D12) {
+                    const int32_t *b = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(blk) + kc * 12u);
+                    const int x = b[0], y = b[1];
+                    const unsigned w = (unsigned)b[2];
+                    r.q = int4{x, y, (int)(w & 0xffffffu),
+                               (int)((((w >> 24) & 7u) + 1u) | ((((w >> 27) & 7u) + 1u) << 8) | (((w >> 30) & 3u) << 16))};
+                } else {
+                    r.q = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(blk) + (kc << 4));
+                }
                 return r;
             };
             auto load_entries = [&](const Dsc &sd) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(KB_WAVES * 64) void sparse_sandwich_blocks_kernel(
     }
 }
 
-template <typename F, bool U8 = false>
+template <typename F, bool U8 = false, bool D12 = false>
 static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const int32_t *cptr, int64_t n,
                                       int64_t m, int64_t nnz, const int32_t *blocks, const int32_t *wg_tab,
                                       int n_wg, int max_nb, const F *d, F *out, hipStream_t st) {
@@ -250,6 +262,7 @@ static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const i
     const int nchunk = (int)ceil_div(m, TS);
     const int n_parts = nchunk * (nchunk + 1) / 2;
     TM_REQUIRE(nnz < (1ll << 31) && n < (1ll << 29), "sparse block too large for the block-list sandwich");
+    TM_REQUIRE(!D12 || n < (1ll << 24), "12-byte block descriptors hold 24 bits of row");
     TM_REQUIRE(max_nb >= 1 && n_wg >= 1, "empty workgroup table");
     const size_t lds = sizeof(lds_acc_t) * (size_t)(TS * TS);
     const size_t tmp_bytes = (sizeof(F) * (size_t)n_parts * TS * TS + 255) / 256 * 256;
@@ -261,14 +274,14 @@ static int run_sparse_sandwich_blocks(const F *data, const int32_t *ind, const i
     F *ws = reinterpret_cast<F *>(reinterpret_cast<char *>(wsv) + tmp_bytes);
     // tiles have different numbers of workgroups: unused partial slots must read as 0
     TM_HIP(hipMemsetAsync(ws, 0, ws_bytes, st));
-    auto kern = &sparse_sandwich_blocks_kernel<F, U8>;
+    auto kern = &sparse_sandwich_blocks_kernel<F, U8, D12>;
     TM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     prof_begin(st);
     // (the wave split of the table -- wg_tab[5] = waves on the FULL list -- is built for this many waves)
     const int kb_waves = (int)std::min<int64_t>(KB_WAVES, std::max<int64_t>(2, tune("k2b_waves", KB_WAVES)));
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(kb_waves * 64), lds, st, data, ind, cptr, n, nnz - 1,
-                       reinterpret_cast<const int4 *>(blocks), reinterpret_cast<const int4 *>(wg_tab), d,
+                       blocks, reinterpret_cast<const int4 *>(wg_tab), d,
                        max_nb, ws, wg_log_ptr());
     prof_end(st);
     TM_LAUNCH_CHECK();
@@ -316,6 +329,24 @@ int tm_sparse_sandwich_blocks_u8_f64(const double *cm_data, const uint8_t *cm_co
     return tmh::run_sparse_sandwich_blocks<double, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr, n, m,
                                                          nnz, blocks, wg_tab, n_wg, max_nb, d, out,
                                                          tmh::as_stream(stream));
+}
+
+// byte columns AND 12-byte descriptors (blocks: int32 [B][3], see the kernel; n < 2^24)
+int tm_sparse_sandwich_blocks_p12_f32(const float *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                      int64_t n, int64_t m, int64_t nnz, const int32_t *blocks12,
+                                      const int32_t *wg_tab, int n_wg, int max_nb, const float *d, float *out,
+                                      void *stream) {
+    return tmh::run_sparse_sandwich_blocks<float, true, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr,
+                                                              n, m, nnz, blocks12, wg_tab, n_wg, max_nb, d, out,
+                                                              tmh::as_stream(stream));
+}
+int tm_sparse_sandwich_blocks_p12_f64(const double *cm_data, const uint8_t *cm_col8, const int32_t *cptr,
+                                      int64_t n, int64_t m, int64_t nnz, const int32_t *blocks12,
+                                      const int32_t *wg_tab, int n_wg, int max_nb, const double *d, double *out,
+                                      void *stream) {
+    return tmh::run_sparse_sandwich_blocks<double, true, true>(cm_data, reinterpret_cast<const int32_t *>(cm_col8), cptr,
+                                                               n, m, nnz, blocks12, wg_tab, n_wg, max_nb, d, out,
+                                                               tmh::as_stream(stream));
 }
 
 }  // extern "C"

@@ -54,6 +54,8 @@ class DenseDev:
 # builders read `.indices`, which then widens into a library-wide scratch tensor (the two most recent widenings are
 # kept; released by later ones or by release_index_scratch()).
 COMPACT_CSR_INDICES = os.environ.get("TABMAT_AMD_COMPACT_CSR", "1") != "0"
+# K2b's static block list with 12-byte descriptors (blocks of fewer than 2^24 rows; tm_sparse_sandwich_blocks_p12_*)
+K2B_DESC12 = os.environ.get("TABMAT_AMD_K2B_DESC12", "1") != "0"
 _WIDE = []          # [(weak reference to the owner CsrDev, int32 tensor)], most recent last; at most two (a call may name two blocks)
 
 
@@ -260,8 +262,8 @@ class CsrDev:
             self._cm_rec_pk = cr
         return cr
 
-    def pair_blocks(self, n_wg: int = 0, nw: int = 16, cyclic=None):
-        """(blocks int32 [B, 4], wg_tab int32 [W, 8], max_nb): the static block list of
+    def pair_blocks(self, n_wg: int = 0, nw: int = 16, cyclic=None, d12=None):
+        """(blocks int32 [B, 4] -- or [B, 3]: 12-byte descriptors, see K2B_DESC12 --, wg_tab int32 [W, 8], max_nb): the static block list of
         tm_sparse_sandwich_blocks_* -- every (row, tile) of the chunk-major twin cut into blocks of
         at most 8 x 8 entries {first A entry, first B entry, row, nA | nB << 8 | flags}, tile after
         tile (part = I (I + 1) / 2 + J); the blocks of a tile are dealt to its workgroups by row range (`cyclic`
@@ -271,7 +273,11 @@ class CsrDev:
         bits 16 / 17: the A / B side is the short one next to a long side, see csrc/sparse_blocks.hip).
         wg_tab row: {part, slot, first block, end, end of the FULL blocks, waves on the FULL list,
         first row, last row}.  Depends on the sparsity pattern only: built once, cached."""
-        pb = getattr(self, "_pb", None)
+        d12 = bool((K2B_DESC12 if d12 is None else d12) and self.n < 2**24)   # 12-byte descriptors: 24 bits of row
+        cache = self.__dict__.get("_pb")
+        if not isinstance(cache, dict):                      # (tests reset the cache with `_pb = None`)
+            cache = self.__dict__["_pb"] = {}
+        pb = cache.get(d12)
         if pb is None:
             _, _, cptr = self.chunk_major()
             nch, n = int(cptr.shape[0]), self.n
@@ -343,8 +349,16 @@ class CsrDev:
                     nb = torch.clamp(cnt[J][row] - 8 * b, max=8)
                     full = (na > 4) & (nb > 4)
                     flags = torch.where((na <= 4) & (nb > 4), 1 << 16, 0) | torch.where((na > 4) & (nb <= 4), 1 << 17, 0)
-                    desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
-                                        row, na | (nb << 8) | flags], dim=1).to(torch.int32)
+                    if d12:
+                        # {first A entry, first B entry, row | nA - 1 << 24 | nB - 1 << 27 | flags << 30}: 12 bytes
+                        word = row | ((na - 1) << 24) | ((nb - 1) << 27) | ((flags >> 16) << 30)
+                        word = torch.where(word >= 2**31, word - 2**32, word)
+                        desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
+                                            word], dim=1).to(torch.int32)
+                        del word
+                    else:
+                        desc = torch.stack([cptr[I][row].to(torch.int64) + 8 * a, cptr[J][row].to(torch.int64) + 8 * b,
+                                            row, na | (nb << 8) | flags], dim=1).to(torch.int32)
                     nb_p = max(1, nbp[part])
                     if cyclic:
                         # row ranges of `cyclic` rows dealt round-robin: every workgroup of every tile sweeps the
@@ -367,7 +381,7 @@ class CsrDev:
                     seg_end = torch.cumsum(cnts.reshape(-1), 0)
                     seg_lo = (seg_end - cnts.reshape(-1)).clamp_(max=c - 1)
                     seg_hi = (seg_end - 1).clamp_(min=0)
-                    srow = desc[:, 2].to(torch.int64)
+                    srow = row[order]
                     big = torch.iinfo(torch.int64).max
                     some = cnts > 0
                     rows_h = torch.where(some, srow[seg_lo].view(nb_p, 2), big).amin(dim=1).cpu().numpy()
@@ -393,11 +407,23 @@ class CsrDev:
                 # round is one sweep over the rows by all tiles at once
                 rounds = max(1, -(-n_wg // 256))
                 tab.sort(key=lambda t: (t[1] % rounds, t[0], t[1]))
-            blocks = torch.cat(descs).contiguous() if descs else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            blocks = torch.cat(descs).contiguous() if descs else \
+                torch.zeros((0, 3 if d12 else 4), dtype=torch.int32, device=dev)
             del descs
             wg_tab = torch.tensor(tab, dtype=torch.int32, device=dev).reshape(-1, 8).contiguous()
-            pb = self._pb = (blocks, wg_tab, max_nb)
+            pb = cache[d12] = (blocks, wg_tab, max_nb)
         return pb
+
+    @staticmethod
+    def unpack_blocks(blocks: torch.Tensor) -> torch.Tensor:
+        """The block list in its 16-byte form {first A entry, first B entry, row, nA | nB << 8 | flags} whichever form
+        `pair_blocks` built (tests, inspection)."""
+        if int(blocks.shape[1]) == 4:
+            return blocks
+        w = blocks[:, 2].to(torch.int64) & 0xFFFFFFFF
+        meta = (((w >> 24) & 7) + 1) | ((((w >> 27) & 7) + 1) << 8) | (((w >> 30) & 3) << 16)
+        return torch.stack([blocks[:, 0].to(torch.int64), blocks[:, 1].to(torch.int64), w & 0xFFFFFF, meta],
+                           dim=1).to(torch.int32)
 
     def csc_blocks(self):
         """(rows int32, vals, bstart int64, n_blocks, col_bptr int64): the CSC form of the block with

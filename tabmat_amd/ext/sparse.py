@@ -277,7 +277,7 @@ def blocks_sandwich_pays(A: CsrDev) -> bool:
     if not (0 < nnz < 2**31) or nnz / (A.n * nch) <= 4.5 or nch > 32:
         return False
     est = 16 * 2 * A.n * nch * (nch + 1) // 2          # bytes, generous
-    return est * 3 < torch.cuda.mem_get_info(A.data.device)[0] or getattr(A, "_pb", None) is not None
+    return est * 3 < torch.cuda.mem_get_info(A.data.device)[0] or bool(getattr(A, "_pb", None))
 
 
 K2B_U8 = os.environ.get("TABMAT_AMD_K2B_U8", "1") == "1"     # byte columns for the block-list kernel's gathers
@@ -290,7 +290,12 @@ def sparse_sandwich_blocks(A: CsrDev, d):
     out = D.out_buf((A.m, A.m), A.dtype)
     D.same_float("sparse_sandwich_blocks", A.data, d)
     cm_data, cm_c8, cptr = A.chunk_major()
-    blocks, wg_tab, max_nb = A.pair_blocks()
+    blocks, wg_tab, max_nb = A.pair_blocks(d12=None if K2B_U8 else False)     # (int32 columns: 16-byte list only)
+    if int(blocks.shape[1]) == 3:            # 12-byte descriptors (always with byte columns)
+        call(f"tm_sparse_sandwich_blocks_p12_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_c8), D.p(cptr), A.n, A.m,
+             int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),
+             D.p(out), D.stream_ptr())
+        return out
     if K2B_U8:
         call(f"tm_sparse_sandwich_blocks_u8_{D.fsuf(A.data)}", D.p(cm_data), D.p(cm_c8), D.p(cptr), A.n, A.m,
              int(cm_data.numel()), D.p(blocks), D.p(wg_tab), int(wg_tab.shape[0]), int(max_nb), D.p(d),

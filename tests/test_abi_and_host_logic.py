@@ -459,8 +459,9 @@ def test_tuning_knobs_round_trip():
     assert v.value == 12
 
 
+@pytest.mark.parametrize("d12", [True, False])
 @pytest.mark.parametrize("seed,m,dens", [(0, 128, 0.1), (1, 300, 0.12), (2, 513, 0.06), (3, 40, 0.9)])
-def test_pair_block_list_covers_every_pair_once(seed, m, dens):
+def test_pair_block_list_covers_every_pair_once(seed, m, dens, d12):
     """CsrDev.pair_blocks (the static block list of tm_sparse_sandwich_blocks_*): replaying the list
     with the kernel's rules (8 x 8 blocks, b <= a triangle on diagonal tiles by COLUMN order, mirror)
     must give A' diag(d) A exactly once per pair -- rows with more than 8 and more than 16 entries
@@ -475,7 +476,9 @@ def test_pair_block_list_covers_every_pair_once(seed, m, dens):
                  torch.from_numpy(A.indptr.astype(np.int64)), n, m)
     cm_data, _, cptr = csr.chunk_major()
     cm_ind = csr.chunk_cols32()           # block columns (the twin itself keeps one byte per entry)
-    blocks, wg_tab, max_nb = csr.pair_blocks(n_wg=24)
+    blocks, wg_tab, max_nb = csr.pair_blocks(n_wg=24, d12=d12)
+    assert int(blocks.shape[1]) == (3 if d12 else 4)       # 12-byte descriptors (round 6) / the 16-byte form
+    blocks = csr.unpack_blocks(blocks)
     cm_data, cm_ind, blocks, wg_tab = cm_data.numpy(), cm_ind.numpy(), blocks.numpy(), wg_tab.numpy()
     assert (cptr.numpy()[:, 1:] - cptr.numpy()[:, :-1]).max() > 8
     d = rng.random(n)

@@ -106,10 +106,13 @@ def test_round_robin_deal_of_row_ranges(n, m, dens, n_wg, cyclic):
     d = rng.random(n)
     A = tm.SparseMatrix(S)._dev()
     ref_blocks, _, _ = A.pair_blocks()
+    assert int(ref_blocks.shape[1]) == 3               # round 6: 12-byte descriptors below 2^24 rows
+    ref_blocks = A.unpack_blocks(ref_blocks)
     n_blocks = int(ref_blocks.shape[0])
     ref_sorted = torch.unique(ref_blocks, dim=0)
     A._pb = None
     blocks, tab, max_nb = A.pair_blocks(n_wg=n_wg, cyclic=cyclic)
+    blocks = A.unpack_blocks(blocks)
     assert int(blocks.shape[0]) == n_blocks and torch.equal(torch.unique(blocks, dim=0), ref_sorted)
     t = tab.cpu().numpy()
     b = blocks.cpu().numpy()
