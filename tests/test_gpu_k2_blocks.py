@@ -46,6 +46,18 @@ def test_blocks_sandwich_vs_oracle(n, m, dens, dtype):
         xs.K2B_U8 = True
     assert rel_err(got, got32) < (1e-12 if dtype == np.float64 else 1e-4)
     assert rel_err(other, other32) < (1e-12 if dtype == np.float64 else 1e-4)
+    # round 6: the default list holds 12-byte descriptors (tm_sparse_sandwich_blocks_p12_*); the 16-byte list on byte
+    # columns (tm_sparse_sandwich_blocks_u8_*: blocks of 2^24 rows or more, TABMAT_AMD_K2B_DESC12=0) gives the same
+    from tabmat_amd.ext import _types as T
+
+    assert int(A.pair_blocks()[0].shape[1]) == 3
+    try:
+        T.K2B_DESC12 = False
+        got16 = D.to_host(xs.sparse_sandwich_blocks(A, D.to_dev(d)))
+        assert int(A.pair_blocks()[0].shape[1]) == 4
+    finally:
+        T.K2B_DESC12 = True
+    assert rel_err(got, got16) < (1e-12 if dtype == np.float64 else 1e-4)
 
 
 @pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"), reason="the fixed-order sparse self sandwich is selected instead")
