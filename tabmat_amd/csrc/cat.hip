@@ -1222,6 +1222,9 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
 #ifndef EN_CS_D
 #define EN_CS_D 4
 #endif
+#ifndef EN_CS_BOTH
+#define EN_CS_BOTH 1
+#endif
 template <typename F, int NC, bool PK>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
@@ -1238,24 +1241,32 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwave = blockDim.x >> 6;
     F *sd = reinterpret_cast<F *>(smem_raw + tile_bytes) + wave * 64;                                      // d of the slab's rows
     int *sc = reinterpret_cast<int *>(smem_raw + tile_bytes + (size_t)nwave * 64 * sizeof(F)) + wave * 64 * NCW;
-    const int h = wave & 1;                               // which of the pair's two groups
-    const int g = 2 * blockIdx.y + h;
-    const int nwh = (nwave + 1 - h) / 2;                  // waves on this group
-    const int wi = wave >> 1;
+    // EN_CS_BOTH: a wave walks BOTH groups of the pair over its slabs (the rows' operands are fetched and parked once per
+    // slab for two blocks: 10 instead of 12 loads and 2 instead of 4 staging writes per slab and pair); else the waves
+    // alternate between the two groups.
+    constexpr int NG = EN_CS_BOTH ? 2 : 1;
+    const int h0 = EN_CS_BOTH ? 0 : (wave & 1);
+    const int g0 = 2 * blockIdx.y + h0;
+    const int nwh = EN_CS_BOTH ? nwave : (nwave + 1 - h0) / 2;     // waves that share this group's slabs
+    const int wi = EN_CS_BOTH ? wave : (wave >> 1);
     const int64_t s0 = (int64_t)blockIdx.x * slabs_per_block;
     const int64_t s1 = min(s0 + slabs_per_block, n_slabs);
-    if (g < n_groups && s1 > s0) {
+    if (g0 < n_groups && s1 > s0) {
         const int64_t spw = (s1 - s0 + nwh - 1) / nwh;
         const int64_t sa = min(s0 + (int64_t)wi * spw, s1), sb = min(sa + spw, s1);
-        const unsigned *brow = bstart + (int64_t)g * (n_slabs + 1);
+        // (an odd number of groups: the last pair's second group does not exist -- its bounds are read from the first
+        // group's row and its blocks count as empty)
+        const bool has[2] = {true, g0 + 1 < n_groups};
+        const unsigned *brow[2] = {bstart + (int64_t)g0 * (n_slabs + 1),
+                                   bstart + (int64_t)(has[1] ? g0 + 1 : g0) * (n_slabs + 1)};
         // Every load of the walk is UNCONDITIONAL (clamped addresses, results masked afterwards): the compiler can only
         // count its waits (s_waitcnt vmcnt(N) for the requests of EN_CS_D slabs ago, the newer ones stay in flight)
         // over loads it knows were issued -- a first version with the loads behind `if (slot < slots of the block)`
         // waited with vmcnt(0) in front of every slab, one memory round trip per slab: 1.27 ms against 0.94 for the
         // gather kernel.  Three stages, EN_CS_D slabs apart: block bounds (two broadcast loads) -> stream + the rows'
         // operands -> scatter.
-        struct Bnd { unsigned b0, b1; };
-        struct Pre { F v; unsigned m; F dd; int c[NCW]; unsigned b0; int nsl; };
+        struct Bnd { unsigned b0[NG], b1[NG]; };
+        struct Pre { F v[NG]; unsigned m[NG]; F dd; int c[NCW]; unsigned b0[NG]; int nsl[NG]; };
         // (the bounds through VECTOR loads at a lane-invariant address the compiler cannot see through: scalar loads
         // share their counter with the LDS atomics, every use would wait for those too)
         int vz = 0;
@@ -1264,20 +1275,26 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
 #endif
         auto request_bounds = [&](int64_t s, Bnd &q) {
             const int64_t sc_ = min(s, sb - 1) + vz;
-            q.b0 = brow[sc_];
-            q.b1 = brow[sc_ + 1];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                q.b0[k] = brow[k][sc_];
+                q.b1[k] = brow[k][sc_ + 1];
+            }
         };
         auto request = [&](int64_t s, const Bnd &q, Pre &p) {
             const bool live = s < sb;
-            const unsigned qb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b0);
-            const unsigned qb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b1);
-            p.b0 = qb0;
-            p.nsl = live ? (int)(qb1 - qb0) * 16 : 0;
-            const bool ok = lane < p.nsl;
-            const int64_t e = (int64_t)qb0 * 16 + (ok ? lane : 0);            // (slot b0 * 16 exists: slack behind the stream)
-            const F v = __builtin_nontemporal_load(vals + e);
-            p.m = __builtin_nontemporal_load(meta + e);
-            p.v = ok ? v : F(0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const unsigned qb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b0[k]);
+                const unsigned qb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.b1[k]);
+                p.b0[k] = qb0;
+                p.nsl[k] = (live && has[k]) ? (int)(qb1 - qb0) * 16 : 0;
+                const bool ok = lane < p.nsl[k];
+                const int64_t e = (int64_t)qb0 * 16 + (ok ? lane : 0);        // (slot b0 * 16 exists: slack behind the stream)
+                const F v = __builtin_nontemporal_load(vals + e);
+                p.m[k] = __builtin_nontemporal_load(meta + e);
+                p.v[k] = ok ? v : F(0);
+            }
             const int64_t row_ = min(s, sb - 1) * 64 + lane;
             const int64_t row = min(row_, n - 1);              // (ragged last slab: no slot names a row beyond n - 1)
             p.dd = d[row];
@@ -1289,38 +1306,45 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
             }
         };
         auto process = [&](Pre &p) {
-            if (p.nsl == 0) return;
+            int any = 0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) any |= p.nsl[k];
+            if (any == 0) return;
             sd[lane] = p.dd;
 #pragma unroll
             for (int c = 0; c < NCW; ++c) sc[c * 64 + lane] = p.c[c];
             __builtin_amdgcn_wave_barrier();
-            F v = p.v;
-            unsigned m = p.m;
-            for (int off = 0; off < p.nsl; off += 64) {
-                if (off > 0) {                 // a block of more than 64 slots: the rest straight from memory
-                    const bool ok = off + lane < p.nsl;
-                    const int64_t e = (int64_t)p.b0 * 16 + off + (ok ? lane : 0);
-                    v = ok ? vals[e] : F(0);
-                    m = meta[e];
-                }
-                const int r6 = (int)((m >> 4) & 63u);
-                const int col = 16 * h + (int)(m & 15u);
-                const F dk = sd[r6];
-                // rows masked out by d == 0 (and padding slots: value 0) contribute exactly nothing
-                const F x = (dk != F(0) && v != F(0)) ? dk * v : F(0);
-                if (x != F(0)) {
-                    if constexpr (PK) {
-                        const unsigned pk = (unsigned)sc[r6];
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const int f = (int)((pk >> (10 * c)) & 1023u);
-                            if (f != 1023) atomic_add(&tile[f * TSTR + col], (lds_acc_t)x);
-                        }
-                    } else {
+            for (int k = 0; k < NG; ++k) {
+                F v = p.v[k];
+                unsigned m = p.m[k];
+                const int cbase = 16 * (h0 + k);
+                for (int off = 0; off < p.nsl[k]; off += 64) {
+                    if (off > 0) {                 // a block of more than 64 slots: the rest straight from memory
+                        const bool ok = off + lane < p.nsl[k];
+                        const int64_t e = (int64_t)p.b0[k] * 16 + off + (ok ? lane : 0);
+                        v = ok ? vals[e] : F(0);
+                        m = meta[e];
+                    }
+                    const int r6 = (int)((m >> 4) & 63u);
+                    const int col = cbase + (int)(m & 15u);
+                    const F dk = sd[r6];
+                    // rows masked out by d == 0 (and padding slots: value 0) contribute exactly nothing
+                    const F x = (dk != F(0) && v != F(0)) ? dk * v : F(0);
+                    if (x != F(0)) {
+                        if constexpr (PK) {
+                            const unsigned pk = (unsigned)sc[r6];
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const int cc = sc[c * 64 + r6];
-                            if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * TSTR + col], (lds_acc_t)x);
+                            for (int c = 0; c < NC; ++c) {
+                                const int f = (int)((pk >> (10 * c)) & 1023u);
+                                if (f != 1023) atomic_add(&tile[f * TSTR + col], (lds_acc_t)x);
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) {
+                                const int cc = sc[c * 64 + r6];
+                                if (cc >= 0) atomic_add(&tile[(cs.off[c] + cc) * TSTR + col], (lds_acc_t)x);
+                            }
                         }
                     }
                 }
