@@ -722,15 +722,19 @@ int tm_multi_cat_sparse_sandwich_rows_u8_f64(const void *const *h_codes, const i
  * tm_csr_dense_sandwich_ent_*): no slab-form twin is needed for a block whose sparse x dense term runs on the entry
  * kernel.  mk = 16 * groups kernel columns; out [sum(n_cols)][mk] in kernel column order (the caller applies the
  * twin's column permutation), overwritten.  Replaces CategoricalMatrix._cross_sparse
- * (categorical_matrix.py:825-838, a scipy.sparse product) for all categoricals of a SplitMatrix at once. */
+ * (categorical_matrix.py:825-838, a scipy.sparse product) for all categoricals of a SplitMatrix at once.
+ * n_slots (round 6): slots of the whole stream (16 x batches; 0 = unknown).  Two kernels sit behind the entry point:
+ * where a (group, slab) block holds at least 44 slots on average (n_slots / (groups x slabs)) and the LDS holds tile +
+ * staging, the rows' operands are fetched per slab and parked in LDS (multi_cat_sparse_ent_staged_kernel); else they
+ * are gathered per slot. */
 int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
-                                         int64_t mk, float *out, void *stream);
+                                         int64_t n_slots, int64_t mk, float *out, void *stream);
 int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
-                                         int64_t mk, double *out, void *stream);
+                                         int64_t n_slots, int64_t mk, double *out, void *stream);
 /* The same with the categoricals' codes PACKED (round 5; at most 3 categoricals, 1022 stacked levels):
  * packed[row] = sum_c field_c << (10 c), field_c = the stacked output row of the row's level in categorical c
  * (offset of c + code - drop_first) or 1023 when the row has none there.  tm_multi_cat_pack_codes builds the
@@ -741,11 +745,11 @@ int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, 
 int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
                                           const float *vals, const uint32_t *meta, const uint32_t *bstart,
-                                          int64_t mk, const uint32_t *packed, float *out, void *stream);
+                                          int64_t n_slots, int64_t mk, const uint32_t *packed, float *out, void *stream);
 int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
                                           const double *vals, const uint32_t *meta, const uint32_t *bstart,
-                                          int64_t mk, const uint32_t *packed, double *out, void *stream);
+                                          int64_t n_slots, int64_t mk, const uint32_t *packed, double *out, void *stream);
 
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,

@@ -1698,7 +1698,7 @@ template <typename F>
 static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
                                     int n_cats, int64_t n, const F *d, const F *vals, const unsigned *meta,
                                     const unsigned *bstart, int64_t mk, F *out, hipStream_t st,
-                                    const unsigned *packed = nullptr) {
+                                    const unsigned *packed = nullptr, int64_t n_slots = 0) {
     CatSet cs;
     int rc = make_catset(h_codes, h_ncols, h_drop, n_cats, &cs);
     if (rc) return rc;
@@ -1743,7 +1743,13 @@ static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h
     // staged form (round 6): d and the code word(s) of a slab's rows parked in per-wave LDS next to the tile
     const int ncw = packed != nullptr ? 1 : n_cats;
     const size_t lds_staged = lds + (size_t)nw * 64 * (sizeof(F) + 4 * (size_t)ncw);
-    if (tune("catsparse_staged", 1) != 0 && lds_staged <= 156 * 1024) {
+    // ... where a (group, slab) block fills a good part of a 64-lane step: the staged walk takes one step (and one
+    // fetch of the rows' operands) per BLOCK, the gather kernel 256 slots per step whatever the blocks hold -- 512
+    // columns @ 5 %: 59 slots per block, staged -16 %; 512 @ 4 % (48): -7 %; 512 @ 3 % (38): +10 %; 2048 @ 1.25 % (18):
+    // +85 % -- the staged walk costs per block, the gather walk per slot; crossover ~44 (profiles/r6_catsparse.txt).  n_slots = slots of the whole stream (0: unknown -> gather kernel).
+    const double fill = (double)n_slots / ((double)std::max(n_groups, 1) * (double)n_slabs);
+    if (tune("catsparse_staged", 1) != 0 && lds_staged <= 156 * 1024 &&
+        fill >= (double)tune("catsparse_staged_fill", 44)) {
         using KS = void (*)(CatSet, const F *, const F *, const unsigned *, const unsigned *, int, int64_t, int64_t,
                             int64_t, F *, int64_t, const unsigned *, int);
         KS ks = nullptr;
@@ -1967,16 +1973,16 @@ int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64
 int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
-                                         int64_t mk, float *out, void *stream) {
+                                         int64_t n_slots, int64_t mk, float *out, void *stream) {
     return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
-                                           out, as_stream(stream));
+                                           out, as_stream(stream), nullptr, n_slots);
 }
 int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
-                                         int64_t mk, double *out, void *stream) {
+                                         int64_t n_slots, int64_t mk, double *out, void *stream) {
     return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
-                                            out, as_stream(stream));
+                                            out, as_stream(stream), nullptr, n_slots);
 }
 int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop_first, int n_cats,
                             int64_t n, uint32_t *packed, void *stream) {
@@ -1993,16 +1999,16 @@ int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, 
 int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
                                           const float *vals, const uint32_t *meta, const uint32_t *bstart,
-                                          int64_t mk, const uint32_t *packed, float *out, void *stream) {
+                                          int64_t n_slots, int64_t mk, const uint32_t *packed, float *out, void *stream) {
     return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk, out,
-                                           as_stream(stream), packed);
+                                           as_stream(stream), packed, n_slots);
 }
 int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
                                           const double *vals, const uint32_t *meta, const uint32_t *bstart,
-                                          int64_t mk, const uint32_t *packed, double *out, void *stream) {
+                                          int64_t n_slots, int64_t mk, const uint32_t *packed, double *out, void *stream) {
     return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
-                                            out, as_stream(stream), packed);
+                                            out, as_stream(stream), packed, n_slots);
 }
 int tm_multi_cat_sparse_sandwich_slab_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n,

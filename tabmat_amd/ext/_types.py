@@ -837,6 +837,10 @@ class SlabEnt:
     def nbytes(self) -> int:
         return sum(int(t.numel()) * t.element_size() for t in (self.vals, self.meta, self.bstart))
 
+    def n_slots(self) -> int:
+        """Slots of the whole stream (16 x batches, the look-ahead slack not counted)."""
+        return int(self.vals.numel()) - SlabEnt.SLACK
+
     @staticmethod
     def from_csr(csr: CsrDev, max_pad: float = None) -> "SlabEnt":
         """Returns None when the padded stream would exceed max_pad x nnz slots (very sparse blocks: every

@@ -474,10 +474,10 @@ def multi_cat_sparse_sandwich_ent(cats, d, E, packed=None):
     D.same_float("multi_cat_sparse_sandwich_ent", E.vals, d)
     if packed is not None:
         call(f"tm_multi_cat_sparse_sandwich_entp_{D.fsuf(E.vals)}", codes, ncols, drop, n, E.n, D.p(d),
-             D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.mk, D.p(packed), D.p(res), D.stream_ptr())
+             D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.n_slots(), E.mk, D.p(packed), D.p(res), D.stream_ptr())
         return res[:, E.inv]
     call(f"tm_multi_cat_sparse_sandwich_ent_{D.fsuf(E.vals)}", codes, ncols, drop, n, E.n, D.p(d),
-         D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.mk, D.p(res), D.stream_ptr())
+         D.p(E.vals), D.p(E.meta), D.p(E.bstart), E.n_slots(), E.mk, D.p(res), D.stream_ptr())
     return res[:, E.inv]      # kernel columns -> the block's columns
 
 

@@ -320,8 +320,10 @@ def _catsparse_kernel(request):
     from tabmat_amd import _lib
 
     _lib.call("tm_tune_set", b"catsparse_staged", 1 if request.param == "staged" else 0)
+    _lib.call("tm_tune_set", b"catsparse_staged_fill", 0)          # (whatever the blocks hold: the kernel is forced)
     yield request.param
-    _lib.call("tm_tune_set", b"catsparse_staged", 1)
+    _lib.call("tm_tune_set", b"catsparse_staged", -2**63)
+    _lib.call("tm_tune_set", b"catsparse_staged_fill", -2**63)
 
 
 @gpu
