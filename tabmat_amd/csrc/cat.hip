@@ -758,11 +758,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_c_kernel(
 constexpr int MCW_RS = 32;
 constexpr int MCW_VEC = 2;
 
-// ROWS: the row-list form (every position mapped through `rows`).  The unrestricted instantiation has NO load behind a
-// branch -- the steps beyond the workgroup's range load clamped rows and scatter nothing -- so that the compiler can count
-// its waits: with the loads of the next step behind `if (more)` it waited with vmcnt(0) in front of every scatter, i.e.
-// for the loads it had just issued (round 6; the lesson of the staged categorical x sparse kernel).
-template <typename F, int NC, bool ROWS = false>
+template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     CatSet cs, const F *__restrict__ d, const F *__restrict__ M, int64_t n, int64_t m,
     int64_t rows_per_block, F *__restrict__ ws, int64_t stride, const int32_t *__restrict__ rows,
@@ -804,7 +800,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
         int64_t kr[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) kr[i] = min(k0 + 4 * i + q, n - 1);
-        if constexpr (ROWS) {
+        if (rows) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) kr[i] = (int64_t)rows[kr[i]];
         }
@@ -815,8 +811,7 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
         }
         const int64_t k = k0 + lr;
         const int64_t kp = min(k, n - 1);
-        int64_t kc = kp;
-        if constexpr (ROWS) kc = (int64_t)rows[kp];
+        const int64_t kc = rows ? (int64_t)rows[kp] : kp;
         R.dk = d[kc];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -855,13 +850,15 @@ __global__ __launch_bounds__(1024) void multi_cat_dense_wide_kernel(
     };
     Regs ra, rb;
     int64_t k0 = t0 + (int64_t)wave * MCW_RS;
-    // (all loads unconditional: rows are clamped to n - 1 inside load(), positions beyond t1 get code -1 = no scatter)
-    load(k0, ra);
+    if (k0 < t1) load(k0, ra);
     for (; k0 < t1; k0 += 2 * step) {
-        load(k0 + step, rb);
+        const bool more = k0 + step < t1;
+        if (more) load(k0 + step, rb);
         process(ra);
-        load(k0 + 2 * step, ra);
-        process(rb);
+        if (more) {
+            if (k0 + 2 * step < t1) load(k0 + 2 * step, ra);
+            process(rb);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) wg_log_end(wglog, t_begin, WG_CAT_DENSE);
@@ -1508,16 +1505,7 @@ static int run_multi_cat_dense(const void *const *h_codes, const int64_t *h_ncol
                 TM_LAUNCH_CHECK();
                 return TM_OK;
             };
-            if (rows != nullptr) {
-                if (n_cats == 1) rc = gow(&multi_cat_dense_wide_kernel<F, 1, true>);
-                else if (n_cats == 2) rc = gow(&multi_cat_dense_wide_kernel<F, 2, true>);
-                else if (n_cats == 3) rc = gow(&multi_cat_dense_wide_kernel<F, 3, true>);
-                else if (n_cats == 4) rc = gow(&multi_cat_dense_wide_kernel<F, 4, true>);
-                else if (n_cats == 5) rc = gow(&multi_cat_dense_wide_kernel<F, 5, true>);
-                else if (n_cats == 6) rc = gow(&multi_cat_dense_wide_kernel<F, 6, true>);
-                else if (n_cats == 7) rc = gow(&multi_cat_dense_wide_kernel<F, 7, true>);
-                else rc = gow(&multi_cat_dense_wide_kernel<F, 8, true>);
-            } else if (n_cats == 1) rc = gow(&multi_cat_dense_wide_kernel<F, 1>);
+            if (n_cats == 1) rc = gow(&multi_cat_dense_wide_kernel<F, 1>);
             else if (n_cats == 2) rc = gow(&multi_cat_dense_wide_kernel<F, 2>);
             else if (n_cats == 3) rc = gow(&multi_cat_dense_wide_kernel<F, 3>);
             else if (n_cats == 4) rc = gow(&multi_cat_dense_wide_kernel<F, 4>);
