@@ -370,11 +370,7 @@ class CategoricalMatrix(MatrixBase):
         if DETERMINISTIC and self.shape[0] > 0:
             # bitwise reproducible sums (the reference's K4a is deterministic); a row restriction
             # becomes a masked vector, a column restriction a masked result
-            if rows is not None:
-                vm = torch.zeros_like(vec)
-                r64 = rows.to(torch.int64)
-                vm[r64] = vec[r64]
-                vec = vm
+            vec = D.masked_d(vec, rows)        # (a repeated row counts per occurrence, as the reference's loop does)
             perm, bstart, n_blocks, cat_bptr = self._det_plan()
             tgt = out_full if cols is None else D.zeros((self.shape[1],), out_full.dtype)
             xc.transpose_matvec_det(perm, bstart, n_blocks, cat_bptr, self.shape[1], vec, tgt,

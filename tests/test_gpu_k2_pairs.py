@@ -3,6 +3,8 @@ parity with the oracle's restatement of ext/sparse.pyx:17-77 entry by entry at t
 kernel's bookkeeping can get wrong (ragged last chunk, empty chunks, one-entry lists, lists longer than the
 prefetched head, d == 0 rows holding inf, row segments shorter than a range), both dtypes, rows / cols through the
 public method, and the dispatch."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -103,6 +105,8 @@ def test_pairs_kernel_excluded_rows_may_hold_inf():
     assert np.isfinite(got).all() and nat_err(got, ref) < 1e-10
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"),
+                    reason="the fixed-order sparse self sandwich is selected instead")
 def test_public_sandwich_takes_the_pairs_kernel_for_wide_blocks(monkeypatch):
     """SparseMatrix.sandwich with the pair-stream form switched on: unrestricted, a long row list (masked d), a
     short one (row-list kernels), a column selection -- all against dense algebra."""

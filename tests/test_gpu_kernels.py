@@ -2,6 +2,8 @@
 inputs at sizes the oracle finishes in seconds.  Bars (BASELINE.json north_star): categorical
 counts bit-exact; fp64 sandwich <= 1e-10 relative; fp32 paths are compared with the fp64
 oracle at a tolerance that covers fp32 accumulation of n terms (stated per test)."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse as sps
@@ -880,6 +882,8 @@ def test_row_restriction_ignores_non_finite_excluded_rows():
     assert nat_err(res, ref) < F64_TOL
 
 
+@pytest.mark.skipif(os.environ.get("TABMAT_AMD_DETERMINISTIC", "0") not in ("", "0"),
+                    reason="the fixed-order paths of TABMAT_AMD_DETERMINISTIC=1 synchronise with the host (not capturable)")
 def test_sandwich_graph_replay_matches_eager():
     """SplitMatrix.sandwich_graph replays the captured launch sequence (tabmat_amd/graph.py):
     same result as the eager call for new d, with and without rows/cols, and after the library's
