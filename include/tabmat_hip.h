@@ -436,17 +436,21 @@ int tm_csr_dense_sandwich_lgc_f64(const double *cvals, const uint32_t *cmap, con
  * the row of a real entry of the block); the blocks of a group follow one another slab after slab, group
  * after group:
  *   vals F[16 * batches + 192]        value (192 slots of slack at the end are read, not used: zeros)
- *   meta uint32[16 * batches + 192]   row << 4 | column in group
+ *   meta uint16[16 * batches + 192]   (slab & 63) << 10 | row in slab << 4 | column in group   (round 6; a uint32
+ *                                     row << 4 | column before: 12 -> 10 bytes per slot).  The kernels rebuild a
+ *                                     slot's slab from the 6-bit tag and a running slab, so two consecutive batches of
+ *                                     a group must lie fewer than 64 slabs apart: the builder gives an EMPTY block one
+ *                                     padding batch (value 0, row = the slab's first row) at every 32nd slab.
  *   bstart uint32[G][S + 1]           first batch of block (group, slab); entry S = the end of the group
  * colsum (length m, kernel column order, = A' d from the same pass; reference standardized_mat.py:149-150)
  * may be NULL.  out: (m, r), kernel column order, overwritten. */
 int tm_ent_rows(void);
 int tm_ent_group_cols(void);
 int tm_ent_batch_slots(void);
-int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const float *B, int64_t r, const float *d, float *out,
                                   float *colsum, void *stream);
-int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const double *B, int64_t r, const double *d, double *out,
                                   double *colsum, void *stream);
 
@@ -729,11 +733,11 @@ int tm_multi_cat_sparse_sandwich_rows_u8_f64(const void *const *h_codes, const i
  * are gathered per slot. */
 int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
-                                         const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         const float *vals, const uint16_t *meta, const uint32_t *bstart,
                                          int64_t n_slots, int64_t mk, float *out, void *stream);
 int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
-                                         const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         const double *vals, const uint16_t *meta, const uint32_t *bstart,
                                          int64_t n_slots, int64_t mk, double *out, void *stream);
 /* The same with the categoricals' codes PACKED (round 5; at most 3 categoricals, 1022 stacked levels):
  * packed[row] = sum_c field_c << (10 c), field_c = the stacked output row of the row's level in categorical c
@@ -744,11 +748,11 @@ int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, 
                             int64_t n, uint32_t *packed, void *stream);
 int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
-                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          const float *vals, const uint16_t *meta, const uint32_t *bstart,
                                           int64_t n_slots, int64_t mk, const uint32_t *packed, float *out, void *stream);
 int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
-                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          const double *vals, const uint16_t *meta, const uint32_t *bstart,
                                           int64_t n_slots, int64_t mk, const uint32_t *packed, double *out, void *stream);
 
 /* ecol[e] = column of entry e within its column group (0 .. tm_slab_group_cols()-1). */

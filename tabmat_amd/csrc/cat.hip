@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_pf_kernel(
 #endif
 template <typename F, int NC>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
-    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
-    const unsigned *__restrict__ bstart, int n_groups, int64_t n_slabs, int64_t slabs_per_block,
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned short *__restrict__ meta,
+    const unsigned *__restrict__ bstart, int n_groups, int64_t n, int64_t n_slabs, int64_t slabs_per_block,
     F *__restrict__ ws, int64_t stride, const unsigned *__restrict__ packed) {
     // packed (round 5, may be NULL; NC <= 3): packed[row] = the tile rows of the row's levels, 10 bits each (1023 =
     // none: missing / dropped level), built once per matrix by tm_multi_cat_pack_codes -- ONE gather per slot
@@ -1161,10 +1161,16 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
                 t.m[u] = meta[i];
             }
         };
+        // (round 6: 16-bit meta words {slab & 63, row in slab, column}: the slab of a slot from the tag and a running
+        // slab, in stream order -- load_rows is called step after step; rows of slots behind the wave's stream clamped)
+        unsigned cur_slab = (unsigned)sa;
+        const unsigned row_max = (unsigned)(n - 1);
         auto load_rows = [&](Step &t) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const unsigned row = t.m[u] >> 4;
+                const unsigned slab = cur_slab + (((t.m[u] >> 10) - cur_slab) & 63u);
+                cur_slab = (unsigned)__builtin_amdgcn_readlane((int)slab, 63);
+                const unsigned row = min((slab << 6) | ((t.m[u] >> 4) & 63u), row_max);
                 t.dk[u] = d[row];
                 if (NC <= 3 && packed != nullptr) {
                     const unsigned pk = packed[row];
@@ -1227,7 +1233,7 @@ __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_kernel(
 #endif
 template <typename F, int NC, bool PK>
 __global__ __launch_bounds__(1024) void multi_cat_sparse_ent_staged_kernel(
-    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned *__restrict__ meta,
+    CatSet cs, const F *__restrict__ d, const F *__restrict__ vals, const unsigned short *__restrict__ meta,
     const unsigned *__restrict__ bstart, int n_groups, int64_t n, int64_t n_slabs, int64_t slabs_per_block,
     F *__restrict__ ws, int64_t stride, const unsigned *__restrict__ packed, int tile_bytes) {
     constexpr int GC = 32, TSTR = GC + 1;
@@ -1696,7 +1702,7 @@ __global__ __launch_bounds__(256) void multi_cat_pack_codes_kernel(CatSet cs, in
 // entry-twin form (see multi_cat_sparse_ent_kernel): out [total levels][mk], mk = 16 * groups kernel columns
 template <typename F>
 static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h_ncols, const int32_t *h_drop,
-                                    int n_cats, int64_t n, const F *d, const F *vals, const unsigned *meta,
+                                    int n_cats, int64_t n, const F *d, const F *vals, const unsigned short *meta,
                                     const unsigned *bstart, int64_t mk, F *out, hipStream_t st,
                                     const unsigned *packed = nullptr, int64_t n_slots = 0) {
     CatSet cs;
@@ -1750,7 +1756,7 @@ static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h
     const double fill = (double)n_slots / ((double)std::max(n_groups, 1) * (double)n_slabs);
     if (tune("catsparse_staged", 1) != 0 && lds_staged <= 156 * 1024 &&
         fill >= (double)tune("catsparse_staged_fill", 44)) {
-        using KS = void (*)(CatSet, const F *, const F *, const unsigned *, const unsigned *, int, int64_t, int64_t,
+        using KS = void (*)(CatSet, const F *, const F *, const unsigned short *, const unsigned *, int, int64_t, int64_t,
                             int64_t, F *, int64_t, const unsigned *, int);
         KS ks = nullptr;
         if (packed != nullptr) {
@@ -1781,7 +1787,7 @@ static int run_multi_cat_sparse_ent(const void *const *h_codes, const int64_t *h
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_begin(st);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)n_pairs), dim3(nw * 64), lds, st, cs, d, vals, meta,
-                           bstart, n_groups, n_slabs, spb, ws, stride, packed);
+                           bstart, n_groups, n, n_slabs, spb, ws, stride, packed);
         prof_end(st);
         TM_LAUNCH_CHECK();
     }
@@ -1972,14 +1978,14 @@ int tm_multi_cat_dense_sandwich_rows_f64(const void *const *h_codes, const int64
 }
 int tm_multi_cat_sparse_sandwich_ent_f32(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
-                                         const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         const float *vals, const uint16_t *meta, const uint32_t *bstart,
                                          int64_t n_slots, int64_t mk, float *out, void *stream) {
     return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
                                            out, as_stream(stream), nullptr, n_slots);
 }
 int tm_multi_cat_sparse_sandwich_ent_f64(const void *const *h_codes, const int64_t *h_ncols,
                                          const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
-                                         const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                         const double *vals, const uint16_t *meta, const uint32_t *bstart,
                                          int64_t n_slots, int64_t mk, double *out, void *stream) {
     return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
                                             out, as_stream(stream), nullptr, n_slots);
@@ -1998,14 +2004,14 @@ int tm_multi_cat_pack_codes(const void *const *h_codes, const int64_t *h_ncols, 
 }
 int tm_multi_cat_sparse_sandwich_entp_f32(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const float *d,
-                                          const float *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          const float *vals, const uint16_t *meta, const uint32_t *bstart,
                                           int64_t n_slots, int64_t mk, const uint32_t *packed, float *out, void *stream) {
     return run_multi_cat_sparse_ent<float>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk, out,
                                            as_stream(stream), packed, n_slots);
 }
 int tm_multi_cat_sparse_sandwich_entp_f64(const void *const *h_codes, const int64_t *h_ncols,
                                           const int32_t *h_drop_first, int n_cats, int64_t n, const double *d,
-                                          const double *vals, const uint32_t *meta, const uint32_t *bstart,
+                                          const double *vals, const uint16_t *meta, const uint32_t *bstart,
                                           int64_t n_slots, int64_t mk, const uint32_t *packed, double *out, void *stream) {
     return run_multi_cat_sparse_ent<double>(h_codes, h_ncols, h_drop_first, n_cats, n, d, vals, meta, bstart, mk,
                                             out, as_stream(stream), packed, n_slots);

@@ -24,9 +24,11 @@
 // BATCHES of 16 slots (padding: value 0, the row of the block's first entry); the blocks of a group follow
 // one another, slab after slab, so a wave walks ONE contiguous stream:
 //     vals F[T]              value
-//     meta uint32[T]         row (of the whole block) << 4 | column in group
+//     meta uint16[T]         (slab & 63) << 10 | row in slab << 4 | column in group   (round 6; uint32 row << 4 | column
+//                            before: 12 -> 10 bytes per slot.  An empty block at every 32nd slab holds one padding batch,
+//                            so that two batches of a group are never 64 slabs apart and the 6-bit tag is unambiguous.)
 //     bstart uint32[G][S+1]  first batch of block (group, slab); entry S = the end of the group's stream
-// 12 bytes per slot.  A wave takes its stream in SUPERBATCHES of 64 slots, lane <-> slot: one coalesced load
+// 10 bytes per slot.  A wave takes its stream in SUPERBATCHES of 64 slots, lane <-> slot: one coalesced load
 // of the values and one of the meta words a whole superbatch (~5000 cycles) ahead, the d of every slot's row
 // gathered from global memory (L2-resident lines) half a superbatch ahead; then, still lane <-> slot, the
 // FOLD: a = value * d, kq = LDS address of the row of B (the all-zero row if value == 0 or d == 0, so inf * 0
@@ -114,13 +116,14 @@ __device__ __forceinline__ unsigned en_read_acc() {
 // "=v" outputs and the wait as a separate asm with "+v" operands the compiler is free to copy the
 // still-in-flight registers BEFORE the wait -- it did, in one of the three wait variants of the f32 kernel.)
 template <typename F>
-__device__ __forceinline__ void en_load_stream(unsigned voff_v, const F *vp, unsigned voff_m, const unsigned *mp) {
+__device__ __forceinline__ void en_load_stream(unsigned voff_v, const F *vp, unsigned voff_m, const unsigned short *mp) {
+    // (the meta word is 16 bits since round 6: global_load_ushort zero-extends into the register)
     if constexpr (sizeof(F) == 8)
         asm volatile("global_load_dwordx2 v[" EN_LD ":" EN_LD "+1], %0, %1\n\t"
-                     "global_load_dword v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
+                     "global_load_ushort v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
     else
         asm volatile("global_load_dword v[" EN_LD "], %0, %1\n\t"
-                     "global_load_dword v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
+                     "global_load_ushort v[" EN_LD "+2], %2, %3" :: "v"(voff_v), "s"(vp), "v"(voff_m), "s"(mp) : "memory");
 }
 template <typename F>
 __device__ __forceinline__ void en_load_d(unsigned voff, const F *dp) {
@@ -156,7 +159,7 @@ __device__ inline en_rsrc_t en_rsrc(const void *, int64_t) { return {}; }
 __device__ inline void en_buf_to_lds16(en_rsrc_t, void *, int, int) {}
 template <typename F> __device__ void en_zero_acc() {}
 template <int K> __device__ unsigned en_read_acc() { return 0u; }
-template <typename F> __device__ void en_load_stream(unsigned, const F *, unsigned, const unsigned *) {}
+template <typename F> __device__ void en_load_stream(unsigned, const F *, unsigned, const unsigned short *) {}
 template <typename F> __device__ void en_load_d(unsigned, const F *) {}
 template <int N, typename F> __device__ void en_take(F &, unsigned &, F &) {}
 #endif
@@ -182,7 +185,7 @@ __device__ void en_batch_asm(unsigned &, unsigned &, unsigned &, unsigned &, F, 
 // add their entry's value * d to a per-wave LDS array of 16 doubles, one ds_add_f64 per batch.
 template <typename F, bool CSUM>
 __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR))) void csr_dense_ent_kernel(
-    const F *__restrict__ vals, const unsigned *__restrict__ meta, const unsigned *__restrict__ bstart,
+    const F *__restrict__ vals, const unsigned short *__restrict__ meta, const unsigned *__restrict__ bstart,
     int n_groups, int64_t n_slabs, int64_t slabs_per_block, const F *__restrict__ B, int64_t n, int64_t r,
     int nB, const F *__restrict__ d, F *__restrict__ ws, F *__restrict__ ws_csum, long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -244,23 +247,34 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
     // superbatch k = slots (b0 + 4 k) * 16 + lane; registers: X {vx, mx} = the superbatch being loaded,
     // Y {vy, my} = the one that has arrived (folded next), dy = the d of Y's rows (being gathered)
     const F *vbase = vals + (int64_t)b0 * EN_B;
-    const unsigned *mbase = meta + (int64_t)b0 * EN_B;
+    const unsigned short *mbase = meta + (int64_t)b0 * EN_B;
     F vx = F(0), vy = F(0), dy = F(0);
     unsigned mx = 0u, my = 0u;
-    const unsigned lane_v = (unsigned)lane * (unsigned)sizeof(F), lane_m = (unsigned)lane * 4u;
+    const unsigned lane_v = (unsigned)lane * (unsigned)sizeof(F), lane_m = (unsigned)lane * 2u;
     // (the loads are written as asm so that THIS code places the waits: the compiler would wait with
     // vmcnt(0) at every use, i.e. also for the copy pieces of the next slab issued a moment before)
     auto request_stream = [&](int k) {
         en_load_stream<F>(lane_v, vbase + (int64_t)k * EN_SB, lane_m, mbase + (int64_t)k * EN_SB);
     };
-    auto request_d = [&]() {          // d of Y's rows (row < 2^28: a 32-bit byte offset)
-        en_load_d<F>((my >> 4) * (unsigned)sizeof(F), d);
+    // The stream's meta word is 16 bits {slab & 63, row in slab, column in group}; the slot's slab is rebuilt from the
+    // 6-bit tag and a wave-uniform running slab (the stream is ordered by slab and the builder leaves no gap of 64 slabs
+    // between two batches of a group): my = row << 4 | column as before round 6, row = slab * 64 + row in slab.
+    const unsigned s0u = (unsigned)s0;
+    unsigned cur_slab = s0u;
+    auto expand = [&](unsigned m16) -> unsigned {
+        const unsigned slab = cur_slab + (((m16 >> 10) - cur_slab) & 63u);
+        cur_slab = (unsigned)__builtin_amdgcn_readlane((int)slab, 63);
+        return (slab << 10) | (m16 & 0x3ffu);
+    };
+    const unsigned row_max = (unsigned)(n - 1);
+    auto request_d = [&]() {          // d of Y's rows (row < 2^28: a 32-bit byte offset); slots behind the wave's stream
+        // belong to another group (or the slack): their rebuilt row means nothing and is clamped into the array
+        en_load_d<F>(min(my >> 4, row_max) * (unsigned)sizeof(F), d);
     };
     auto wait_loads = [&](auto nc) { en_take<decltype(nc)::value>(vx, mx, dy); };
     int psince = 0;                    // copy pieces issued since the last requests
     int lsince = 0;                    // stream / d loads requested since the last copy pieces
     (void)lsince;
-    const unsigned s0u = (unsigned)s0;
     // boundary k: fold superbatch k (= Y, dy) into the scratch, Y <- X = superbatch k + 1, requests
     auto boundary = [&](int k) {
         // (everything requested before the last `psince` pieces has arrived once at most that many operations
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
             if (4 * k * EN_B + lane < nbw * EN_B) atomic_add(cs_lds + (jv >> JSH), (double)a);
         }
         vy = vx;
-        my = mx;
+        my = expand(mx);
         request_d();
         request_stream(k + 2);
         psince = 0;
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(EN_THREADS) __attribute__((amdgpu_num_vgpr(EN_CVGPR
     request_stream(0);
     wait_loads(std::integral_constant<int, 0>{});
     vy = vx;
-    my = mx;
+    my = expand(mx);
     request_d();
     request_stream(1);
     __syncthreads();
@@ -451,7 +465,7 @@ __global__ void en_csum_kernel(const F *__restrict__ part, int nblk, int64_t m, 
 }
 
 template <typename F>
-static int run_csr_dense_ent(const F *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n, int64_t m,
+static int run_csr_dense_ent(const F *vals, const uint16_t *meta, const uint32_t *bstart, int64_t n, int64_t m,
                              const F *B, int64_t r, const F *d, F *out, F *colsum, hipStream_t st) {
     const int64_t nB = r;
     const int64_t total = m * nB;
@@ -523,12 +537,12 @@ int tm_ent_rows(void) { return tmh::EN_R; }
 int tm_ent_group_cols(void) { return tmh::EN_C; }
 int tm_ent_batch_slots(void) { return tmh::EN_B; }
 
-int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
+int tm_csr_dense_sandwich_ent_f32(const float *vals, const uint16_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const float *B, int64_t r, const float *d, float *out,
                                   float *colsum, void *stream) {
     return tmh::run_csr_dense_ent<float>(vals, meta, bstart, n, m, B, r, d, out, colsum, tmh::as_stream(stream));
 }
-int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint32_t *meta, const uint32_t *bstart, int64_t n,
+int tm_csr_dense_sandwich_ent_f64(const double *vals, const uint16_t *meta, const uint32_t *bstart, int64_t n,
                                   int64_t m, const double *B, int64_t r, const double *d, double *out,
                                   double *colsum, void *stream) {
     return tmh::run_csr_dense_ent<double>(vals, meta, bstart, n, m, B, r, d, out, colsum, tmh::as_stream(stream));

@@ -815,13 +815,14 @@ class SlabEnt:
     """Entry twin of a sparse block for tm_csr_dense_sandwich_ent_* (csrc/sparse_ent.hip, round 4): rows in
     slabs of R = 64, columns dealt to G groups of C = 16 (one wave each) in the order of their density
     (rank r -> group r % G: the groups of a workgroup carry equal shares of every slab).  The entries
-    {value, row << 4 | column in group} of block (group, slab) are padded to whole batches of 16 slots
-    (padding: value 0, the row of the block's first entry); blocks follow one another slab after slab, group
-    after group; bstart[g, s] = first batch of the block.  12 bytes per slot, 1.16 slots per nonzero at 5 %
-    density and 512 columns.  Built once per block on the device."""
+    {value, (slab & 63) << 10 | row in slab << 4 | column in group} of block (group, slab) are padded to whole
+    batches of 16 slots (padding: value 0, the row of the block's first entry); blocks follow one another slab
+    after slab, group after group; bstart[g, s] = first batch of the block.  10 bytes per slot (f64; 12 until
+    round 5: a 32-bit row << 4 | column), 1.16 slots per nonzero at 5 % density and 512 columns.  Built once per
+    block on the device."""
 
     vals: torch.Tensor     # F[T + 192]
-    meta: torch.Tensor     # int32[T + 192]
+    meta: torch.Tensor     # int16[T + 192] (bit pattern of the 16-bit words)
     bstart: torch.Tensor   # int32[G, S + 1] (read as uint32)
     inv: torch.Tensor      # int64[m]  kernel row of column c of the block
     n: int
@@ -869,13 +870,18 @@ class SlabEnt:
         SL = SlabEnt.SLACK
         if nnz == 0 or S == 0:
             return SlabEnt(torch.zeros(SL, dtype=csr.data.dtype, device=dev),
-                           torch.zeros(SL, dtype=torch.int32, device=dev),
+                           torch.zeros(SL, dtype=torch.int16, device=dev),
                            torch.zeros((G, S + 1), dtype=torch.int32, device=dev), inv, n, m, G * C)
         counts = csr.indptr[1:] - csr.indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), counts)
         key = grp_of[idx64] * S + torch.div(rows, R, rounding_mode="floor")
         cnt = torch.bincount(key, minlength=G * S)
         nb = torch.div(cnt + (U - 1), U, rounding_mode="floor")
+        # round 6: the meta word carries 6 bits of the slab; an EMPTY block at every 32nd slab gets one padding batch, so
+        # that two consecutive batches of a group are never 64 slabs apart (the kernels rebuild the slab from the tag and
+        # a running slab).  Nothing is added where the blocks hold entries (BASELINE configs[3]: none).
+        slab_of = torch.arange(G * S, device=dev, dtype=torch.int64) % S
+        nb = nb + ((cnt == 0) & (slab_of % 32 == 0)).to(nb.dtype)
         total_b = int(nb.sum().item())
         if max_pad is not None and total_b * U > max_pad * nnz and total_b * U > (1 << 22):
             return None
@@ -892,15 +898,21 @@ class SlabEnt:
         T = total_b * U
         rows_p = rows[perm]
         del rows
-        # padding slots: value 0, the row of the block's first entry (a valid row of the same slab)
-        nz = cnt > 0
-        frow = (rows_p[first[nz]] << 4).to(torch.int32)
-        meta = torch.zeros(T + SL, dtype=torch.int32, device=dev)
-        meta[:T] = torch.repeat_interleave(frow, nb[nz] * U)
-        del frow, nz, first, cnt, nb
+        # meta word (16 bits): (slab & 63) << 10 | row in slab << 4 | column in group
+        def word16(row, col):
+            w = (((row >> 6) & 63) << 10) | ((row & 63) << 4) | col
+            return torch.where(w >= 32768, w - 65536, w).to(torch.int16)
+
+        # padding slots: value 0, the row of the block's first entry (a valid row of the same slab; an empty block
+        # that holds the continuity batch: the slab's first row)
+        has = nb > 0
+        frow = torch.where(cnt > 0, rows_p[first.clamp(max=nnz - 1)], slab_of * R)[has]
+        meta = torch.zeros(T + SL, dtype=torch.int16, device=dev)
+        meta[:T] = torch.repeat_interleave(word16(frow, torch.zeros_like(frow)), nb[has] * U)
+        del frow, has, first, cnt, nb, slab_of
         vals = torch.zeros(T + SL, dtype=csr.data.dtype, device=dev)
         vals[pos] = csr.data[perm]
-        meta[pos] = ((rows_p << 4) | jloc_of[idx64[perm]]).to(torch.int32)
+        meta[pos] = word16(rows_p, jloc_of[idx64[perm]])
         del pos, perm, rows_p, idx64
         gi = torch.arange(G, device=dev, dtype=torch.int64)[:, None] * S + \
             torch.arange(S + 1, device=dev, dtype=torch.int64)[None, :]

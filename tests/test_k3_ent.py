@@ -3,7 +3,7 @@ kernel on it (csrc/sparse_ent.hip, round 4; reference: ext/sparse.pyx:211-260 cs
 ext/sparse_helpers-tmpl.cpp:23-146).
 
 CPU part: the twin builder is plain torch, so its output is decoded here exactly the way the kernel walks it
-(groups, batches of 16 slots, meta = row << 4 | column, bstart) and compared with the matrix.  GPU part: the
+(groups, batches of 16 slots, meta = slab tag | row in slab | column, bstart) and compared with the matrix.  GPU part: the
 kernel through the C ABI against the oracle's csr_dense_sandwich -- float64 within 1e-10 (observed 1e-15),
 float32 within 2e-5 of the float64 oracle."""
 import numpy as np
@@ -25,7 +25,7 @@ def _csr_cpu(S, dtype):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("n,m,density", [(300, 40, 0.05), (64, 16, 0.5), (129, 33, 0.2), (1000, 512, 0.02),
-                                         (5, 3, 1.0), (200, 20, 0.0)])
+                                         (5, 3, 1.0), (200, 20, 0.0), (64 * 150 + 7, 20, 0.0002)])
 def test_twin_decodes_to_the_matrix(n, m, density, dtype):
     rng = np.random.default_rng(n + m)
     S = sps.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
@@ -34,7 +34,7 @@ def test_twin_decodes_to_the_matrix(n, m, density, dtype):
     G = tw.mk // C
     nS = (n + R - 1) // R
     assert tw.bstart.shape == (G, nS + 1)
-    vals, meta, bst = tw.vals.numpy(), tw.meta.numpy().view(np.uint32), tw.bstart.numpy().view(np.uint32)
+    vals, meta, bst = tw.vals.numpy(), tw.meta.numpy().view(np.uint16), tw.bstart.numpy().view(np.uint32)
     assert vals.shape[0] == meta.shape[0] == int(bst[-1, -1]) * U + SlabEnt.SLACK
     assert not vals[int(bst[-1, -1]) * U:].any() and not meta[int(bst[-1, -1]) * U:].any()    # the slack
     dense = np.zeros((tw.mk, n))
@@ -46,13 +46,18 @@ def test_twin_decodes_to_the_matrix(n, m, density, dtype):
             assert b1 >= b0
             real = 0
             for q in range(b0 * U, b1 * U):
-                row, col = int(meta[q]) >> 4, int(meta[q]) & 15
-                assert s * R <= row < min((s + 1) * R, n)  # every slot (padding too) names a row of ITS slab
+                # round 6: 16-bit words {slab & 63, row in slab, column in group}
+                tag, r6, col = int(meta[q]) >> 10, (int(meta[q]) >> 4) & 63, int(meta[q]) & 15
+                assert tag == (s & 63)
+                row = s * R + r6
+                assert row < n                             # every slot (padding too) names a row of ITS slab
                 if vals[q] != 0:
                     assert dense[g * C + col, row] == 0
                     dense[g * C + col, row] = vals[q]
                     real += 1
-            assert (b1 - b0) == (real + U - 1) // U        # whole batches, no empty ones
+            # whole batches; an EMPTY block holds none -- except the continuity batch at every 32nd slab (a matrix
+            # without any entry has no stream at all)
+            assert (b1 - b0) == (real + U - 1) // U + int(real == 0 and s % 32 == 0 and S.nnz > 0)
         prev_end = int(bst[g, nS])
     np.testing.assert_array_equal(dense[tw.inv.numpy()].T, S.toarray().astype(dtype))
 
