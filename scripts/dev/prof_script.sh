@@ -7,7 +7,7 @@ python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:24]:
+for r in rows[:40]:
     n = int(r["Calls"])
     print(f"   {r['Name'].split('(')[0].replace('void ', '')[:78]:80s} calls {n:4d}  avg {float(r['AverageNs']) / 1e3:10.1f} us  total {float(r['TotalDurationNs']) / 1e6:9.2f} ms")
 PY
