@@ -148,6 +148,12 @@ def _structured(kind, n, m, rng):
         S = sps.lil_matrix((n, m))
         for r in rng.choice(n, 5, replace=False):
             S[r, :] = rng.standard_normal((1, m))
+    elif kind == "far_apart_slabs":            # entries in a few slabs hundreds of slabs apart (round 6: the 16-bit meta
+        S = sps.lil_matrix((n, m))             # word carries 6 bits of the slab; empty stretches get continuity batches)
+        for s0 in sorted(set([0, (n // 64) // 3, max(0, (n - 1) // 64 - 70), (n - 1) // 64])):
+            for r in range(s0 * 64, min(s0 * 64 + 64, n), 3):
+                S[r, (7 * r) % m] = float(r % 11 + 1)
+                S[r, (7 * r + m // 2) % m] = -0.5
     else:                                      # "first_slab_only"
         S = sps.lil_matrix((n, m))
         S[:min(64, n), :] = rng.standard_normal((min(64, n), m))
@@ -159,8 +165,9 @@ def _structured(kind, n, m, rng):
 
 @gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("kind", ["one_full_column", "last_group_last_slab", "banded", "dense_rows", "first_slab_only"])
-@pytest.mark.parametrize("n,m", [(5003, 100), (64 * 40, 512), (130, 17)])
+@pytest.mark.parametrize("kind", ["one_full_column", "last_group_last_slab", "banded", "dense_rows", "first_slab_only",
+                                  "far_apart_slabs"])
+@pytest.mark.parametrize("n,m", [(5003, 100), (64 * 40, 512), (130, 17), (64 * 700 + 5, 48)])
 def test_ent_kernel_structured_patterns(kind, n, m, dtype):
     """Blocks of exactly / more than 64 slots in every slab, groups and slabs without any entry, entries only in the
     ragged tail: the cases the superbatch fold, the quad cut and the slab walk have branches for."""
@@ -409,3 +416,30 @@ def test_split_matrix_needs_no_slab_twin_beside_the_entry_twin():
         assert np.abs(got - want).max() / np.abs(want).max() < 1e-10
         sp = m2.matrices[1]
         assert getattr(sp, "_entblk", None) and getattr(sp, "_slabblk", None) is None
+
+
+@gpu
+@pytest.mark.parametrize("_catsparse_kernel", ["staged", "gather"], indirect=True)
+def test_cat_sparse_on_slabs_far_apart(_catsparse_kernel):
+    """Round 6 (16-bit meta word): blocks hundreds of slabs apart, last slab ragged -- the gather kernel rebuilds every
+    slot's slab from its 6-bit tag and a running slab, the staged kernel walks the slabs themselves; both against the
+    oracle."""
+    from oracle import oracle as orc
+    from tabmat_amd.ext import split as xsplit
+
+    rng = np.random.default_rng(3)
+    n, m = 64 * 700 + 5, 48
+    S = _structured("far_apart_slabs", n, m, rng)
+    d = rng.random(n)
+    csr = CsrDev(torch.from_numpy(S.data.copy()).cuda(), torch.from_numpy(S.indices.astype(np.int32)).cuda(),
+                 torch.from_numpy(S.indptr.astype(np.int64)).cuda(), n, m)
+    tw = SlabEnt.from_csr(csr, max_pad=1e9)
+    cats, refs = [], []
+    for lv in (9, 4):
+        codes = rng.integers(0, lv, n).astype(np.int32)
+        cats.append((torch.from_numpy(codes).cuda(), lv, False))
+        refs.append(orc.sandwich_cat_sparse(codes, lv, d, S.tocsr(), None, None, None))
+    for pk in (None, xsplit.pack_codes(cats)):
+        got = xsplit.multi_cat_sparse_sandwich_ent(cats, torch.from_numpy(d).cuda(), tw, pk).cpu().numpy()
+        want = np.vstack(refs)
+        assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
